@@ -1,0 +1,91 @@
+"""ctypes binding of libadvgrpo_hip.so (the C ABI declared in include/advgrpo.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C adv_grpo_amd/csrc``.
+There is NO CPU fallback: if the shared object is missing or a symbol cannot be resolved the
+import of any product module that needs a kernel raises, loudly.
+"""
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p, POINTER
+
+import torch
+
+F32, BF16, F64 = 0, 1, 2
+SDE_EPS, SDE_PHILOX, SDE_REPLAY = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadvgrpo_hip.so")
+
+_P = c_void_p
+# name -> (restype, argtypes); must list every function include/advgrpo.h declares
+SIGNATURES = {
+    "advgrpo_abi_version": (c_int, []),
+    "advgrpo_last_error": (ctypes.c_char_p, []),
+    "advgrpo_randn": (c_int, [_P, c_int, c_int64, c_uint64, c_uint64, _P]),
+    "advgrpo_sde_step_workspace_bytes": (c_int64, [c_int, c_int64]),
+    "advgrpo_sde_step": (c_int, [_P, _P, c_int, c_float, _P, c_int, _P, _P, c_int, c_float, c_int, _P, c_uint64,
+                                 c_uint64, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int64, _P]),
+    "advgrpo_sde_step_bwd": (c_int, [_P, _P, c_int, c_float, _P, c_int, _P, _P, c_int, c_float, _P, c_int, _P, _P,
+                                     _P, c_int, c_int64, _P]),
+    "advgrpo_group_advantage": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P]),
+    "advgrpo_grpo_loss": (c_int, [_P, _P, _P, c_int, c_float, c_float, _P, _P, _P]),
+}
+
+
+class AdvGrpoError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the HIP library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AdvGrpoError(
+            f"{LIB_PATH} not found: build the gfx950 kernels first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C adv_grpo_amd/csrc). "
+            "adv_grpo_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: intended
+        fn.restype = res
+        fn.argtypes = args
+    if lib.advgrpo_abi_version() != 1:
+        raise AdvGrpoError(f"ABI version mismatch: library {lib.advgrpo_abi_version()} != binding 1")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise AdvGrpoError(load().advgrpo_last_error().decode() or f"advgrpo call failed ({rc})")
+
+
+def dtype_code(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    if t == torch.float64:
+        return F64
+    raise AdvGrpoError(f"unsupported dtype {t}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise AdvGrpoError("adv_grpo_amd kernels take device tensors (got a CPU tensor); there is no CPU path")
+    if not t.is_contiguous():
+        raise AdvGrpoError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream_ptr(stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return s.cuda_stream

@@ -1,0 +1,113 @@
+// common.hpp -- shared device helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/advgrpo.h"
+
+namespace advgrpo {
+
+// ---- error reporting (thread-local message, negative return codes)
+void set_error(const char* fmt, ...);
+#define ADVGRPO_CHECK(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            advgrpo::set_error(__VA_ARGS__); \
+            return -1;                      \
+        }                                   \
+    } while (0)
+#define ADVGRPO_LAUNCH_CHECK()                                                        \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            advgrpo::set_error("%s:%d launch failed: %s", __FILE__, __LINE__,         \
+                               hipGetErrorString(e__));                               \
+            return -2;                                                                \
+        }                                                                             \
+    } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved), bit-identical to torch's cast
+__host__ __device__ inline float bf2f(uint16_t h) {
+    union { uint32_t u; float f; } c; c.u = (uint32_t)h << 16; return c.f;
+}
+__host__ __device__ inline uint16_t f2bf(float f) {
+    union { uint32_t u; float f; } c; c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ inline float round_bf16(float f) { return bf2f(f2bf(f)); }
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+
+// ---- wave / block reductions (64-lane wave)
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// sum over a block of NW waves; result valid in every thread. smem: >= NW floats.
+template <int NW>
+__device__ inline float block_sum(float v, float* smem) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r += smem[i];
+    return r;
+}
+
+inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+inline int dtype_size(int dt) { return dt == ADVGRPO_BF16 ? 2 : (dt == ADVGRPO_F64 ? 8 : 4); }
+
+// ---- Philox4x32-10
+struct Philox {
+    uint32_t k0, k1;
+    __device__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+    __device__ inline void operator()(uint64_t ctr, uint32_t out[4]) const {
+        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+            const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+            const uint32_t n0 = hi1 ^ c1 ^ a, n2 = hi0 ^ c3 ^ b;
+            c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+            a += 0x9E3779B9u; b += 0xBB67AE85u;
+        }
+        out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    }
+};
+// four standard normals from one Philox block (Box-Muller)
+__device__ inline void philox_normal4(const Philox& ph, uint64_t ctr, float z[4]) {
+    uint32_t r[4];
+    ph(ctr, r);
+    const float k = 2.3283064365386963e-10f;  // 2^-32
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float u1 = ((float)r[2 * p] + 0.5f) * k;
+        const float u2 = ((float)r[2 * p + 1] + 0.5f) * k;
+        const float rad = sqrtf(-2.0f * logf(fminf(fmaxf(u1, 1e-30f), 1.0f)));
+        float s, c;
+        sincosf(6.283185307179586f * u2, &s, &c);
+        z[2 * p] = rad * c;
+        z[2 * p + 1] = rad * s;
+    }
+}
+
+}  // namespace advgrpo

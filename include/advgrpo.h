@@ -1,0 +1,105 @@
+/*
+ * advgrpo.h -- C ABI of libadvgrpo_hip.so: the MI355X (gfx950) kernels behind the Adv-GRPO
+ * SD3 rollout-and-update hot path.
+ *
+ * The reference (showlab/Adv-GRPO) is 100 % Python and owns no native boundary; each entry
+ * point below names the reference Python site(s) it replaces (paths relative to the upstream
+ * checkout).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a caller-owned DEVICE pointer unless the name ends in _host;
+ *     outputs are pre-allocated by the caller; no entry point allocates, frees or synchronises
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on that stream and
+ *     thread-safe for distinct streams (the reward scorers are called from worker threads,
+ *     scripts/train_sd3_fast_pickscore.py:668,816-817)
+ *   - return 0 on success, <0 on error (message: advgrpo_last_error(), thread-local)
+ *   - tensors are dense row-major; dtype codes below; "tokens" layouts are [rows, features]
+ */
+#ifndef ADVGRPO_H
+#define ADVGRPO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADVGRPO_ABI_VERSION 1
+
+enum advgrpo_dtype { ADVGRPO_F32 = 0, ADVGRPO_BF16 = 1, ADVGRPO_F64 = 2 };
+
+int advgrpo_abi_version(void);
+const char* advgrpo_last_error(void);
+
+/* ------------------------------------------------------------------ RNG
+ * Philox4x32-10 standard normals, element i uses counter (offset + i/4).  Replaces the
+ * global-device-RNG draws of prepare_latents (sd3_pipeline_with_logprob_fast.py:559-568) and
+ * randn_tensor (sd3_sde_with_logprob.py:125-130).  Not bit-compatible with torch's stream
+ * (SURVEY.md section 7 "RNG parity"): parity tests inject epsilon instead. */
+int advgrpo_randn(void* out, int out_dtype, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* ------------------------------------------------------------------ SDE step
+ * Fused CFG combine + Flow-CPS SDE step + per-sample Gaussian log-prob.
+ * Replaces sd3_pipeline_with_logprob_fast.py:640-655 (CFG, step, cast back) and
+ * sd3_sde_with_logprob.py:77-139; in replay mode, train_sd3_fast_pickscore.py:242-265.
+ *
+ *   v      = v_text ? v_uncond + guidance*(v_text - v_uncond) : v_uncond     (in v_dtype; bf16 =>
+ *            three bf16 roundings exactly like the three torch ops), then promoted to f32
+ *   std    = sigma_prev * sin_coeff          sin_coeff = (float)sin(noise_level*pi/2), host-side
+ *   mean   = (x - sigma*v)*(1-sigma_prev) + (x + v*(1-sigma))*sqrt(sigma_prev^2 - std^2)
+ *   next   = mode==REPLAY ? prev_sample : mean + std*eps
+ *   log_prob[b] = mean_over_n( -(next-mean)^2 )
+ * All f32, one rounding per reference op (no FMA contraction): mean/next are bit-exact with the
+ * reference's torch-CPU result; log_prob differs only by summation order.
+ *
+ * sigma / sigma_prev: device f32, element b*sigma_stride (stride 0 = one value for all samples).
+ * eps: f32 [B,n] (mode EPS) ; seed/offset (mode PHILOX); prev_sample [B,n] in prev_dtype (REPLAY).
+ * out_next_f32, out_next_cast (dtype out_cast_dtype), out_mean: optional (NULL to skip).
+ * workspace: >= advgrpo_sde_step_workspace_bytes(B, n) bytes. */
+enum advgrpo_sde_mode { ADVGRPO_SDE_EPS = 0, ADVGRPO_SDE_PHILOX = 1, ADVGRPO_SDE_REPLAY = 2 };
+
+int64_t advgrpo_sde_step_workspace_bytes(int B, int64_t n);
+
+int advgrpo_sde_step(const void* v_uncond, const void* v_text, int v_dtype, float guidance_scale,
+                     const void* x, int x_dtype,
+                     const float* sigma, const float* sigma_prev, int sigma_stride, float sin_coeff,
+                     int mode, const float* eps, uint64_t seed, uint64_t offset,
+                     const void* prev_sample, int prev_dtype,
+                     float* out_next_f32, void* out_next_cast, int out_cast_dtype,
+                     float* out_mean, float* out_log_prob, float* out_std,
+                     void* workspace, int B, int64_t n, void* stream);
+
+/* Backward of the replay-mode step w.r.t. the two CFG halves of the transformer output
+ * (autograd of train_sd3_fast_pickscore.py:242-265 as reached from loss.backward(), :1165):
+ *   g_v = grad_log_prob[b] * 2*(prev-mean)/n * ((1-sigma)*sqrt(sigma_prev^2-std^2) - sigma*(1-sigma_prev))
+ *   grad_v_text = guidance*g_v ; grad_v_uncond = (1-guidance)*g_v      (written in v_dtype)
+ * Without CFG (v_text NULL) grad_v_uncond = g_v and grad_v_text is ignored. */
+int advgrpo_sde_step_bwd(const void* v_uncond, const void* v_text, int v_dtype, float guidance_scale,
+                         const void* x, int x_dtype,
+                         const float* sigma, const float* sigma_prev, int sigma_stride, float sin_coeff,
+                         const void* prev_sample, int prev_dtype, const float* grad_log_prob,
+                         void* grad_v_uncond, void* grad_v_text, int B, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------ group advantage
+ * PerPromptStatTracker.update(type='grpo') on a fresh tracker -- adv_grpo/stat_tracking.py:18-47:
+ * float64, per-group mean over rows, std = global (np.std over all rows, per column) or
+ * per-group, +1e-4; adv = (r - mean_g)/std.  group_id replaces the decoded prompt strings
+ * (train_sd3_fast_pickscore.py:960-970): any int32 key, equal key <=> same prompt.
+ * rewards: [N,T] in rewards_dtype (F32 as gathered, or F64); out_adv: [N,T] f64.
+ * Sums run in row order like numpy's axis-0 reduction, so results are bit-exact with it. */
+int advgrpo_group_advantage(const void* rewards, int rewards_dtype, const int32_t* group_id,
+                            int N, int T, int global_std, double* out_adv, void* stream);
+
+/* ------------------------------------------------------------------ GRPO loss
+ * Clipped surrogate forward + backward + diagnostics, train_sd3_fast_pickscore.py:1111-1162
+ * (beta == 0).  log_prob/old_log_prob/advantages: f32 [B].
+ * out_scalars[6] = {loss, approx_kl, clipfrac, clipfrac_gt_one, clipfrac_lt_one, policy_loss};
+ * out_grad_log_prob[B] = d loss / d log_prob (NULL to skip). */
+int advgrpo_grpo_loss(const float* log_prob, const float* old_log_prob, const float* advantages,
+                      int B, float adv_clip_max, float clip_range,
+                      float* out_scalars, float* out_grad_log_prob, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADVGRPO_H */
