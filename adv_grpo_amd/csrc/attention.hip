@@ -1,0 +1,257 @@
+// attention.hip -- fused softmax(Q K^T * scale) V for gfx950 (flash-style, bf16 in/out, f32 math).
+//
+// Serves the joint image+text attention of the MMDiT blocks (1229 tokens at 512^2, 24 heads x 64;
+// reference call sites sd3_pipeline_with_logprob_fast.py:630-637 / train_sd3_fast_pickscore.py:235-255
+// via diffusers' JointAttnProcessor2_0 -> F.scaled_dot_product_attention) and the ViT reward
+// towers (DINOv2-B 1370 tokens, 12 heads x 64; CLIP text 77 tokens causal).
+//
+// CDNA4 mapping (wave64, v_mfma_f32_16x16x32_bf16):
+//   * workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 queries.
+//   * S^T = K Q^T is computed with K as the MFMA A operand, so a lane holds scores of ONE query
+//     (column lane&15) for 16 keys: row max / row sum are in-lane plus two cross-lane steps, and
+//     the probabilities are already in the B-operand layout of the P V product -- no LDS round
+//     trip and no permutes between the two MFMAs (the key order inside a 32-deep MFMA step is
+//     permuted consistently on the P and the V side, which a sum over keys does not see).
+//   * V^T fragments come from the row-major V tile through ds_read_b64_tr_b16 (hardware
+//     transpose), K fragments through ds_read_b128; both tiles use a 144-byte row pitch, which
+//     spreads the 16 rows of a fragment over all 16-byte bank slots.
+//   * K/V tiles are register staged: the next tile's global loads are issued before the current
+//     tile's MFMAs and written to the other LDS buffer afterwards (one barrier per tile).
+//   * O is kept transposed in the accumulators (lane = one query, 4 consecutive d): the online
+//     softmax rescale is a per-lane scalar and the epilogue is an 8-byte bf16x4 store per lane.
+#include "common.hpp"
+#include "gemm.hpp"
+
+namespace advgrpo {
+
+struct AttnParams {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
+    int64_t ldq, ldk, ldv, ldo;   // row pitch (elements)
+    int64_t bsq, bsk, bsv, bso;   // batch pitch (elements)
+    int H, Sq, Skv;
+    float scale_log2e;            // softmax scale * log2(e)
+    int causal;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+constexpr int ATT_QB = 128;   // queries per workgroup
+constexpr int ATT_KB = 64;    // keys per tile
+constexpr int ATT_PITCH = 72; // LDS row pitch in elements (144 B)
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) {
+    static_assert(HD == 64, "head dim 64");
+    constexpr int TILE = ATT_KB * ATT_PITCH;  // elements per K or V tile
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * TILE];  // K0 K1 V0 V1
+    bf16_t* Ks = smem;
+    bf16_t* Vs = smem + 2 * TILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, t = lane & 15;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * ATT_QB + wave * 32;
+
+    const bf16_t* qp = p.q + (int64_t)b * p.bsq + h * HD;
+    const bf16_t* kp = p.k + (int64_t)b * p.bsk + h * HD;
+    const bf16_t* vp = p.v + (int64_t)b * p.bsv + h * HD;
+
+    // ---- Q fragments (B operand: lane = query t, 8 consecutive d at (ks*32 + g*8))
+    bf16x8_t qf[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        int qr = q0 + qb * 16 + t;
+        qr = qr < p.Sq ? qr : p.Sq - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[qb][ks] = *reinterpret_cast<const bf16x8_t*>(qp + (int64_t)qr * p.ldq + ks * 32 + g * 8);
+    }
+
+    // ---- staging: 512 16-byte chunks per tile, 2 per thread for K and for V
+    const int srow0 = tid >> 3, scol = (tid & 7) * 8;  // second chunk: row + 32
+    uint4 kreg[2], vreg[2];
+    auto issue = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r = kv0 + srow0 + i * 32;
+            r = r < p.Skv ? r : p.Skv - 1;
+            kreg[i] = *reinterpret_cast<const uint4*>(kp + (int64_t)r * p.ldk + scol);
+            vreg[i] = *reinterpret_cast<const uint4*>(vp + (int64_t)r * p.ldv + scol);
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int off = (srow0 + i * 32) * ATT_PITCH + scol;
+            *reinterpret_cast<uint4*>(Ks + buf * TILE + off) = kreg[i];
+            *reinterpret_cast<uint4*>(Vs + buf * TILE + off) = vreg[i];
+        }
+    };
+
+    f32x4 o[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+    int kv_end = p.Skv;
+    if (p.causal) {  // keys <= last query of the workgroup
+        const int last_q = min(blockIdx.x * ATT_QB + ATT_QB, p.Sq) - 1;
+        kv_end = min(kv_end, last_q + 1);
+    }
+    const int nt = (kv_end + ATT_KB - 1) / ATT_KB;
+
+    issue(0);
+    commit(0);
+    __syncthreads();
+    for (int it = 0; it < nt; ++it) {
+        const int buf = it & 1, kv0 = it * ATT_KB;
+        if (it + 1 < nt) issue(kv0 + ATT_KB);
+        const bf16_t* Kt = Ks + buf * TILE;
+        const bf16_t* Vt = Vs + buf * TILE;
+
+        // ---- S^T[key][q] = K Q^T
+        f32x4 s[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t kf[4];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+                kf[kb] = *reinterpret_cast<const bf16x8_t*>(Kt + (kb * 16 + t) * ATT_PITCH + ks * 32 + g * 8);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+                    s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb][ks], s[kb][qb], 0, 0, 0);
+        }
+        // lane holds S[key = kv0 + kb*16 + g*4 + r][query = q0 + qb*16 + t]
+        const bool edge = (kv0 + ATT_KB > p.Skv) || p.causal;
+        if (edge) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kv0 + kb * 16 + g * 4 + r;
+                        const int qi = q0 + qb * 16 + t;
+                        if (key >= p.Skv || (p.causal && key > qi)) s[kb][qb][r] = -INFINITY;
+                    }
+        }
+        // ---- online softmax (base-2), per query block
+        bf16x8_t pf[2][2];  // [qb][key pair]
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qb], mx * p.scale_log2e);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
+            m_run[qb] = m_new;
+            float psum = 0.f;
+            float pv[4][4];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[kb][qb][r] * p.scale_log2e - m_use);
+                    pv[kb][r] = e;
+                    psum += e;
+                }
+            l_run[qb] = l_run[qb] * alpha + psum;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) o[db][qb] *= alpha;
+#pragma unroll
+            for (int kpair = 0; kpair < 2; ++kpair) {
+                bf16x8_t f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f[r] = (__bf16)pv[2 * kpair][r];
+                    f[4 + r] = (__bf16)pv[2 * kpair + 1][r];
+                }
+                pf[qb][kpair] = f;
+            }
+        }
+        // ---- O^T[d][q] += V^T P^T ; A operand = V^T via transpose reads
+#pragma unroll
+        for (int kpair = 0; kpair < 2; ++kpair) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const bf16_t* a0 = Vt + ((2 * kpair) * 16 + g * 4 + (t >> 2)) * ATT_PITCH + db * 16 + (t & 3) * 4;
+                const bf16_t* a1 = a0 + 16 * ATT_PITCH;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(a0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(a1));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, both);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][kpair], o[db][qb], 0, 0, 0);
+            }
+        }
+        if (it + 1 < nt) commit(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: normalise and store bf16x4 (query t, d = db*16 + g*4 .. +3)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float l = l_run[qb];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        const int qi = q0 + qb * 16 + t;
+        if (qi >= p.Sq) continue;
+        bf16_t* op = p.o + (int64_t)b * p.bso + (int64_t)qi * p.ldo + h * HD + g * 4;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const f32x4 v = o[db][qb] * inv;
+            uint2 pk;
+            pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(op + db * 16) = pk;
+        }
+    }
+}
+
+int attention_fwd(const AttnParams& p, int B, int head_dim, hipStream_t s) {
+    ADVGRPO_CHECK(head_dim == 64, "attention: head_dim %d not supported (64 only)", head_dim);
+    ADVGRPO_CHECK(p.q && p.k && p.v && p.o, "attention: null pointer");
+    ADVGRPO_CHECK(p.Sq > 0 && p.Skv > 0 && p.H > 0 && B > 0, "attention: bad shape");
+    ADVGRPO_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0,
+                  "attention: row pitches must keep 16-byte (q,k,v) / 8-byte (o) alignment");
+    dim3 grid((p.Sq + ATT_QB - 1) / ATT_QB, p.H, B);
+    hipLaunchKernelGGL(attention_fwd_kernel<64>, grid, dim3(256), 0, s, p);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace advgrpo
+
+using namespace advgrpo;
+
+extern "C" int advgrpo_attention_fwd(const void* q, const void* k, const void* v, void* o, int64_t ldq, int64_t ldk,
+                                     int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso,
+                                     int B, int H, int Sq, int Skv, int head_dim, float scale, int causal,
+                                     void* stream) {
+    AttnParams p{};
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.bsq = bsq; p.bsk = bsk; p.bsv = bsv; p.bso = bso;
+    p.H = H; p.Sq = Sq; p.Skv = Skv;
+    p.scale_log2e = scale * 1.4426950408889634f;
+    p.causal = causal;
+    return attention_fwd(p, B, head_dim, as_stream(stream));
+}

@@ -1,0 +1,27 @@
+// gemm.hpp -- parameter block of the bf16 MFMA GEMM family (internal C++ interface).
+#pragma once
+#include "common.hpp"
+
+namespace advgrpo {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3 };
+
+struct GemmParams {
+    const bf16_t* A; const bf16_t* W; void* C;
+    int64_t lda, ldw, ldc;
+    int out_dtype;
+    int M, N, K;
+    // epilogue: y = act(alpha*acc + bias[n]); y *= gate[gb, n]; y += residual[orow, n]
+    const bf16_t* bias; int act; float alpha;
+    const bf16_t* gate; int64_t gate_stride; int gate_rows; int64_t gate_batch_stride;  // gb = m / gate_rows
+    const bf16_t* residual; int64_t ldr; int64_t strideR;
+    // output row map: orow = (m / seg_rows) * seg_stride + seg_off + m % seg_rows   (seg_rows = 0: identity)
+    int seg_rows; int64_t seg_stride, seg_off;
+    int batch; int64_t strideA, strideW, strideC;
+};
+
+int gemm_bf16(const GemmParams& p, hipStream_t stream);
+
+}  // namespace advgrpo

@@ -99,6 +99,36 @@ int advgrpo_grpo_loss(const float* log_prob, const float* old_log_prob, const fl
                       int B, float adv_clip_max, float clip_range,
                       float* out_scalars, float* out_grad_log_prob, void* stream);
 
+/* ------------------------------------------------------------------ dense contraction
+ * C[M,N] = epilogue(A[M,K] . W[N,K]^T): bf16 operands (K contiguous, torch nn.Linear weight
+ * layout), f32 accumulation on v_mfma_f32_16x16x32_bf16.  Carries every nn.Linear the hot path
+ * reaches inside diffusers' SD3Transformer2DModel (sd3_pipeline_with_logprob_fast.py:630-637,
+ * train_sd3_fast_pickscore.py:235-255), transformers' CLIPModel (adv_grpo/pickscore_scorer.py:40-44)
+ * and timm's DINOv2 (adv_grpo/rewards.py:397).
+ *   y = act(alpha*acc + bias[n]);  y *= gate[(m / gate_rows)*gate_stride + n];  y += residual[orow*ldr + n]
+ *   orow = seg_rows ? (m / seg_rows)*seg_stride + seg_off + m % seg_rows : m      (row-segment scatter)
+ * bias/gate/residual: bf16, optional (NULL).  act: 0 none, 1 GELU(tanh), 2 GELU(erf), 3 SiLU.
+ * out_dtype: BF16 or F32.  K % 64 == 0; lda/ldw % 8 == 0.  batch > 1: grid-batched with element
+ * strides (residual uses strideC). */
+int advgrpo_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                      int out_dtype, int M, int N, int K, const void* bias, int act, float alpha,
+                      const void* gate, int64_t gate_stride, int gate_rows, const void* residual,
+                      int64_t ldr, int seg_rows, int64_t seg_stride, int64_t seg_off, int batch,
+                      int64_t strideA, int64_t strideW, int64_t strideC, void* stream);
+
+/* ------------------------------------------------------------------ fused attention
+ * o = softmax(q k^T * scale [+ causal mask]) v per (batch, head); bf16 in/out, f32 softmax.
+ * Replaces F.scaled_dot_product_attention as reached through the transformer / ViT calls
+ * (sd3_pipeline_with_logprob_fast.py:630-637; adv_grpo/rewards.py:397; pickscore_scorer.py:40-44).
+ * q/k/v/o are [B, S, H*head_dim]-shaped VIEWS: element (b, s, h, d) at
+ * ptr + b*bs + s*ld + h*head_dim + d, so packed QKV GEMM outputs are consumed in place.
+ * head_dim: 64.  ld{q,k,v} % 8 == 0, ldo % 4 == 0. */
+int advgrpo_attention_fwd(const void* q, const void* k, const void* v, void* o,
+                          int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                          int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso,
+                          int B, int H, int Sq, int Skv, int head_dim, float scale, int causal,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif
