@@ -30,8 +30,16 @@ SIGNATURES = {
     "advgrpo_group_advantage": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P]),
     "advgrpo_grpo_loss": (c_int, [_P, _P, _P, c_int, c_float, c_float, _P, _P, _P]),
     "advgrpo_gemm_bf16": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_int, _P, c_int,
-                                  c_float, _P, c_int64, c_int, _P, c_int64, c_int, c_int64, c_int64, c_int,
-                                  c_int64, c_int64, c_int64, _P]),
+                                  c_float, _P, c_int64, c_int, _P, c_int64, c_int, c_int64, c_int64, c_int, c_int64,
+                                  c_int64, c_int, c_int64, c_int64, c_int64, _P]),
+    "advgrpo_layernorm_mod": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int,
+                                      c_int, c_float, _P]),
+    "advgrpo_rmsnorm_heads": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int, c_float, c_int, c_int64, c_int64,
+                                      _P]),
+    "advgrpo_timestep_embedding": (c_int, [_P, _P, c_int, c_int, _P]),
+    "advgrpo_unary": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
+    "advgrpo_patchify": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "advgrpo_unpatchify": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "advgrpo_attention_fwd": (c_int, [_P, _P, _P, _P] + [c_int64] * 8 + [c_int] * 5 + [c_float, c_int, _P]),
 }
 

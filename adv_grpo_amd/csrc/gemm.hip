@@ -79,7 +79,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     for (int it = 0; it < A_INST; ++it) {
         int r = m0 + (wave + it * 4) * 8 + lrow;
         r = r < p.M ? r : p.M - 1;
-        a_src[it] = A + (int64_t)r * p.lda + schunk * 8;
+        int64_t ar = r;
+        if (p.a_seg_rows > 0) {
+            const int bi = r / p.a_seg_rows;
+            ar = (int64_t)bi * p.a_seg_stride + p.a_seg_off + (r - bi * p.a_seg_rows);
+        }
+        a_src[it] = A + ar * p.lda + schunk * 8;
     }
 #pragma unroll
     for (int it = 0; it < B_INST; ++it) {
@@ -226,8 +231,9 @@ using namespace advgrpo;
 extern "C" int advgrpo_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                                  int out_dtype, int M, int N, int K, const void* bias, int act, float alpha,
                                  const void* gate, int64_t gate_stride, int gate_rows, const void* residual,
-                                 int64_t ldr, int seg_rows, int64_t seg_stride, int64_t seg_off, int batch,
-                                 int64_t strideA, int64_t strideW, int64_t strideC, void* stream) {
+                                 int64_t ldr, int seg_rows, int64_t seg_stride, int64_t seg_off, int a_seg_rows,
+                                 int64_t a_seg_stride, int64_t a_seg_off, int batch, int64_t strideA,
+                                 int64_t strideW, int64_t strideC, void* stream) {
     GemmParams p{};
     p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C;
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.out_dtype = out_dtype;
@@ -236,6 +242,7 @@ extern "C" int advgrpo_gemm_bf16(const void* A, int64_t lda, const void* W, int6
     p.gate = (const bf16_t*)gate; p.gate_stride = gate_stride; p.gate_rows = gate_rows; p.gate_batch_stride = 0;
     p.residual = (const bf16_t*)residual; p.ldr = ldr; p.strideR = strideC;
     p.seg_rows = seg_rows; p.seg_stride = seg_stride; p.seg_off = seg_off;
+    p.a_seg_rows = a_seg_rows; p.a_seg_stride = a_seg_stride; p.a_seg_off = a_seg_off;
     p.batch = batch < 1 ? 1 : batch; p.strideA = strideA; p.strideW = strideW; p.strideC = strideC;
     return gemm_bf16(p, as_stream(stream));
 }

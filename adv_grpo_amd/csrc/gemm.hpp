@@ -19,6 +19,8 @@ struct GemmParams {
     const bf16_t* residual; int64_t ldr; int64_t strideR;
     // output row map: orow = (m / seg_rows) * seg_stride + seg_off + m % seg_rows   (seg_rows = 0: identity)
     int seg_rows; int64_t seg_stride, seg_off;
+    // input row map for A (same formula), e.g. reading the image rows out of a joint image+text buffer
+    int a_seg_rows; int64_t a_seg_stride, a_seg_off;
     int batch; int64_t strideA, strideW, strideC;
 };
 

@@ -1,0 +1,274 @@
+// norm.hip -- HBM-bound row kernels of the transformer / ViT blocks for gfx950.
+//
+//   layernorm_mod : out = (LN(x) [* w + b]) * (1 + scale[batch]) + shift[batch]   (one or two outputs)
+//                   = diffusers AdaLayerNormZero / AdaLayerNormContinuous / nn.LayerNorm as reached
+//                   through sd3_pipeline_with_logprob_fast.py:630-637 (MMDiT) and the ViT towers.
+//   rmsnorm_heads : in-place per-head RMSNorm(64) * weight on the q and k slices of a packed QKV
+//                   buffer (qk_norm="rms_norm" of the SD3.5 attention).
+//   timestep_embedding, silu, patchify / unpatchify, l2norm rows.
+//
+// Shape of the work: every row is read once from HBM with 16-byte lane loads (8 bf16), kept in
+// registers for the two-pass mean/variance, reduced with wave64 shuffles (one row per wave, four
+// rows per workgroup), and written once -- 4 B of traffic per element against ~10 flops: purely
+// bandwidth bound, so no LDS staging and no MFMA.
+#include "common.hpp"
+
+namespace advgrpo {
+
+constexpr int LN_MAX_CHUNKS = 4;  // 8-element chunks per lane => D <= 2048
+
+__device__ inline void unpack8(const uint4& r, float o[8]) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        o[2 * k] = bf2f((bf16_t)(w[k] & 0xffffu));
+        o[2 * k + 1] = bf2f((bf16_t)(w[k] >> 16));
+    }
+}
+__device__ inline uint4 pack8(const float o[8]) {
+    uint4 r;
+    r.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+    r.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+    r.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
+    r.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+    return r;
+}
+
+struct LnParams {
+    const bf16_t* x; int64_t ldx;
+    bf16_t* out0; bf16_t* out1; int64_t ldo;
+    const bf16_t* w; const bf16_t* b;           // optional affine [D]
+    const bf16_t* scale0; const bf16_t* shift0; // optional modulation, row m uses [(m / rows_per_batch) * mod_stride + d]
+    const bf16_t* scale1; const bf16_t* shift1; // second modulation for out1
+    int64_t mod_stride; int rows_per_batch;
+    int M, D; float eps;
+};
+
+__global__ __launch_bounds__(256) void layernorm_mod_kernel(const LnParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int nch = p.D >> 3;
+    float v[LN_MAX_CHUNKS][8];
+    const bf16_t* xr = p.x + (int64_t)row * p.ldx;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), v[i]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += v[i][k];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)p.D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float d = v[i][k] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
+    const int64_t mrow = p.rows_per_batch > 0 ? (int64_t)(row / p.rows_per_batch) * p.mod_stride : 0;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int c = lane + i * 64;
+        if (c >= nch) continue;
+        float n[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) n[k] = (v[i][k] - mean) * rstd;
+        if (p.w) {
+            float w[8], bb[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.w + c * 8), w);
+            if (p.b) unpack8(*reinterpret_cast<const uint4*>(p.b + c * 8), bb);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) n[k] = n[k] * w[k] + (p.b ? bb[k] : 0.f);
+        }
+        float o[8];
+        if (p.scale0) {
+            float sc[8], sh[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.scale0 + mrow + c * 8), sc);
+            unpack8(*reinterpret_cast<const uint4*>(p.shift0 + mrow + c * 8), sh);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = n[k] * (1.0f + sc[k]) + sh[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = n[k];
+        }
+        *reinterpret_cast<uint4*>(p.out0 + (int64_t)row * p.ldo + c * 8) = pack8(o);
+        if (p.out1) {
+            float sc[8], sh[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.scale1 + mrow + c * 8), sc);
+            unpack8(*reinterpret_cast<const uint4*>(p.shift1 + mrow + c * 8), sh);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = n[k] * (1.0f + sc[k]) + sh[k];
+            *reinterpret_cast<uint4*>(p.out1 + (int64_t)row * p.ldo + c * 8) = pack8(o);
+        }
+    }
+}
+
+// in-place RMSNorm over 64-wide heads: buffer rows [M, ld], heads at columns [col0, col0 + nheads*64);
+// head hh uses weight w[(hh / heads_per_weight) * 64 ...] (q heads then k heads => heads_per_weight = H)
+__global__ __launch_bounds__(256) void rmsnorm_heads_kernel(bf16_t* __restrict__ buf, int64_t ld, int M, int col0,
+                                                            int nheads, const bf16_t* __restrict__ w,
+                                                            int heads_per_weight, float eps, int seg_rows,
+                                                            int64_t seg_stride, int64_t seg_off) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    int64_t row = m;
+    if (seg_rows > 0) row = (int64_t)(m / seg_rows) * seg_stride + seg_off + (m % seg_rows);
+    bf16_t* r = buf + row * ld + col0;
+    const int sub = lane & 7;  // 8 lanes x 8 elements = one head
+    for (int h0 = 0; h0 < nheads; h0 += 8) {
+        const int hh = h0 + (lane >> 3);
+        if (hh >= nheads) break;  // trailing lanes idle (nheads is a multiple of 8 for every model here)
+        float v[8], ww[8];
+        unpack8(*reinterpret_cast<const uint4*>(r + hh * 64 + sub * 8), v);
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sq += v[k] * v[k];
+        sq += __shfl_xor(sq, 1, 64);
+        sq += __shfl_xor(sq, 2, 64);
+        sq += __shfl_xor(sq, 4, 64);
+        const float rs = rsqrtf(sq * (1.0f / 64.0f) + eps);
+        unpack8(*reinterpret_cast<const uint4*>(w + (hh / heads_per_weight) * 64 + sub * 8), ww);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = round_bf16(v[k] * rs) * ww[k];  // x.to(bf16) * weight
+        *reinterpret_cast<uint4*>(r + hh * 64 + sub * 8) = pack8(v);
+    }
+}
+
+// sinusoidal timestep embedding, diffusers get_timestep_embedding(t, 256, flip_sin_to_cos=True,
+// downscale_freq_shift=0): [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(1e4) i / 128); optional SiLU-free.
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, int B, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= B * half) return;
+    const int b = i / half, k = i % half;
+    const float f = expf(-9.210340371976184f * (float)k / (float)half);
+    const float a = t[b] * f;
+    out[(int64_t)b * dim + k] = f2bf(cosf(a));
+    out[(int64_t)b * dim + half + k] = f2bf(sinf(a));
+}
+
+// y = act(x [+ x2]) elementwise on bf16 (n % 8 == 0)
+__global__ __launch_bounds__(256) void unary_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ x2,
+                                                    bf16_t* __restrict__ y, int64_t n, int act) {
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n;
+         i += (int64_t)gridDim.x * blockDim.x * 8) {
+        float v[8], u[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + i), v);
+        if (x2) {
+            unpack8(*reinterpret_cast<const uint4*>(x2 + i), u);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += u[k];
+        }
+        if (act == 3) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = v[k] / (1.0f + __expf(-v[k]));
+        }
+        *reinterpret_cast<uint4*>(y + i) = pack8(v);
+    }
+}
+
+// latents [B,C,H,W] (f32 or bf16) -> patch rows [B*(H/2)*(W/2), C*4] bf16, column = c*4 + py*2 + px
+// (= Conv2d(C, D, k=2, s=2) weight flattened [D, C*2*2])
+__global__ void patchify_kernel(const void* __restrict__ x, int x_dt, bf16_t* __restrict__ out, int B, int C, int H,
+                                int W) {
+    const int64_t total = (int64_t)B * C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = i % W, h = (i / W) % H, c = (i / ((int64_t)W * H)) % C, b = i / ((int64_t)W * H * C);
+        const float v = x_dt == ADVGRPO_BF16 ? bf2f(reinterpret_cast<const bf16_t*>(x)[i])
+                                             : reinterpret_cast<const float*>(x)[i];
+        const int64_t tok = ((int64_t)b * (H / 2) + h / 2) * (W / 2) + w / 2;
+        out[tok * (C * 4) + c * 4 + (h & 1) * 2 + (w & 1)] = f2bf(v);
+    }
+}
+// tokens [B*(H/2)*(W/2), 4*C] (column = (py*2+px)*C + c) -> [B,C,H,W] in out_dt
+__global__ void unpatchify_kernel(const bf16_t* __restrict__ tok, void* __restrict__ out, int out_dt, int B, int C,
+                                  int H, int W) {
+    const int64_t total = (int64_t)B * C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = i % W, h = (i / W) % H, c = (i / ((int64_t)W * H)) % C, b = i / ((int64_t)W * H * C);
+        const int64_t t = ((int64_t)b * (H / 2) + h / 2) * (W / 2) + w / 2;
+        const bf16_t v = tok[t * (C * 4) + ((h & 1) * 2 + (w & 1)) * C + c];
+        if (out_dt == ADVGRPO_BF16) reinterpret_cast<bf16_t*>(out)[i] = v;
+        else reinterpret_cast<float*>(out)[i] = bf2f(v);
+    }
+}
+
+}  // namespace advgrpo
+
+using namespace advgrpo;
+
+extern "C" int advgrpo_layernorm_mod(const void* x, int64_t ldx, void* out0, void* out1, int64_t ldo, const void* w,
+                                     const void* b, const void* scale0, const void* shift0, const void* scale1,
+                                     const void* shift1, int64_t mod_stride, int rows_per_batch, int M, int D,
+                                     float eps, void* stream) {
+    ADVGRPO_CHECK(x && out0, "layernorm_mod: null pointer");
+    ADVGRPO_CHECK(M > 0 && D > 0 && D % 8 == 0 && D <= LN_MAX_CHUNKS * 512, "layernorm_mod: need D %% 8 == 0, D <= %d (D=%d)",
+                  LN_MAX_CHUNKS * 512, D);
+    ADVGRPO_CHECK(ldx % 8 == 0 && ldo % 8 == 0 && mod_stride % 8 == 0, "layernorm_mod: pitches must be multiples of 8");
+    ADVGRPO_CHECK((scale0 == nullptr) == (shift0 == nullptr), "layernorm_mod: scale0/shift0 come together");
+    ADVGRPO_CHECK(!out1 || (scale1 && shift1), "layernorm_mod: out1 needs scale1/shift1");
+    LnParams p{(const bf16_t*)x, ldx, (bf16_t*)out0, (bf16_t*)out1, ldo, (const bf16_t*)w, (const bf16_t*)b,
+               (const bf16_t*)scale0, (const bf16_t*)shift0, (const bf16_t*)scale1, (const bf16_t*)shift1,
+               mod_stride, rows_per_batch, M, D, eps};
+    hipLaunchKernelGGL(layernorm_mod_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_rmsnorm_heads(void* buf, int64_t ld, int M, int col0, int nheads, const void* weight,
+                                     int heads_per_weight, float eps, int seg_rows, int64_t seg_stride,
+                                     int64_t seg_off, void* stream) {
+    ADVGRPO_CHECK(buf && weight && M > 0 && nheads > 0 && heads_per_weight > 0, "rmsnorm_heads: bad argument");
+    ADVGRPO_CHECK(ld % 8 == 0 && col0 % 8 == 0, "rmsnorm_heads: pitch/offset must be multiples of 8");
+    hipLaunchKernelGGL(rmsnorm_heads_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), (bf16_t*)buf, ld, M,
+                       col0, nheads, (const bf16_t*)weight, heads_per_weight, eps, seg_rows, seg_stride, seg_off);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_timestep_embedding(const float* t, void* out, int B, int dim, void* stream) {
+    ADVGRPO_CHECK(t && out && B > 0 && dim > 0 && dim % 2 == 0, "timestep_embedding: bad argument");
+    const int n = B * dim / 2;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), t,
+                       (bf16_t*)out, B, dim);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_unary(const void* x, const void* x2, void* y, int64_t n, int act, void* stream) {
+    ADVGRPO_CHECK(x && y && n > 0 && n % 8 == 0, "unary: need n %% 8 == 0");
+    int64_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(unary_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), (const bf16_t*)x,
+                       (const bf16_t*)x2, (bf16_t*)y, n, act);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_patchify(const void* x, int x_dtype, void* out, int B, int C, int H, int W, void* stream) {
+    ADVGRPO_CHECK(x && out && B > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, "patchify: bad argument");
+    hipLaunchKernelGGL(patchify_kernel, dim3(1024), dim3(256), 0, as_stream(stream), x, x_dtype, (bf16_t*)out, B, C, H,
+                       W);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_unpatchify(const void* tokens, void* out, int out_dtype, int B, int C, int H, int W,
+                                  void* stream) {
+    ADVGRPO_CHECK(tokens && out && B > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, "unpatchify: bad argument");
+    hipLaunchKernelGGL(unpatchify_kernel, dim3(1024), dim3(256), 0, as_stream(stream), (const bf16_t*)tokens, out,
+                       out_dtype, B, C, H, W);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,180 @@
+"""SD3 / SD3.5 MMDiT forward on the gfx950 kernels (host orchestration only).
+
+Stands in for diffusers' ``SD3Transformer2DModel`` at the reference call sites
+adv_grpo/diffusers_patch/sd3_pipeline_with_logprob_fast.py:630-637 and
+scripts/train_sd3_fast_pickscore.py:235-255: same call signature
+``transformer(hidden_states, timestep, encoder_hidden_states, pooled_projections,
+joint_attention_kwargs=None, return_dict=False)[0]``, weights loaded from a diffusers-named
+state dict.
+
+Data layout in HBM (bf16 unless noted), B = batch incl. the CFG halves, S = N_img + N_txt:
+  x   [B*N_img, D]   image residual stream        c   [B*N_txt, D]  text residual stream
+  qkv [B*S, 3D]      joint packed q|k|v: image rows first, then text rows, per sample -- the two
+                     QKV GEMMs scatter straight into it (row-segment epilogue) and the attention
+                     kernel reads the three column slices in place (no torch.cat / transpose)
+  mods [B, N_mod]    every adaLN modulation vector of every block from ONE skinny GEMM per forward
+                     (SiLU(temb) . W_mod^T with all 49 modulation Linears concatenated: 1.5 GB of
+                     weights streamed once instead of 49 launches)
+LoRA (peft r=32, alpha=64 on the attention projections, train_sd3_fast_pickscore.py:490-505) is merged
+into the bf16 weights for the no-grad rollout: W_eff = W + (alpha/r) B A.
+"""
+import torch
+
+from . import ops
+
+
+class SD3Transformer2DModel:
+    def __init__(self, state_dict, cfg, device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.config = type("Cfg", (), {"in_channels": cfg.in_channels})()
+        self._prepare({k: v for k, v in state_dict.items()})
+        self._pos_cache = {}
+
+    # ------------------------------------------------------------------ weight preparation
+    def _prepare(self, sd):
+        cfg, dev = self.cfg, self.device
+        D = cfg.dim
+        bf = lambda t: t.to(device=dev, dtype=torch.bfloat16).contiguous()
+        w = {}
+        w["patch.w"] = bf(sd["pos_embed.proj.weight"].reshape(D, -1))
+        w["patch.b"] = bf(sd["pos_embed.proj.bias"])
+        self.pos_embed = sd["pos_embed.pos_embed"].to(dev)
+        for name in ("time_text_embed.timestep_embedder.linear_1", "time_text_embed.timestep_embedder.linear_2",
+                     "time_text_embed.text_embedder.linear_1", "time_text_embed.text_embedder.linear_2",
+                     "context_embedder", "proj_out"):
+            w[name + ".w"], w[name + ".b"] = bf(sd[name + ".weight"]), bf(sd[name + ".bias"])
+        mod_w, mod_b, self.mod_off = [], [], {}
+        off = 0
+
+        def add_mod(key, name):
+            nonlocal off
+            mod_w.append(sd[name + ".weight"]); mod_b.append(sd[name + ".bias"])
+            self.mod_off[key] = off
+            off += sd[name + ".weight"].shape[0]
+        self.blocks = []
+        for i in range(cfg.num_layers):
+            p = f"transformer_blocks.{i}"
+            dual = i in cfg.dual_attention_layers
+            last = i == cfg.num_layers - 1
+            add_mod(("x", i), f"{p}.norm1.linear")
+            add_mod(("c", i), f"{p}.norm1_context.linear")
+            b = {"dual": dual, "last": last}
+            cat = lambda names: (bf(torch.cat([sd[f"{p}.{n}.weight"] for n in names])),
+                                 bf(torch.cat([sd[f"{p}.{n}.bias"] for n in names])))
+            b["qkv.w"], b["qkv.b"] = cat(["attn.to_q", "attn.to_k", "attn.to_v"])
+            b["cqkv.w"], b["cqkv.b"] = cat(["attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj"])
+            b["rms_x"] = bf(torch.stack([sd[f"{p}.attn.norm_q.weight"], sd[f"{p}.attn.norm_k.weight"]]))
+            b["rms_c"] = bf(torch.stack([sd[f"{p}.attn.norm_added_q.weight"], sd[f"{p}.attn.norm_added_k.weight"]]))
+            b["out.w"], b["out.b"] = bf(sd[f"{p}.attn.to_out.0.weight"]), bf(sd[f"{p}.attn.to_out.0.bias"])
+            if not last:
+                b["cout.w"], b["cout.b"] = bf(sd[f"{p}.attn.to_add_out.weight"]), bf(sd[f"{p}.attn.to_add_out.bias"])
+            if dual:
+                b["qkv2.w"], b["qkv2.b"] = cat(["attn2.to_q", "attn2.to_k", "attn2.to_v"])
+                b["rms_2"] = bf(torch.stack([sd[f"{p}.attn2.norm_q.weight"], sd[f"{p}.attn2.norm_k.weight"]]))
+                b["out2.w"], b["out2.b"] = bf(sd[f"{p}.attn2.to_out.0.weight"]), bf(sd[f"{p}.attn2.to_out.0.bias"])
+            for n, k in (("ff.net.0.proj", "ff1"), ("ff.net.2", "ff2")):
+                b[k + ".w"], b[k + ".b"] = bf(sd[f"{p}.{n}.weight"]), bf(sd[f"{p}.{n}.bias"])
+            if not last:
+                for n, k in (("ff_context.net.0.proj", "cff1"), ("ff_context.net.2", "cff2")):
+                    b[k + ".w"], b[k + ".b"] = bf(sd[f"{p}.{n}.weight"]), bf(sd[f"{p}.{n}.bias"])
+            self.blocks.append(b)
+        add_mod(("out",), "norm_out.linear")
+        w["mod.w"], w["mod.b"] = bf(torch.cat(mod_w)), bf(torch.cat(mod_b))
+        self.n_mod = off
+        self.w = w
+
+    def _pos(self, B, hh, ww):
+        key = (B, hh, ww)
+        if key not in self._pos_cache:
+            m = self.cfg.pos_embed_max_size
+            top, left = (m - hh) // 2, (m - ww) // 2
+            pe = self.pos_embed.reshape(m, m, -1)[top:top + hh, left:left + ww].reshape(hh * ww, -1)
+            self._pos_cache[key] = pe.to(torch.bfloat16).repeat(B, 1).contiguous()
+        return self._pos_cache[key]
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def __call__(self, hidden_states, timestep, encoder_hidden_states, pooled_projections,
+                 joint_attention_kwargs=None, return_dict=False, out_dtype=None, return_intermediates=False):
+        cfg, w = self.cfg, self.w
+        D, H = cfg.dim, cfg.num_heads
+        B, C, h, wd = hidden_states.shape
+        hh, ww = h // cfg.patch_size, wd // cfg.patch_size
+        Ni, Nt = hh * ww, encoder_hidden_states.shape[1]
+        S = Ni + Nt
+        dev = hidden_states.device
+        bf16 = torch.bfloat16
+        inter = {}
+
+        x = ops.gemm(ops.patchify(hidden_states.contiguous()), w["patch.w"], bias=w["patch.b"],
+                     residual=self._pos(B, hh, ww))
+        t1 = "time_text_embed.timestep_embedder.linear_1"; t2 = "time_text_embed.timestep_embedder.linear_2"
+        p1 = "time_text_embed.text_embedder.linear_1"; p2 = "time_text_embed.text_embedder.linear_2"
+        te = ops.gemm(ops.gemm(ops.timestep_embedding(timestep), w[t1 + ".w"], bias=w[t1 + ".b"], act="silu"),
+                      w[t2 + ".w"], bias=w[t2 + ".b"])
+        temb = ops.gemm(ops.gemm(pooled_projections.to(bf16).contiguous(), w[p1 + ".w"], bias=w[p1 + ".b"], act="silu"),
+                        w[p2 + ".w"], bias=w[p2 + ".b"], residual=te)
+        mods = ops.gemm(ops.unary(temb, "silu"), w["mod.w"], bias=w["mod.b"])           # [B, n_mod]
+        c = ops.gemm(encoder_hidden_states.to(bf16).reshape(B * Nt, -1).contiguous(), w["context_embedder.w"],
+                     bias=w["context_embedder.b"])
+        if return_intermediates:
+            inter.update(x0=x.view(B, Ni, D).clone(), c0=c.view(B, Nt, D).clone(), temb=temb.clone())
+
+        def mod(key, j):
+            o = self.mod_off[key] + j * D
+            return mods[:, o:o + D]
+
+        qkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
+        qkv3 = qkv.view(B, S, 3 * D)
+        att = torch.empty(B, S, D, dtype=bf16, device=dev)
+        att2d = att.view(B * S, D)
+        for i, b in enumerate(self.blocks):
+            kx, kc = ("x", i), ("c", i)
+            # --- norms + modulation (chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+            #     [, shift_msa2, scale_msa2, gate_msa2]); AdaLayerNormContinuous (last context): scale, shift
+            if b["dual"]:
+                nx, nx2 = ops.layernorm_mod(x, scale=mod(kx, 1), shift=mod(kx, 0), scale2=mod(kx, 7), shift2=mod(kx, 6),
+                                            rows_per_batch=Ni)
+            else:
+                nx = ops.layernorm_mod(x, scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
+            if b["last"]:
+                nc = ops.layernorm_mod(c, scale=mod(kc, 0), shift=mod(kc, 1), rows_per_batch=Nt)
+            else:
+                nc = ops.layernorm_mod(c, scale=mod(kc, 1), shift=mod(kc, 0), rows_per_batch=Nt)
+            # --- joint attention
+            ops.gemm(nx, b["qkv.w"], bias=b["qkv.b"], out=qkv, seg=(Ni, S, 0))
+            ops.gemm(nc, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni))
+            if cfg.qk_norm:
+                ops.rmsnorm_heads(qkv, 0, 2 * H, b["rms_x"], H, seg=(Ni, S, 0), M=B * Ni)
+                ops.rmsnorm_heads(qkv, 0, 2 * H, b["rms_c"], H, seg=(Nt, S, Ni), M=B * Nt)
+            ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att)
+            ops.gemm(att2d, b["out.w"], bias=b["out.b"], gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x,
+                     a_seg=(Ni, S, 0), M=B * Ni)
+            if not b["last"]:
+                ops.gemm(att2d, b["cout.w"], bias=b["cout.b"], gate=mod(kc, 2), gate_rows=Nt, residual=c, out=c,
+                         a_seg=(Nt, S, Ni), M=B * Nt)
+            if b["dual"]:
+                qkv2 = ops.gemm(nx2, b["qkv2.w"], bias=b["qkv2.b"])
+                if cfg.qk_norm:
+                    ops.rmsnorm_heads(qkv2, 0, 2 * H, b["rms_2"], H)
+                q3 = qkv2.view(B, Ni, 3 * D)
+                o2 = ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], H)
+                ops.gemm(o2.view(B * Ni, D), b["out2.w"], bias=b["out2.b"], gate=mod(kx, 8), gate_rows=Ni, residual=x,
+                         out=x)
+            # --- MLPs
+            nx = ops.layernorm_mod(x, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
+            hmid = ops.gemm(nx, b["ff1.w"], bias=b["ff1.b"], act="gelu_tanh")
+            ops.gemm(hmid, b["ff2.w"], bias=b["ff2.b"], gate=mod(kx, 5), gate_rows=Ni, residual=x, out=x)
+            if not b["last"]:
+                nc = ops.layernorm_mod(c, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
+                hmid = ops.gemm(nc, b["cff1.w"], bias=b["cff1.b"], act="gelu_tanh")
+                ops.gemm(hmid, b["cff2.w"], bias=b["cff2.b"], gate=mod(kc, 5), gate_rows=Nt, residual=c, out=c)
+            if return_intermediates:
+                inter[f"x{i + 1}"] = x.view(B, Ni, D).clone()
+        nx = ops.layernorm_mod(x, scale=mod(("out",), 0), shift=mod(("out",), 1), rows_per_batch=Ni)
+        tok = ops.gemm(nx, w["proj_out.w"], bias=w["proj_out.b"])
+        out = ops.unpatchify(tok, B, cfg.out_channels, h, wd, out_dtype or bf16)
+        if return_intermediates:
+            return (out,), inter
+        return (out,)

@@ -9,7 +9,7 @@ ACT = {None: 0, "none": 0, "gelu_tanh": 1, "gelu": 2, "gelu_erf": 2, "silu": 3}
 
 
 def gemm(a, w, bias=None, act=None, alpha=1.0, gate=None, gate_rows=0, residual=None, out=None,
-         out_dtype=torch.bfloat16, seg=None):
+         out_dtype=torch.bfloat16, seg=None, a_seg=None, M=None):
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T).  a, w: bf16, last dim contiguous.
     gate: [G, N] bf16 with row m using gate[m // gate_rows].  residual: [rows, N] bf16 (indexed with the
     output row map).  seg = (seg_rows, seg_stride, seg_off) scatters row m to
@@ -18,19 +18,22 @@ def gemm(a, w, bias=None, act=None, alpha=1.0, gate=None, gate_rows=0, residual=
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
     assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1]
     assert a.stride(1) == 1 and w.stride(1) == 1
-    M, K = a.shape
+    K = a.shape[1]
+    M = a.shape[0] if M is None else M
     N = w.shape[0]
     if out is None:
         assert seg is None
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
     assert out.stride(-1) == 1
     seg_rows, seg_stride, seg_off = seg if seg is not None else (0, 0, 0)
+    a_rows, a_stride, a_off = a_seg if a_seg is not None else (0, 0, 0)
     _lib.check(lib.advgrpo_gemm_bf16(
         a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(-2),
         _lib.dtype_code(out.dtype), M, N, K, _lib.ptr(bias), ACT[act], float(alpha),
         gate.data_ptr() if gate is not None else None, gate.stride(0) if gate is not None else 0, int(gate_rows),
         residual.data_ptr() if residual is not None else None, residual.stride(-2) if residual is not None else 0,
-        int(seg_rows), int(seg_stride), int(seg_off), 1, 0, 0, 0, _lib.stream_ptr()))
+        int(seg_rows), int(seg_stride), int(seg_off), int(a_rows), int(a_stride), int(a_off), 1, 0, 0, 0,
+        _lib.stream_ptr()))
     return out
 
 
@@ -44,7 +47,7 @@ def bmm_nt(a, w, out=None, out_dtype=torch.bfloat16, alpha=1.0):
         out = torch.empty(B, M, N, dtype=out_dtype, device=a.device)
     _lib.check(lib.advgrpo_gemm_bf16(
         a.data_ptr(), a.stride(1), w.data_ptr(), w.stride(1), out.data_ptr(), out.stride(1),
-        _lib.dtype_code(out.dtype), M, N, K, None, 0, float(alpha), None, 0, 0, None, 0, 0, 0, 0,
+        _lib.dtype_code(out.dtype), M, N, K, None, 0, float(alpha), None, 0, 0, None, 0, 0, 0, 0, 0, 0, 0,
         B, a.stride(0), w.stride(0), out.stride(0), _lib.stream_ptr()))
     return out
 
@@ -64,4 +67,67 @@ def attention(q, k, v, num_heads, scale=None, causal=False, out=None):
         q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(1), k.stride(1), v.stride(1),
         out.stride(1), q.stride(0), k.stride(0), v.stride(0), out.stride(0), B, num_heads, Sq, Skv, D,
         float(scale), int(causal), _lib.stream_ptr()))
+    return out
+
+
+def layernorm_mod(x, out=None, w=None, b=None, scale=None, shift=None, scale2=None, shift2=None,
+                  rows_per_batch=0, eps=1e-6):
+    """x [M,D] bf16.  scale/shift [Bt,D] views (row pitch = stride(0)); returns out (and out2 if scale2 given)."""
+    lib = _lib.load()
+    M, D = x.shape
+    out = torch.empty(M, D, dtype=torch.bfloat16, device=x.device) if out is None else out
+    out2 = torch.empty_like(out) if scale2 is not None else None
+    ms = scale.stride(0) if scale is not None else 0
+    if scale is not None:
+        assert shift.stride(0) == ms and scale.stride(1) == 1
+    if scale2 is not None:
+        assert scale2.stride(0) == ms and shift2.stride(0) == ms
+    dp = lambda t: t.data_ptr() if t is not None else None
+    _lib.check(lib.advgrpo_layernorm_mod(x.data_ptr(), x.stride(0), out.data_ptr(), dp(out2), out.stride(0), dp(w),
+                                         dp(b), dp(scale), dp(shift), dp(scale2), dp(shift2), ms, int(rows_per_batch),
+                                         M, D, float(eps), _lib.stream_ptr()))
+    return (out, out2) if scale2 is not None else out
+
+
+def rmsnorm_heads(buf, col0, nheads, weight, heads_per_weight, eps=1e-6, seg=None, M=None):
+    """In place on buf [rows, ld] bf16; weight [(nheads/heads_per_weight), 64] bf16."""
+    lib = _lib.load()
+    seg_rows, seg_stride, seg_off = seg if seg is not None else (0, 0, 0)
+    M = buf.shape[0] if M is None else M
+    _lib.check(lib.advgrpo_rmsnorm_heads(buf.data_ptr(), buf.stride(0), M, col0, nheads, weight.data_ptr(),
+                                         heads_per_weight, float(eps), int(seg_rows), int(seg_stride), int(seg_off),
+                                         _lib.stream_ptr()))
+    return buf
+
+
+def timestep_embedding(t, dim=256):
+    lib = _lib.load()
+    t = t.float().contiguous()
+    out = torch.empty(t.shape[0], dim, dtype=torch.bfloat16, device=t.device)
+    _lib.check(lib.advgrpo_timestep_embedding(t.data_ptr(), out.data_ptr(), t.shape[0], dim, _lib.stream_ptr()))
+    return out
+
+
+def unary(x, act=None, x2=None):
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    _lib.check(lib.advgrpo_unary(x.data_ptr(), x2.data_ptr() if x2 is not None else None, y.data_ptr(), x.numel(),
+                                 ACT[act], _lib.stream_ptr()))
+    return y
+
+
+def patchify(x):
+    lib = _lib.load()
+    B, C, H, W = x.shape
+    out = torch.empty(B * (H // 2) * (W // 2), C * 4, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.advgrpo_patchify(_lib.ptr(x), _lib.dtype_code(x.dtype), out.data_ptr(), B, C, H, W,
+                                    _lib.stream_ptr()))
+    return out
+
+
+def unpatchify(tokens, B, C, H, W, out_dtype=torch.bfloat16):
+    lib = _lib.load()
+    out = torch.empty(B, C, H, W, dtype=out_dtype, device=tokens.device)
+    _lib.check(lib.advgrpo_unpatchify(_lib.ptr(tokens), out.data_ptr(), _lib.dtype_code(out_dtype), B, C, H, W,
+                                      _lib.stream_ptr()))
     return out

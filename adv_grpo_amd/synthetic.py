@@ -1,0 +1,84 @@
+"""Seeded synthetic weights / inputs with the exact shapes of the models on the hot path.
+
+No checkpoints or tokenizers exist on the build or GPU boxes (no network), so measurements and
+parity tests use seeded random weights of the real architecture: SD3.5-medium
+MMDiT-X, SD3 VAE decoder, CLIP ViT-H/14 (PickScore), DINOv2 ViT-B/14, DINO head.  Keys follow the
+upstream state_dict names (diffusers / transformers), so real checkpoints can replace them.
+Weights ~ N(0, 1/fan_in) (keeps activations O(1) through 24 blocks, which makes parity tests
+sensitive to every block), biases ~ N(0, 0.1^2), norm weights ~ 1 + N(0, 0.1^2).
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def linear_(W, name, out_f, in_f, g, bias=True, std=None):
+    std = (1.0 / math.sqrt(in_f)) if std is None else std
+    W[name + ".weight"] = torch.randn(out_f, in_f, generator=g) * std
+    if bias:
+        W[name + ".bias"] = torch.randn(out_f, generator=g) * 0.1
+
+
+def sincos_pos_embed_2d(dim, grid_size, base_size):
+    """diffusers get_2d_sincos_pos_embed(dim, grid_size, base_size=base_size, interpolation_scale=1)."""
+    def emb1d(d, pos):
+        omega = 1.0 / 10000 ** (np.arange(d // 2, dtype=np.float64) / (d / 2.0))
+        out = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+    gh = np.arange(grid_size, dtype=np.float32) / (grid_size / base_size)
+    gw = np.arange(grid_size, dtype=np.float32) / (grid_size / base_size)
+    grid = np.stack(np.meshgrid(gw, gh), axis=0).reshape(2, 1, grid_size, grid_size)
+    emb = np.concatenate([emb1d(dim // 2, grid[0]), emb1d(dim // 2, grid[1])], axis=1)
+    return torch.from_numpy(emb).float().unsqueeze(0)
+
+
+def mmdit_weights(cfg, seed=1234):
+    """fp32 CPU weights dict keyed like diffusers SD3Transformer2DModel.state_dict()."""
+    g = _gen(seed)
+    D, W = cfg.dim, {}
+    ps, C = cfg.patch_size, cfg.in_channels
+    W["pos_embed.proj.weight"] = torch.randn(D, C, ps, ps, generator=g) / math.sqrt(C * ps * ps)
+    W["pos_embed.proj.bias"] = torch.randn(D, generator=g) * 0.1
+    W["pos_embed.pos_embed"] = sincos_pos_embed_2d(D, cfg.pos_embed_max_size, 64)
+    linear_(W, "time_text_embed.timestep_embedder.linear_1", D, 256, g)
+    linear_(W, "time_text_embed.timestep_embedder.linear_2", D, D, g)
+    linear_(W, "time_text_embed.text_embedder.linear_1", D, cfg.pooled_projection_dim, g)
+    linear_(W, "time_text_embed.text_embedder.linear_2", D, D, g)
+    linear_(W, "context_embedder", D, cfg.joint_attention_dim, g)
+    for i in range(cfg.num_layers):
+        p = f"transformer_blocks.{i}"
+        dual = i in cfg.dual_attention_layers
+        last = i == cfg.num_layers - 1
+        linear_(W, f"{p}.norm1.linear", (9 if dual else 6) * D, D, g, std=0.5 / math.sqrt(D))
+        linear_(W, f"{p}.norm1_context.linear", (2 if last else 6) * D, D, g, std=0.5 / math.sqrt(D))
+        for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0"):
+            linear_(W, f"{p}.attn.{n}", D, D, g)
+        if not last:
+            linear_(W, f"{p}.attn.to_add_out", D, D, g)
+        for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+            W[f"{p}.attn.{n}.weight"] = 1 + 0.1 * torch.randn(cfg.head_dim, generator=g)
+        if dual:
+            for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                linear_(W, f"{p}.attn2.{n}", D, D, g)
+            for n in ("norm_q", "norm_k"):
+                W[f"{p}.attn2.{n}.weight"] = 1 + 0.1 * torch.randn(cfg.head_dim, generator=g)
+        linear_(W, f"{p}.ff.net.0.proj", 4 * D, D, g)
+        linear_(W, f"{p}.ff.net.2", D, 4 * D, g)
+        if not last:
+            linear_(W, f"{p}.ff_context.net.0.proj", 4 * D, D, g)
+            linear_(W, f"{p}.ff_context.net.2", D, 4 * D, g)
+    linear_(W, "norm_out.linear", 2 * D, D, g, std=0.5 / math.sqrt(D))
+    linear_(W, "proj_out", ps * ps * cfg.out_channels, D, g)
+    return W
+
+
+def prompt_embeddings(seed=7, n_tokens=205, ctx_dim=4096, pooled_dim=2048):
+    """Synthetic prompt: (prompt_embeds [1,205,4096], pooled [1,2048], negative ..., negative pooled ...)."""
+    g = _gen(seed)
+    return (torch.randn(1, n_tokens, ctx_dim, generator=g), torch.randn(1, pooled_dim, generator=g),
+            torch.randn(1, n_tokens, ctx_dim, generator=g), torch.randn(1, pooled_dim, generator=g))

@@ -107,14 +107,39 @@ int advgrpo_grpo_loss(const float* log_prob, const float* old_log_prob, const fl
  * and timm's DINOv2 (adv_grpo/rewards.py:397).
  *   y = act(alpha*acc + bias[n]);  y *= gate[(m / gate_rows)*gate_stride + n];  y += residual[orow*ldr + n]
  *   orow = seg_rows ? (m / seg_rows)*seg_stride + seg_off + m % seg_rows : m      (row-segment scatter)
+ *   A row m is read from arow = a_seg_rows ? (m / a_seg_rows)*a_seg_stride + a_seg_off + m % a_seg_rows : m
  * bias/gate/residual: bf16, optional (NULL).  act: 0 none, 1 GELU(tanh), 2 GELU(erf), 3 SiLU.
  * out_dtype: BF16 or F32.  K % 64 == 0; lda/ldw % 8 == 0.  batch > 1: grid-batched with element
  * strides (residual uses strideC). */
 int advgrpo_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                       int out_dtype, int M, int N, int K, const void* bias, int act, float alpha,
                       const void* gate, int64_t gate_stride, int gate_rows, const void* residual,
-                      int64_t ldr, int seg_rows, int64_t seg_stride, int64_t seg_off, int batch,
+                      int64_t ldr, int seg_rows, int64_t seg_stride, int64_t seg_off, int a_seg_rows,
+                      int64_t a_seg_stride, int64_t a_seg_off, int batch,
                       int64_t strideA, int64_t strideW, int64_t strideC, void* stream);
+
+/* ------------------------------------------------------------------ row kernels (HBM bound)
+ * layernorm_mod: out = (LN(x) [*w + b]) * (1 + scale[m / rows_per_batch]) + shift[...]; optional second
+ * output with a second (scale1, shift1) from the same statistics.  Replaces nn.LayerNorm +
+ * AdaLayerNormZero / AdaLayerNormContinuous modulation inside the transformer call and the ViT LayerNorms.
+ * All tensors bf16; w/b/scale/shift optional; D % 8 == 0, D <= 2048. */
+int advgrpo_layernorm_mod(const void* x, int64_t ldx, void* out0, void* out1, int64_t ldo,
+                          const void* w, const void* b, const void* scale0, const void* shift0,
+                          const void* scale1, const void* shift1, int64_t mod_stride, int rows_per_batch,
+                          int M, int D, float eps, void* stream);
+/* In-place RMSNorm over 64-wide heads (SD3.5 qk_norm): rows of buf[., ld], heads at columns
+ * [col0, col0 + 64*nheads); head hh is scaled by weight[(hh / heads_per_weight)*64 ...].  Row m maps
+ * through (seg_rows, seg_stride, seg_off) like the GEMM output map. */
+int advgrpo_rmsnorm_heads(void* buf, int64_t ld, int M, int col0, int nheads, const void* weight,
+                          int heads_per_weight, float eps, int seg_rows, int64_t seg_stride,
+                          int64_t seg_off, void* stream);
+/* diffusers Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0): t f32 [B] -> bf16 [B, dim]. */
+int advgrpo_timestep_embedding(const float* t, void* out, int B, int dim, void* stream);
+/* y = act(x [+ x2]) on bf16, n % 8 == 0 (act 0 none, 3 SiLU). */
+int advgrpo_unary(const void* x, const void* x2, void* y, int64_t n, int act, void* stream);
+/* [B,C,H,W] latents <-> 2x2 patch token rows (PatchEmbed conv k2 s2 as im2col; proj_out unpatchify). */
+int advgrpo_patchify(const void* x, int x_dtype, void* out, int B, int C, int H, int W, void* stream);
+int advgrpo_unpatchify(const void* tokens, void* out, int out_dtype, int B, int C, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------ fused attention
  * o = softmax(q k^T * scale [+ causal mask]) v per (batch, head); bf16 in/out, f32 softmax.
