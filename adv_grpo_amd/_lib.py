@@ -40,6 +40,11 @@ SIGNATURES = {
     "advgrpo_unary": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "advgrpo_patchify": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "advgrpo_unpatchify": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "advgrpo_conv3x3_nhwc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
+    "advgrpo_groupnorm_nhwc": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    "advgrpo_softmax_rows": (c_int, [_P, c_int64, c_int, _P]),
+    "advgrpo_latents_to_nhwc": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
+    "advgrpo_image_postprocess": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _P]),
     "advgrpo_attention_fwd": (c_int, [_P, _P, _P, _P] + [c_int64] * 8 + [c_int] * 5 + [c_float, c_int, _P]),
 }
 

@@ -46,7 +46,7 @@ __device__ inline int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool CONV>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     constexpr int BK = 64;
     constexpr int TM = BM / 2, TN = BN / 2;     // wave tile
@@ -75,16 +75,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     const int schunk = (lane & 7) ^ lrow;        // source 16-B chunk for this lane's LDS slot
     const bf16_t* a_src[A_INST];
     const bf16_t* b_src[B_INST];
+    int a_y[A_INST], a_x[A_INST];        // CONV: output pixel of this lane's row
+    int64_t a_img[A_INST];               // CONV: element offset of the image (b) in the input
 #pragma unroll
     for (int it = 0; it < A_INST; ++it) {
         int r = m0 + (wave + it * 4) * 8 + lrow;
         r = r < p.M ? r : p.M - 1;
-        int64_t ar = r;
-        if (p.a_seg_rows > 0) {
-            const int bi = r / p.a_seg_rows;
-            ar = (int64_t)bi * p.a_seg_stride + p.a_seg_off + (r - bi * p.a_seg_rows);
+        if constexpr (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int bi = r / hw, rem = r - bi * hw;
+            a_y[it] = rem / p.Wout;
+            a_x[it] = rem - a_y[it] * p.Wout;
+            a_img[it] = (int64_t)bi * (p.Hout >> p.ups) * (p.Wout >> p.ups) * p.Cin;
+            a_src[it] = nullptr;
+        } else {
+            int64_t ar = r;
+            if (p.a_seg_rows > 0) {
+                const int bi = r / p.a_seg_rows;
+                ar = (int64_t)bi * p.a_seg_stride + p.a_seg_off + (r - bi * p.a_seg_rows);
+            }
+            a_src[it] = A + ar * p.lda + schunk * 8;
         }
-        a_src[it] = A + ar * p.lda + schunk * 8;
     }
 #pragma unroll
     for (int it = 0; it < B_INST; ++it) {
@@ -94,10 +105,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     }
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * STAGE;
+        if constexpr (CONV) {
+            // one 64-wide k tile lies inside one filter tap (Cin % 64 == 0)
+            const int k0 = kt * BK;
+            const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const int win = p.Wout >> p.ups;
 #pragma unroll
-        for (int it = 0; it < A_INST; ++it)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[it] + kt * BK),
-                                             (lds_ptr_t)(base + (wave + it * 4) * 1024), 16, 0, 0);
+            for (int it = 0; it < A_INST; ++it) {
+                const int yy = a_y[it] + dy, xx = a_x[it] + dx;
+                const bool ok = (unsigned)yy < (unsigned)p.Hout && (unsigned)xx < (unsigned)p.Wout;
+                const bf16_t* src = ok ? A + a_img[it] + ((int64_t)(yy >> p.ups) * win + (xx >> p.ups)) * p.Cin + c0 +
+                                             schunk * 8
+                                       : p.zero_page + schunk * 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(base + (wave + it * 4) * 1024), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < A_INST; ++it)
+                __builtin_amdgcn_global_load_lds((gptr_t)(a_src[it] + kt * BK),
+                                                 (lds_ptr_t)(base + (wave + it * 4) * 1024), 16, 0, 0);
+        }
 #pragma unroll
         for (int it = 0; it < B_INST; ++it)
             __builtin_amdgcn_global_load_lds((gptr_t)(b_src[it] + kt * BK),
@@ -195,17 +223,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool CONV>
 static int launch(const GemmParams& p, hipStream_t s) {
     constexpr int lds = 2 * (BM + BN) * 64 * 2;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<BM, BN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<BM, BN, CONV>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN>), dim3(tiles, p.batch), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, CONV>), dim3(tiles, p.batch), dim3(256), lds, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
@@ -219,9 +247,16 @@ int gemm_bf16(const GemmParams& p, hipStream_t s) {
     ADVGRPO_CHECK(p.batch >= 1, "gemm: batch must be >= 1");
     // tile choice: big tiles when they still fill the 256 CUs, smaller ones for skinny problems
     const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
-    if (p.N <= 64) return launch<128, 64>(p, s);
-    if (t128 >= 256 || p.M > 2048) return launch<128, 128>(p, s);
-    return launch<64, 128>(p, s);
+    if (p.conv) {
+        ADVGRPO_CHECK(p.Cin % 64 == 0 && p.K == 9 * p.Cin && p.zero_page && p.batch == 1,
+                      "conv3x3: need Cin %% 64 == 0, K == 9*Cin, a zero page and batch 1 (Cin=%d K=%d)", p.Cin, p.K);
+        ADVGRPO_CHECK((p.Hout % (1 << p.ups)) == 0 && (p.Wout % (1 << p.ups)) == 0, "conv3x3: bad upsample shape");
+        if (p.N <= 64) return launch<128, 64, true>(p, s);
+        return launch<128, 128, true>(p, s);
+    }
+    if (p.N <= 64) return launch<128, 64, false>(p, s);
+    if (t128 >= 256 || p.M > 2048) return launch<128, 128, false>(p, s);
+    return launch<64, 128, false>(p, s);
 }
 
 }  // namespace advgrpo
@@ -244,5 +279,21 @@ extern "C" int advgrpo_gemm_bf16(const void* A, int64_t lda, const void* W, int6
     p.seg_rows = seg_rows; p.seg_stride = seg_stride; p.seg_off = seg_off;
     p.a_seg_rows = a_seg_rows; p.a_seg_stride = a_seg_stride; p.a_seg_off = a_seg_off;
     p.batch = batch < 1 ? 1 : batch; p.strideA = strideA; p.strideW = strideW; p.strideC = strideC;
+    return gemm_bf16(p, as_stream(stream));
+}
+
+/* implicit-GEMM conv3x3 (stride 1, pad 1) over NHWC bf16, optional fused nearest-x2 upsample of the input */
+extern "C" int advgrpo_conv3x3_nhwc(const void* x, const void* w, void* y, int out_dtype, int B, int Hout, int Wout,
+                                    int Cin, int Cout, int upsample, const void* bias, int act, const void* residual,
+                                    const void* zero_page, void* stream) {
+    GemmParams p{};
+    p.A = (const bf16_t*)x; p.W = (const bf16_t*)w; p.C = y;
+    p.lda = Cin; p.ldw = 9 * (int64_t)Cin; p.ldc = Cout; p.out_dtype = out_dtype;
+    p.M = B * Hout * Wout; p.N = Cout; p.K = 9 * Cin;
+    p.bias = (const bf16_t*)bias; p.act = act; p.alpha = 1.0f;
+    p.residual = (const bf16_t*)residual; p.ldr = Cout;
+    p.batch = 1;
+    p.conv = 1; p.Hout = Hout; p.Wout = Wout; p.Cin = Cin; p.ups = upsample ? 1 : 0;
+    p.zero_page = (const bf16_t*)zero_page;
     return gemm_bf16(p, as_stream(stream));
 }

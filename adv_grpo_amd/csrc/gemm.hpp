@@ -22,6 +22,9 @@ struct GemmParams {
     // input row map for A (same formula), e.g. reading the image rows out of a joint image+text buffer
     int a_seg_rows; int64_t a_seg_stride, a_seg_off;
     int batch; int64_t strideA, strideW, strideC;
+    // implicit-GEMM 3x3 conv (stride 1, pad 1, optional nearest x2 upsample of the input), NHWC:
+    // A = input [B, Hout>>ups, Wout>>ups, Cin], row m = output pixel (b, y, x), k = (ky*3+kx)*Cin + c
+    int conv; int Hout, Wout, Cin, ups; const bf16_t* zero_page;
 };
 
 int gemm_bf16(const GemmParams& p, hipStream_t stream);

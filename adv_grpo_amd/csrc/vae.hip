@@ -1,0 +1,231 @@
+// vae.hip -- HBM-bound kernels of the SD3 VAE decoder (NHWC bf16 activations) for gfx950.
+//
+// The reference decodes with diffusers' AutoencoderKL in fp32 (sd3_pipeline_with_logprob_fast.py:667-670,
+// train_sd3_fast_pickscore.py:481).  Here the 3x3 convolutions run as implicit GEMMs on the bf16 MFMA
+// kernel (gemm.hip, conv loader); this file holds what sits between them:
+//   groupnorm_stats  per-(image, group) sum / sum-of-squares, f32 per thread, f64 atomics per block
+//   groupnorm_apply  (x - mean) * rstd * w + b, optional SiLU, bf16 out  -- one read, one write
+//   softmax_rows     in-place row softmax of the mid-block attention scores (4096 keys, 1 head)
+//   latents_to_nhwc  z/scaling + shift, NCHW f32|bf16 -> NHWC bf16 padded to 64 channels
+//   image_postprocess NHWC (3 of ldc channels) -> NCHW f32, (x/2 + 0.5).clamp(0, 1)
+// Activations are as large as 1 GB (8 x 512 x 512 x 128 bf16), far beyond the 256 MB Infinity Cache:
+// each kernel is shaped as a single streaming pass with 16-byte lane accesses along the contiguous
+// channel axis.
+#include "common.hpp"
+
+namespace advgrpo {
+
+__device__ inline void unpack8v(const uint4& r, float o[8]) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        o[2 * k] = bf2f((bf16_t)(w[k] & 0xffffu));
+        o[2 * k + 1] = bf2f((bf16_t)(w[k] >> 16));
+    }
+}
+__device__ inline uint4 pack8v(const float o[8]) {
+    uint4 r;
+    r.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+    r.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+    r.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
+    r.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+    return r;
+}
+
+// x: [B, HW, C] bf16.  grid (chunks, B); each block walks pixels [chunk*ppb, (chunk+1)*ppb).
+// A thread owns one 8-channel slice (c8 = tid % (C/8)) => with C/G in {4, 8, 16} its 8 channels
+// belong to at most two groups... we keep per-thread sums per 4-channel half and reduce in LDS.
+// stats: [B, G, 2] f64 (sum, sumsq), zeroed by the caller.
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __restrict__ x, double* __restrict__ stats,
+                                                              int HW, int C, int G, int ppb) {
+    __shared__ float s_sum[64], s_sq[64];   // G <= 64
+    const int b = blockIdx.y;
+    const int c8n = C >> 3;                  // 8-channel slices per pixel
+    const int slice = threadIdx.x % c8n, prow = threadIdx.x / c8n, pstep = blockDim.x / c8n;
+    const int cpg = C / G;                   // channels per group (4, 8, 16, ...)
+    if (threadIdx.x < 64) { s_sum[threadIdx.x] = 0.f; s_sq[threadIdx.x] = 0.f; }
+    __syncthreads();
+    float sum[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};   // halves: channels [0,4) and [4,8) of the slice
+    const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
+    const bf16_t* xb = x + (int64_t)b * HW * C;
+    for (int p = p0 + prow; p < p1; p += pstep) {
+        float v[8];
+        unpack8v(*reinterpret_cast<const uint4*>(xb + (int64_t)p * C + slice * 8), v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            sum[k >> 2] += v[k];
+            sq[k >> 2] += v[k] * v[k];
+        }
+    }
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+        const int g = (slice * 8 + hlf * 4) / cpg;
+        atomicAdd(&s_sum[g], sum[hlf]);
+        atomicAdd(&s_sq[g], sq[hlf]);
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        atomicAdd(&stats[((int64_t)b * G + threadIdx.x) * 2], (double)s_sum[threadIdx.x]);
+        atomicAdd(&stats[((int64_t)b * G + threadIdx.x) * 2 + 1], (double)s_sq[threadIdx.x]);
+    }
+}
+
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                              const double* __restrict__ stats,
+                                                              const bf16_t* __restrict__ w, const bf16_t* __restrict__ bb,
+                                                              int HW, int C, int G, float eps, int silu, int64_t total8) {
+    const int c8n = C >> 3, cpg = C / G;
+    const double cnt = (double)HW * cpg;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int slice = i % c8n;
+        const int64_t pix = i / c8n;
+        const int b = pix / HW;
+        float v[8], ww[8], bv[8];
+        unpack8v(*reinterpret_cast<const uint4*>(x + i * 8), v);
+        unpack8v(*reinterpret_cast<const uint4*>(w + slice * 8), ww);
+        unpack8v(*reinterpret_cast<const uint4*>(bb + slice * 8), bv);
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int g = (slice * 8 + hlf * 4) / cpg;
+            const double s = stats[((int64_t)b * G + g) * 2], q = stats[((int64_t)b * G + g) * 2 + 1];
+            const double mean = s / cnt;
+            const double var = q / cnt - mean * mean;
+            const float mu = (float)mean, rstd = rsqrtf(fmaxf((float)var, 0.f) + eps);
+#pragma unroll
+            for (int k = hlf * 4; k < hlf * 4 + 4; ++k) {
+                float t = (v[k] - mu) * rstd * ww[k] + bv[k];
+                if (silu) t = t / (1.0f + __expf(-t));
+                v[k] = t;
+            }
+        }
+        *reinterpret_cast<uint4*>(y + i * 8) = pack8v(v);
+    }
+}
+
+// in-place softmax over rows of length n (n % 8 == 0, n <= 8192): one wave per row, row kept in registers
+__global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ s, int64_t rows, int n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    bf16_t* r = s + row * n;
+    constexpr int MAXC = 16;
+    float v[MAXC][8];
+    const int n8 = n >> 3;  // 16-byte chunks in the row
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = i * 64 + lane;
+        if (c < n8) {
+            unpack8v(*reinterpret_cast<const uint4*>(r + c * 8), v[i]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mx = fmaxf(mx, v[i][k]);
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = i * 64 + lane;
+        if (c < n8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v[i][k] = __expf(v[i][k] - mx);
+                sum += v[i][k];
+            }
+        }
+    }
+    const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = i * 64 + lane;
+        if (c < n8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[i][k] *= inv;
+            *reinterpret_cast<uint4*>(r + c * 8) = pack8v(v[i]);
+        }
+    }
+}
+
+// z [B,C,H,W] (f32 or bf16) -> NHWC bf16 [B,H,W,Cpad], value z*inv_scale + shift in channels < C, else 0
+__global__ void latents_to_nhwc_kernel(const void* __restrict__ z, int z_dt, bf16_t* __restrict__ out, int B, int C,
+                                       int H, int W, int Cpad, float scaling, float shift) {
+    const int64_t total = (int64_t)B * H * W * Cpad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = i % Cpad;
+        const int64_t pix = i / Cpad;
+        const int w = pix % W, h = (pix / W) % H, b = pix / ((int64_t)W * H);
+        float v = 0.f;
+        if (c < C) {
+            const int64_t src = (((int64_t)b * C + c) * H + h) * W + w;
+            v = z_dt == ADVGRPO_BF16 ? bf2f(reinterpret_cast<const bf16_t*>(z)[src]) : reinterpret_cast<const float*>(z)[src];
+            v = v / scaling + shift;   // latents / scaling_factor + shift_factor (PF:667), one f32 rounding each
+        }
+        out[i] = f2bf(v);
+    }
+}
+
+// y NHWC [B,H,W,ldc] (bf16 or f32; channels 0..2 used) -> image NCHW f32 [B,3,H,W] = clamp(y/2+0.5, 0, 1)
+__global__ void image_postprocess_kernel(const void* __restrict__ y, int y_dt, int ldc, float* __restrict__ img, int B,
+                                         int H, int W) {
+    const int64_t total = (int64_t)B * 3 * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = i % W, h = (i / W) % H, c = (i / ((int64_t)W * H)) % 3, b = i / ((int64_t)W * H * 3);
+        const int64_t src = (((int64_t)b * H + h) * W + w) * ldc + c;
+        const float v = y_dt == ADVGRPO_BF16 ? bf2f(reinterpret_cast<const bf16_t*>(y)[src])
+                                             : reinterpret_cast<const float*>(y)[src];
+        img[i] = fminf(fmaxf(v / 2.0f + 0.5f, 0.f), 1.f);
+    }
+}
+
+}  // namespace advgrpo
+
+using namespace advgrpo;
+
+extern "C" int advgrpo_groupnorm_nhwc(const void* x, void* y, double* stats, const void* weight, const void* bias, int B,
+                                      int HW, int C, int G, float eps, int silu, void* stream) {
+    ADVGRPO_CHECK(x && y && stats && weight && bias, "groupnorm: null pointer");
+    ADVGRPO_CHECK(B > 0 && HW > 0 && C % 8 == 0 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 4 == 0 && 256 % (C / 8) == 0,
+                  "groupnorm: unsupported shape C=%d G=%d", C, G);
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(double), s) != hipSuccess) {
+        set_error("groupnorm: memset failed");
+        return -2;
+    }
+    const int ppb = 512;  // pixels per block
+    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, s, (const bf16_t*)x, stats,
+                       HW, C, G, ppb);
+    ADVGRPO_LAUNCH_CHECK();
+    const int64_t total8 = (int64_t)B * HW * (C / 8);
+    int64_t blocks = (total8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3((int)blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, stats,
+                       (const bf16_t*)weight, (const bf16_t*)bias, HW, C, G, eps, silu, total8);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_softmax_rows(void* s, int64_t rows, int n, void* stream) {
+    ADVGRPO_CHECK(s && rows > 0 && n > 0 && n % 8 == 0 && n <= 8192, "softmax_rows: need n %% 8 == 0, n <= 8192 (n=%d)", n);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), (bf16_t*)s,
+                       rows, n);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_latents_to_nhwc(const void* z, int z_dtype, void* out, int B, int C, int H, int W, int Cpad,
+                                       float scaling_factor, float shift_factor, void* stream) {
+    ADVGRPO_CHECK(z && out && B > 0 && C > 0 && Cpad >= C, "latents_to_nhwc: bad argument");
+    hipLaunchKernelGGL(latents_to_nhwc_kernel, dim3(1024), dim3(256), 0, as_stream(stream), z, z_dtype, (bf16_t*)out, B, C,
+                       H, W, Cpad, scaling_factor, shift_factor);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_image_postprocess(const void* y, int y_dtype, int ldc, float* image, int B, int H, int W,
+                                         void* stream) {
+    ADVGRPO_CHECK(y && image && B > 0 && ldc >= 3, "image_postprocess: bad argument");
+    hipLaunchKernelGGL(image_postprocess_kernel, dim3(2048), dim3(256), 0, as_stream(stream), y, y_dtype, ldc, image, B, H,
+                       W);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}

@@ -131,3 +131,63 @@ def unpatchify(tokens, B, C, H, W, out_dtype=torch.bfloat16):
     _lib.check(lib.advgrpo_unpatchify(_lib.ptr(tokens), out.data_ptr(), _lib.dtype_code(out_dtype), B, C, H, W,
                                       _lib.stream_ptr()))
     return out
+
+
+_ZERO_PAGE = {}
+
+
+def zero_page(device):
+    key = str(device)
+    if key not in _ZERO_PAGE:
+        _ZERO_PAGE[key] = torch.zeros(256, dtype=torch.bfloat16, device=device)
+    return _ZERO_PAGE[key]
+
+
+def conv3x3(x, w, bias=None, upsample=False, act=None, residual=None, out_dtype=torch.bfloat16):
+    """x NHWC bf16 [B,Hin,Win,Cin]; w [Cout, 9*Cin] bf16 (k = (ky*3+kx)*Cin + c) -> [B,Hout,Wout,Cout]."""
+    lib = _lib.load()
+    B, Hin, Win, Cin = x.shape
+    Cout = w.shape[0]
+    Hout, Wout = (Hin * 2, Win * 2) if upsample else (Hin, Win)
+    y = torch.empty(B, Hout, Wout, Cout, dtype=out_dtype, device=x.device)
+    _lib.check(lib.advgrpo_conv3x3_nhwc(_lib.ptr(x), _lib.ptr(w), y.data_ptr(), _lib.dtype_code(out_dtype), B, Hout, Wout,
+                                        Cin, Cout, int(upsample), _lib.ptr(bias), ACT[act], _lib.ptr(residual),
+                                        zero_page(x.device).data_ptr(), _lib.stream_ptr()))
+    return y
+
+
+def groupnorm_nhwc(x, weight, bias, groups=32, eps=1e-6, silu=False):
+    lib = _lib.load()
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    stats = torch.empty(B * groups * 2, dtype=torch.float64, device=x.device)
+    _lib.check(lib.advgrpo_groupnorm_nhwc(_lib.ptr(x), y.data_ptr(), stats.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), B,
+                                          HW, C, groups, float(eps), int(silu), _lib.stream_ptr()))
+    return y
+
+
+def softmax_rows_(s):
+    lib = _lib.load()
+    n = s.shape[-1]
+    _lib.check(lib.advgrpo_softmax_rows(_lib.ptr(s), s.numel() // n, n, _lib.stream_ptr()))
+    return s
+
+
+def latents_to_nhwc(z, cpad, scaling_factor, shift_factor):
+    lib = _lib.load()
+    B, C, H, W = z.shape
+    out = torch.empty(B, H, W, cpad, dtype=torch.bfloat16, device=z.device)
+    _lib.check(lib.advgrpo_latents_to_nhwc(_lib.ptr(z.contiguous()), _lib.dtype_code(z.dtype), out.data_ptr(), B, C, H, W,
+                                           cpad, float(scaling_factor), float(shift_factor), _lib.stream_ptr()))
+    return out
+
+
+def image_postprocess(y):
+    """y NHWC [B,H,W,ldc] (bf16/f32) -> [B,3,H,W] f32 in [0,1]."""
+    lib = _lib.load()
+    B, H, W, ldc = y.shape
+    img = torch.empty(B, 3, H, W, dtype=torch.float32, device=y.device)
+    _lib.check(lib.advgrpo_image_postprocess(_lib.ptr(y), _lib.dtype_code(y.dtype), ldc, img.data_ptr(), B, H, W,
+                                             _lib.stream_ptr()))
+    return img

@@ -82,3 +82,43 @@ def prompt_embeddings(seed=7, n_tokens=205, ctx_dim=4096, pooled_dim=2048):
     g = _gen(seed)
     return (torch.randn(1, n_tokens, ctx_dim, generator=g), torch.randn(1, pooled_dim, generator=g),
             torch.randn(1, n_tokens, ctx_dim, generator=g), torch.randn(1, pooled_dim, generator=g))
+
+
+def conv_(W, name, cout, cin, k, g):
+    W[name + ".weight"] = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    W[name + ".bias"] = torch.randn(cout, generator=g) * 0.1
+
+
+def norm_(W, name, c, g):
+    W[name + ".weight"] = 1 + 0.1 * torch.randn(c, generator=g)
+    W[name + ".bias"] = 0.1 * torch.randn(c, generator=g)
+
+
+def vae_decoder_weights(cfg, seed=4321):
+    """fp32 CPU weights keyed like diffusers AutoencoderKL.state_dict() (decoder.* only)."""
+    g = _gen(seed)
+    W = {}
+    ch = list(reversed(cfg.block_out_channels))          # 512, 512, 256, 128
+    conv_(W, "decoder.conv_in", ch[0], cfg.latent_channels, 3, g)
+
+    def res(p, ci, co):
+        norm_(W, f"{p}.norm1", ci, g); conv_(W, f"{p}.conv1", co, ci, 3, g)
+        norm_(W, f"{p}.norm2", co, g); conv_(W, f"{p}.conv2", co, co, 3, g)
+        if ci != co:
+            conv_(W, f"{p}.conv_shortcut", co, ci, 1, g)
+    res("decoder.mid_block.resnets.0", ch[0], ch[0])
+    a = "decoder.mid_block.attentions.0"
+    norm_(W, f"{a}.group_norm", ch[0], g)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        linear_(W, f"{a}.{n}", ch[0], ch[0], g)
+    res("decoder.mid_block.resnets.1", ch[0], ch[0])
+    prev = ch[0]
+    for i, co in enumerate(ch):
+        for j in range(cfg.layers_per_block + 1):
+            res(f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else co, co)
+        prev = co
+        if i < len(ch) - 1:
+            conv_(W, f"decoder.up_blocks.{i}.upsamplers.0.conv", co, co, 3, g)
+    norm_(W, "decoder.conv_norm_out", ch[-1], g)
+    conv_(W, "decoder.conv_out", 3, ch[-1], 3, g)
+    return W

@@ -154,6 +154,29 @@ int advgrpo_attention_fwd(const void* q, const void* k, const void* v, void* o,
                           int B, int H, int Sq, int Skv, int head_dim, float scale, int causal,
                           void* stream);
 
+/* ------------------------------------------------------------------ VAE decoder pieces
+ * Replace diffusers AutoencoderKL.decode + VaeImageProcessor.postprocess("pt") as reached at
+ * sd3_pipeline_with_logprob_fast.py:667-670.  Activations are NHWC bf16; 3x3 convolutions are implicit
+ * GEMMs on the MFMA kernel (f32 accumulate).  DEVIATION: the reference runs the VAE in fp32
+ * (train_sd3_fast_pickscore.py:481); tolerance is stated in tests/test_gpu_vae.py and DESIGN.md. */
+/* y[b,yo,xo,:] = act(conv3x3(x)[...] + bias) + residual ; x: [B, Hout>>up, Wout>>up, Cin] (nearest x2
+ * upsample fused when upsample != 0); w: [Cout, 9*Cin] with k = (ky*3+kx)*Cin + c; Cin % 64 == 0;
+ * zero_page: >= 128 bytes of zeros (padding taps are read from it). */
+int advgrpo_conv3x3_nhwc(const void* x, const void* w, void* y, int out_dtype, int B, int Hout, int Wout,
+                         int Cin, int Cout, int upsample, const void* bias, int act, const void* residual,
+                         const void* zero_page, void* stream);
+/* GroupNorm(G) over NHWC [B, HW, C] + affine (+ SiLU): stats scratch [B, G, 2] f64. */
+int advgrpo_groupnorm_nhwc(const void* x, void* y, double* stats, const void* weight, const void* bias,
+                           int B, int HW, int C, int G, float eps, int silu, void* stream);
+/* in-place softmax over rows of a bf16 [rows, n] matrix (n % 8 == 0, n <= 8192). */
+int advgrpo_softmax_rows(void* s, int64_t rows, int n, void* stream);
+/* z [B,C,H,W] -> NHWC bf16 [B,H,W,Cpad] of z/scaling_factor + shift_factor (zero in the pad channels). */
+int advgrpo_latents_to_nhwc(const void* z, int z_dtype, void* out, int B, int C, int H, int W, int Cpad,
+                            float scaling_factor, float shift_factor, void* stream);
+/* decoder output NHWC (first 3 of ldc channels) -> image [B,3,H,W] f32 = clamp(y/2 + 0.5, 0, 1). */
+int advgrpo_image_postprocess(const void* y, int y_dtype, int ldc, float* image, int B, int H, int W,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif
