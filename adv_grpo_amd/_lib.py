@@ -45,6 +45,13 @@ SIGNATURES = {
     "advgrpo_softmax_rows": (c_int, [_P, c_int64, c_int, _P]),
     "advgrpo_latents_to_nhwc": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
     "advgrpo_image_postprocess": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _P]),
+    "advgrpo_clip_preprocess_patches": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P,
+                                                _P, c_int, POINTER(c_float), POINTER(c_float), _P]),
+    "advgrpo_dino_preprocess_patches": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_float),
+                                                POINTER(c_float), _P]),
+    "advgrpo_gather_l2norm_rows": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "advgrpo_dino_head_combine": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    "advgrpo_pickscore_pairs": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P]),
     "advgrpo_attention_fwd": (c_int, [_P, _P, _P, _P] + [c_int64] * 8 + [c_int] * 5 + [c_float, c_int, _P]),
 }
 

@@ -37,11 +37,17 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 constexpr int ATT_QB = 128;   // queries per workgroup
 constexpr int ATT_KB = 64;    // keys per tile
-constexpr int ATT_PITCH = 72; // LDS row pitch in elements (144 B)
 
+// HD = 64 (MMDiT, DINOv2, CLIP text) or 80 (CLIP ViT-H vision: 1280 / 16 heads).  For HD = 80 the
+// QK^T contraction is padded to 96 with zero columns in LDS (K) and zero Q fragments.
 template <int HD>
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) {
-    static_assert(HD == 64, "head dim 64");
+    static_assert(HD == 64 || HD == 80, "head dim 64 or 80");
+    constexpr int KS = (HD + 31) / 32;          // 32-deep MFMA steps over d
+    constexpr int DB = HD / 16;                 // 16-wide output blocks over d
+    constexpr int ATT_PITCH = KS * 32 + 8;      // LDS row pitch in elements: 144 B / 208 B, odd multiple of 16 B
+    constexpr int CPR = HD / 8;                 // 16-byte chunks per row
+    constexpr int NCH = (ATT_KB * CPR + 255) / 256;  // staging chunks per thread
     constexpr int TILE = ATT_KB * ATT_PITCH;  // elements per K or V tile
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * TILE];  // K0 K1 V0 V1
     bf16_t* Ks = smem;
@@ -57,40 +63,55 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
     const bf16_t* vp = p.v + (int64_t)b * p.bsv + h * HD;
 
     // ---- Q fragments (B operand: lane = query t, 8 consecutive d at (ks*32 + g*8))
-    bf16x8_t qf[2][2];
+    bf16x8_t qf[2][KS];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         int qr = q0 + qb * 16 + t;
         qr = qr < p.Sq ? qr : p.Sq - 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            qf[qb][ks] = *reinterpret_cast<const bf16x8_t*>(qp + (int64_t)qr * p.ldq + ks * 32 + g * 8);
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks * 32 + g * 8 < HD)
+                qf[qb][ks] = *reinterpret_cast<const bf16x8_t*>(qp + (int64_t)qr * p.ldq + ks * 32 + g * 8);
+            else
+                qf[qb][ks] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
     }
 
-    // ---- staging: 512 16-byte chunks per tile, 2 per thread for K and for V
-    const int srow0 = tid >> 3, scol = (tid & 7) * 8;  // second chunk: row + 32
-    uint4 kreg[2], vreg[2];
+    // ---- staging: ATT_KB * CPR 16-byte chunks per tile, NCH per thread for K and for V
+    uint4 kreg[NCH], vreg[NCH];
     auto issue = [&](int kv0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int r = kv0 + srow0 + i * 32;
-            r = r < p.Skv ? r : p.Skv - 1;
-            kreg[i] = *reinterpret_cast<const uint4*>(kp + (int64_t)r * p.ldk + scol);
-            vreg[i] = *reinterpret_cast<const uint4*>(vp + (int64_t)r * p.ldv + scol);
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * 256;
+            if (c < ATT_KB * CPR) {
+                int r = kv0 + c / CPR;
+                r = r < p.Skv ? r : p.Skv - 1;
+                kreg[i] = *reinterpret_cast<const uint4*>(kp + (int64_t)r * p.ldk + (c % CPR) * 8);
+                vreg[i] = *reinterpret_cast<const uint4*>(vp + (int64_t)r * p.ldv + (c % CPR) * 8);
+            }
         }
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int off = (srow0 + i * 32) * ATT_PITCH + scol;
-            *reinterpret_cast<uint4*>(Ks + buf * TILE + off) = kreg[i];
-            *reinterpret_cast<uint4*>(Vs + buf * TILE + off) = vreg[i];
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * 256;
+            if (c < ATT_KB * CPR) {
+                const int off = (c / CPR) * ATT_PITCH + (c % CPR) * 8;
+                *reinterpret_cast<uint4*>(Ks + buf * TILE + off) = kreg[i];
+                *reinterpret_cast<uint4*>(Vs + buf * TILE + off) = vreg[i];
+            }
         }
     };
+    if constexpr (KS * 32 != HD) {  // zero the padded K columns of both buffers once
+        for (int i = tid; i < 2 * ATT_KB * (KS * 32 - HD) / 8; i += 256) {
+            const int row = i / ((KS * 32 - HD) / 8), cc = i % ((KS * 32 - HD) / 8);
+            *reinterpret_cast<uint4*>(Ks + row * ATT_PITCH + HD + cc * 8) = uint4{0, 0, 0, 0};
+        }
+    }
 
-    f32x4 o[4][2];
+    f32x4 o[DB][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < DB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
@@ -118,7 +139,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
 #pragma unroll
             for (int j = 0; j < 2; ++j) s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             bf16x8_t kf[4];
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
@@ -170,7 +191,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
                 }
             l_run[qb] = l_run[qb] * alpha + psum;
 #pragma unroll
-            for (int db = 0; db < 4; ++db) o[db][qb] *= alpha;
+            for (int db = 0; db < DB; ++db) o[db][qb] *= alpha;
 #pragma unroll
             for (int kpair = 0; kpair < 2; ++kpair) {
                 bf16x8_t f;
@@ -186,7 +207,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
 #pragma unroll
         for (int kpair = 0; kpair < 2; ++kpair) {
 #pragma unroll
-            for (int db = 0; db < 4; ++db) {
+            for (int db = 0; db < DB; ++db) {
                 const bf16_t* a0 = Vt + ((2 * kpair) * 16 + g * 4 + (t >> 2)) * ATT_PITCH + db * 16 + (t & 3) * 4;
                 const bf16_t* a1 = a0 + 16 * ATT_PITCH;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -216,7 +237,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
         if (qi >= p.Sq) continue;
         bf16_t* op = p.o + (int64_t)b * p.bso + (int64_t)qi * p.ldo + h * HD + g * 4;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
+        for (int db = 0; db < DB; ++db) {
             const f32x4 v = o[db][qb] * inv;
             uint2 pk;
             pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
@@ -227,13 +248,14 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
 }
 
 int attention_fwd(const AttnParams& p, int B, int head_dim, hipStream_t s) {
-    ADVGRPO_CHECK(head_dim == 64, "attention: head_dim %d not supported (64 only)", head_dim);
+    ADVGRPO_CHECK(head_dim == 64 || head_dim == 80, "attention: head_dim %d not supported (64, 80)", head_dim);
     ADVGRPO_CHECK(p.q && p.k && p.v && p.o, "attention: null pointer");
     ADVGRPO_CHECK(p.Sq > 0 && p.Skv > 0 && p.H > 0 && B > 0, "attention: bad shape");
     ADVGRPO_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0,
                   "attention: row pitches must keep 16-byte (q,k,v) / 8-byte (o) alignment");
     dim3 grid((p.Sq + ATT_QB - 1) / ATT_QB, p.H, B);
-    hipLaunchKernelGGL(attention_fwd_kernel<64>, grid, dim3(256), 0, s, p);
+    if (head_dim == 64) hipLaunchKernelGGL(attention_fwd_kernel<64>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attention_fwd_kernel<80>, grid, dim3(256), 0, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

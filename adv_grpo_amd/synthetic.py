@@ -122,3 +122,77 @@ def vae_decoder_weights(cfg, seed=4321):
     norm_(W, "decoder.conv_norm_out", ch[-1], g)
     conv_(W, "decoder.conv_out", 3, ch[-1], 3, g)
     return W
+
+
+def _ln(W, name, d, g):
+    W[name + ".weight"] = 1 + 0.1 * torch.randn(d, generator=g)
+    W[name + ".bias"] = 0.1 * torch.randn(d, generator=g)
+
+
+def clip_weights(cfg, seed=777):
+    """fp32 CPU weights keyed like transformers CLIPModel.state_dict() (PickScore_v1 architecture)."""
+    g = _gen(seed)
+    W = {"logit_scale": torch.tensor(math.log(100.0))}
+
+    def layers(pfx, n, d, mlp):
+        for i in range(n):
+            p = f"{pfx}.encoder.layers.{i}"
+            _ln(W, f"{p}.layer_norm1", d, g); _ln(W, f"{p}.layer_norm2", d, g)
+            for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                linear_(W, f"{p}.self_attn.{nm}", d, d, g)
+            linear_(W, f"{p}.mlp.fc1", mlp, d, g)
+            linear_(W, f"{p}.mlp.fc2", d, mlp, g)
+    v = "vision_model"
+    W[f"{v}.embeddings.patch_embedding.weight"] = torch.randn(cfg.v_hidden, 3, cfg.patch, cfg.patch, generator=g) / math.sqrt(3 * cfg.patch ** 2)
+    W[f"{v}.embeddings.class_embedding"] = torch.randn(cfg.v_hidden, generator=g) * 0.5
+    npos = (cfg.image_size // cfg.patch) ** 2 + 1
+    W[f"{v}.embeddings.position_embedding.weight"] = torch.randn(npos, cfg.v_hidden, generator=g) * 0.5
+    _ln(W, f"{v}.pre_layrnorm", cfg.v_hidden, g)
+    layers(v, cfg.v_layers, cfg.v_hidden, cfg.v_mlp)
+    _ln(W, f"{v}.post_layernorm", cfg.v_hidden, g)
+    linear_(W, "visual_projection", cfg.proj, cfg.v_hidden, g, bias=False)
+    t = "text_model"
+    W[f"{t}.embeddings.token_embedding.weight"] = torch.randn(cfg.vocab, cfg.t_hidden, generator=g) * 0.5
+    W[f"{t}.embeddings.position_embedding.weight"] = torch.randn(cfg.max_pos, cfg.t_hidden, generator=g) * 0.5
+    layers(t, cfg.t_layers, cfg.t_hidden, cfg.t_mlp)
+    _ln(W, f"{t}.final_layer_norm", cfg.t_hidden, g)
+    linear_(W, "text_projection", cfg.proj, cfg.t_hidden, g, bias=False)
+    return W
+
+
+def dino_weights(cfg, seed=888):
+    """fp32 CPU weights keyed like timm vit_base_patch14_dinov2 state_dict()."""
+    g = _gen(seed)
+    D = cfg.hidden
+    W = {"patch_embed.proj.weight": torch.randn(D, 3, cfg.patch, cfg.patch, generator=g) / math.sqrt(3 * cfg.patch ** 2),
+         "patch_embed.proj.bias": torch.randn(D, generator=g) * 0.1,
+         "cls_token": torch.randn(1, 1, D, generator=g) * 0.5,
+         "pos_embed": torch.randn(1, (cfg.image_size // cfg.patch) ** 2 + 1, D, generator=g) * 0.5}
+    for i in range(cfg.layers):
+        p = f"blocks.{i}"
+        _ln(W, f"{p}.norm1", D, g); _ln(W, f"{p}.norm2", D, g)
+        linear_(W, f"{p}.attn.qkv", 3 * D, D, g); linear_(W, f"{p}.attn.proj", D, D, g)
+        linear_(W, f"{p}.mlp.fc1", cfg.mlp, D, g); linear_(W, f"{p}.mlp.fc2", D, cfg.mlp, g)
+        W[f"{p}.ls1.gamma"] = 0.3 + 0.1 * torch.randn(D, generator=g)
+        W[f"{p}.ls2.gamma"] = 0.3 + 0.1 * torch.randn(D, generator=g)
+    _ln(W, "norm", D, g)
+    return W
+
+
+def dino_head_weights(in_dim=768, hidden=512, seed=999):
+    """DINOHead (train_sd3_fast_dino_patch.py:592-603): layers.0 Linear(in,512), layers.2 Linear(512,1)."""
+    g = _gen(seed)
+    W = {}
+    linear_(W, "layers.0", hidden, in_dim, g, std=1.0)      # inputs are unit vectors: keep logits O(1)
+    linear_(W, "layers.2", 1, hidden, g)
+    return W
+
+
+def clip_input_ids(n, seed=3, vocab=49408, eos=49407, length=77):
+    """Synthetic CLIP token ids: random tokens, EOS at a random position >= 8, pad (= EOS) after."""
+    g = _gen(seed)
+    ids = torch.randint(1, eos - 1, (n, length), generator=g)
+    pos = torch.randint(8, length, (n,), generator=g)
+    for i in range(n):
+        ids[i, pos[i]:] = eos
+    return ids

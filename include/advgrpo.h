@@ -177,6 +177,34 @@ int advgrpo_latents_to_nhwc(const void* z, int z_dtype, void* out, int B, int C,
 int advgrpo_image_postprocess(const void* y, int y_dtype, int ldc, float* image, int B, int H, int W,
                               void* stream);
 
+/* ------------------------------------------------------------------ reward preprocessing + epilogues
+ * CLIP path: (x*255).round().clamp -> uint8 (adv_grpo/rewards.py:567), Pillow 8-bit antialiased bicubic
+ * resize H x W -> OH x OW (bit-exact emulation of CLIPProcessor's PIL resize, pickscore_scorer.py:21-27),
+ * rescale 1/255, normalise, and im2col for the 14x14 patch embedding: patches bf16 [B*(OH/14)*(OW/14), 640]
+ * (column = c*196 + iy*14 + ix; 588..639 zero).  bounds_{h,v}: int [out, 2] = (first tap, taps);
+ * coefs_{h,v}: int [out, ksize] 22-bit fixed point (device; built on the host, adv_grpo_amd/preprocess.py).
+ * tmp: B*3*H*OW bytes.  mean3_host/std3_host: HOST float[3]. */
+int advgrpo_clip_preprocess_patches(const void* image, int image_dtype, void* patches, uint8_t* tmp,
+                                    int B, int H, int W, int OH, int OW,
+                                    const int* bounds_h, const int* coefs_h, int ksize_h,
+                                    const int* bounds_v, const int* coefs_v, int ksize_v,
+                                    const float* mean3_host, const float* std3_host, void* stream);
+/* DINO path (adv_grpo/rewards.py:379-391): F.interpolate(bicubic, align_corners=False) to OH x OW on
+ * bf16-rounded pixels, bf16 round, (x-mean)/std in f32, bf16; same im2col output. */
+int advgrpo_dino_preprocess_patches(const void* image, int image_dtype, void* patches, int B, int H, int W,
+                                    int OH, int OW, const float* mean3_host, const float* std3_host,
+                                    void* stream);
+/* rows [B*(1+n), D]: row 0 = feats[b,0], rows 1.. = feats[b, 1+idx[b,j]], each x/(||x||+eps) (rewards.py:400-412). */
+int advgrpo_gather_l2norm_rows(const void* feats, const int64_t* idx, void* out, int B, int T, int D, int n,
+                               float eps, void* stream);
+/* DINO head second Linear + cls/patch mix (rewards.py:414-421): hidden [B*(1+n), Hd] bf16 after Linear+GELU. */
+int advgrpo_dino_head_combine(const void* hidden, const void* w2, const void* b2, int B, int Hd, int n,
+                              float cls_weight, float* hybrid, float* cls_score, float* patch_scores,
+                              void* stream);
+/* PickScore (pickscore_scorer.py:40-52): scores[b] = logit_scale_exp * cos(text_b, image_b) / 26. */
+int advgrpo_pickscore_pairs(const void* image_embs, const void* text_embs, int B, int P, float logit_scale_exp,
+                            float* scores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

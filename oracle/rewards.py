@@ -30,9 +30,17 @@ def weighted_sum(score_dict, per_scorer_scores):
     return details
 
 
-def dino_preprocess(images):
-    """rewards.py:379-391: bicubic (no antialias) to 518, ImageNet normalise, cast bf16."""
-    images = F.interpolate(images, size=(518, 518), mode="bicubic", align_corners=False)
+def dino_preprocess(images, cuda_semantics=False):
+    """rewards.py:379-391: bicubic (no antialias) to 518, ImageNet normalise, cast bf16.
+
+    For bf16 inputs torch-CPU rounds the four cubic weights to bf16 while torch-CUDA (what the reference
+    runs on) keeps weights and accumulation in f32 and rounds only the result.  cuda_semantics=False
+    reproduces the CPU op bit-exactly (this is what the golden made on the CPU pins);
+    cuda_semantics=True is the GPU arithmetic the HIP kernel follows."""
+    if cuda_semantics and images.dtype == torch.bfloat16:
+        images = F.interpolate(images.float(), size=(518, 518), mode="bicubic", align_corners=False).to(torch.bfloat16)
+    else:
+        images = F.interpolate(images, size=(518, 518), mode="bicubic", align_corners=False)
     mean = torch.tensor(IMAGENET_MEAN, device=images.device)[None, :, None, None]
     std = torch.tensor(IMAGENET_STD, device=images.device)[None, :, None, None]
     return ((images - mean) / std).to(torch.bfloat16)

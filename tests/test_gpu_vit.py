@@ -1,0 +1,128 @@
+"""GPU parity of the reward towers and their pre/post-processing against the oracle
+(oracle/vit.py is pinned against transformers in tests/test_oracle_vit.py)."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm()).item()
+
+
+def _pil_clip_preprocess(images_u8):
+    """Reference CPU path: PIL BICUBIC resize to 224, /255, CLIP normalise (CLIPProcessor, square inputs)."""
+    from adv_grpo_amd.preprocess import CLIP_MEAN, CLIP_STD
+    out = []
+    for im in images_u8:
+        r = np.asarray(Image.fromarray(im).resize((224, 224), Image.BICUBIC)).astype(np.float32) * np.float32(1 / 255)
+        out.append((r - np.array(CLIP_MEAN, dtype=np.float32)) / np.array(CLIP_STD, dtype=np.float32))
+    return torch.from_numpy(np.stack(out)).permute(0, 3, 1, 2).contiguous()
+
+
+def _unpatch(patches, B, size):
+    g = size // 14
+    x = patches.float().view(B, g, g, 640)[..., :588].reshape(B, g, g, 3, 14, 14)
+    return x.permute(0, 3, 1, 4, 2, 5).reshape(B, 3, size, size)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_clip_preprocess_is_pil_exact(dt):
+    from adv_grpo_amd import preprocess
+    from oracle.rewards import to_uint8
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(3, 3, 512, 512, generator=g).to(dt)
+    patches = preprocess.clip_patches(img.cuda(), 224)
+    u8 = to_uint8(img).permute(0, 2, 3, 1).numpy()        # rewards.py:567-569 (same dtype as the reference path)
+    ref = _pil_clip_preprocess(u8)
+    got = _unpatch(patches, 3, 224).cpu()
+    # identical uint8 resize => only the final bf16 rounding of the normalised pixel differs
+    assert torch.equal(got, ref.to(torch.bfloat16).float())
+
+
+def test_dino_preprocess_matches_torch_bicubic():
+    from adv_grpo_amd import preprocess
+    from oracle.rewards import dino_preprocess
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand(2, 3, 512, 512, generator=g).to(torch.bfloat16)
+    got = _unpatch(preprocess.dino_patches(img.cuda(), 518), 2, 518).cpu()
+    ref = dino_preprocess(img, cuda_semantics=True).float()
+    err = (got - ref).abs()
+    # the 16-tap bicubic sum is accumulated in a different order than torch's: where the f32 sums straddle
+    # a bf16 rounding boundary the interpolated pixel flips by one bf16 ulp (<= 2^-8), which /std and the
+    # final bf16 rounding turn into <= 0.06 on the normalised pixel; it must stay a rare event.
+    frac = (err > 0).float().mean().item()
+    print("dino preprocess mismatch fraction", frac, "max", err.max().item())
+    assert err.max().item() <= 0.06 and frac < 0.005 and err.mean().item() < 1e-4
+
+
+def test_clip_towers_and_pickscore_vs_oracle():
+    from adv_grpo_amd import synthetic, vit
+    from oracle import rewards as o_rw
+    from oracle import vit as o
+    cfg = o.ClipConfig(v_layers=3, t_layers=3)                  # full ViT-H widths (1280/80-dim heads, 1024), 3 layers
+    W = synthetic.clip_weights(cfg, 5)
+    Wb = {k: v.to(torch.bfloat16) for k, v in W.items()}
+    model = vit.CLIPModel(Wb, cfg, "cuda")
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand(4, 3, 512, 512, generator=g).to(torch.bfloat16)
+    ids = synthetic.clip_input_ids(4, 3)
+    ie = model.get_image_features(images=img.cuda())
+    te = model.get_text_features(ids)
+    W32 = {k: v.float().cuda() for k, v in Wb.items()}
+    px = _pil_clip_preprocess(o_rw.to_uint8(img).permute(0, 2, 3, 1).numpy()).to(torch.bfloat16).float().cuda()
+    ri = o.clip_image_features(W32, cfg, px)
+    rt = o.clip_text_features(W32, cfg, ids.cuda())
+    assert _rel(ie, ri) < 2e-2 and _rel(te, rt) < 2e-2, (_rel(ie, ri), _rel(te, rt))
+    s = vit.pickscore_scores(ie, te, Wb["logit_scale"].float())
+    rs = o_rw.pickscore_from_embeddings(ri, rt, W32["logit_scale"])
+    # <= 1e-3 abs on the /26 score scale would need ~3e-4 cosine accuracy; bf16 towers give ~1e-2 relative
+    assert (s.cpu() - rs.cpu()).abs().max().item() < 2e-2 * max(1.0, rs.abs().max().item())
+
+
+def test_clip_vit_h_full_depth_image_tower():
+    from adv_grpo_amd import synthetic, vit
+    from oracle import vit as o
+    cfg = o.ClipConfig(t_layers=1)
+    W = synthetic.clip_weights(cfg, 6)
+    Wb = {k: v.to(torch.bfloat16) for k, v in W.items()}
+    model = vit.CLIPModel(Wb, cfg, "cuda")
+    g = torch.Generator().manual_seed(3)
+    px = torch.randn(2, 3, 224, 224, generator=g).to(torch.bfloat16)
+    gsz = 16
+    patches = torch.zeros(2 * 256, 640, dtype=torch.bfloat16)
+    patches[:, :588] = px.view(2, 3, gsz, 14, gsz, 14).permute(0, 2, 4, 1, 3, 5).reshape(2 * 256, 588)
+    ie = model.get_image_features(pixel_patches=patches.cuda())
+    ri = o.clip_image_features({k: v.float().cuda() for k, v in Wb.items()}, cfg, px.float().cuda())
+    assert _rel(ie, ri) < 3e-2, _rel(ie, ri)
+
+
+def test_dinov2_features_and_patch_head_vs_oracle():
+    from adv_grpo_amd import synthetic, vit
+    from oracle import losses as o_l
+    from oracle import rewards as o_rw
+    from oracle import vit as o
+    cfg = o.DinoConfig()                                        # full ViT-B/14 @ 518: 1370 tokens, 12 layers
+    W = synthetic.dino_weights(cfg, 7)
+    Wb = {k: v.to(torch.bfloat16) for k, v in W.items()}
+    model = vit.DinoV2(Wb, cfg, "cuda")
+    g = torch.Generator().manual_seed(4)
+    img = torch.rand(2, 3, 512, 512, generator=g).to(torch.bfloat16)
+    feats = model.forward_features(images=img.cuda())
+    ref = o.dino_forward_features({k: v.float().cuda() for k, v in Wb.items()}, cfg, o_rw.dino_preprocess(img, cuda_semantics=True).float().cuda())
+    assert feats.shape == (2, 1370, 768)
+    assert _rel(feats, ref) < 2e-2, _rel(feats, ref)
+    # head epilogue on identical (bf16) features and indices
+    hw = synthetic.dino_head_weights(768, 512, 8)
+    head = vit.DinoHead(hw, "cuda")
+    idx = torch.randint(0, 1369, (2, 64), generator=g)
+    hyb, cls, pat = head.patch_score(feats, idx.cuda())
+    oh = o_l.DinoHead(768, 512)
+    oh.load_state_dict({k: v for k, v in hw.items()})
+    oh = oh.to(torch.bfloat16)
+    rh, rc, rp = o_rw.dino_patch_score(feats.cpu(), oh, idx)
+    assert (cls.cpu() - rc.float()).abs().max().item() < 3e-2 * max(1.0, rc.float().abs().max().item())
+    assert (hyb.cpu() - rh.float()).abs().max().item() < 3e-2 * max(1.0, rh.float().abs().max().item())
+    assert (pat.cpu() - rp.float()).abs().max().item() < 5e-2 * max(1.0, rp.float().abs().max().item())
