@@ -1,0 +1,88 @@
+"""SD3 rollout with per-step log-prob on the gfx950 kernels.
+
+Drop-in for ``pipeline_with_logprob_random``
+(adv_grpo/diffusers_patch/sd3_pipeline_with_logprob_fast.py:453-674): same keyword arguments, same return
+tuple ``(image, all_latents, all_log_probs, all_timesteps)``, same cast order (SDE step in f32, latents stored
+in the prompt-embedding dtype, log-prob from the pre-cast sample) and the same RNG call pattern (one epsilon
+draw per step, also when noise_level == 0).  ``self`` is a pipeline object exposing ``transformer``,
+``scheduler``, ``vae`` (see adv_grpo_amd/pipeline.py).
+
+What changes underneath: per step ONE transformer call on the CFG batch, then ONE fused kernel for CFG
+combine + SDE step + log-prob + cast (instead of ~12 torch kernels, a randn and two host syncs), epsilon from
+an in-kernel Philox stream (or injected via ``noises=`` for parity tests), no ``index_for_timestep`` sync.
+"""
+import random
+
+import torch
+
+from ..scheduler import retrieve_timesteps
+from .sd3_sde_with_logprob import sde_step_cfg
+
+
+@torch.no_grad()
+def pipeline_with_logprob_random(self, prompt=None, prompt_2=None, prompt_3=None, height=None, width=None,
+                                 num_inference_steps=28, mini_num_image_per_prompt=1, sigmas=None, guidance_scale=7.0,
+                                 negative_prompt=None, negative_prompt_2=None, negative_prompt_3=None, generator=None,
+                                 latents=None, prompt_embeds=None, negative_prompt_embeds=None,
+                                 pooled_prompt_embeds=None, negative_pooled_prompt_embeds=None, output_type="pt",
+                                 joint_attention_kwargs=None, clip_skip=None,
+                                 callback_on_step_end_tensor_inputs=("latents",), max_sequence_length=256,
+                                 skip_layer_guidance_scale=2.8, noise_level=0.7, train_num_steps=1, process_index=0,
+                                 sample_num_steps=10, random_timestep=None, noises=None, seed=None):
+    if prompt_embeds is None:
+        raise ValueError("prompt strings need text encoders, which are outside the accelerated path "
+                         "(SURVEY.md 8a2 / f3): pass prompt_embeds / pooled_prompt_embeds")
+    height = height or self.default_sample_size * self.vae_scale_factor
+    width = width or self.default_sample_size * self.vae_scale_factor
+    self._guidance_scale = guidance_scale
+    device = self._execution_device
+    G = mini_num_image_per_prompt
+    pe = prompt_embeds.to(device).repeat(G, 1, 1)                              # PF:551-554
+    ppe = pooled_prompt_embeds.to(device).repeat(G, 1)
+    do_cfg = guidance_scale > 1
+    if do_cfg:
+        npe = negative_prompt_embeds.to(device).repeat(G, 1, 1)
+        nppe = negative_pooled_prompt_embeds.to(device).repeat(G, 1)
+        tem_pe = torch.cat([npe, pe], dim=0)                                   # PF:598-599
+        tem_ppe = torch.cat([nppe, ppe], dim=0)
+    else:
+        tem_pe, tem_ppe = pe, ppe
+    dtype = prompt_embeds.dtype
+    B = pe.shape[0]
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())
+    if latents is None:                                                        # PF:559-568 prepare_latents
+        latents = self.prepare_latents(B, self.transformer.config.in_channels, height, width, dtype, device, seed)
+    latents = latents.to(device=device, dtype=dtype)
+    timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device)   # PF:574
+    random.seed(process_index)                                                 # PF:585
+    if random_timestep is None:
+        random_timestep = random.randint(0, sample_num_steps // 2)
+    all_latents, all_log_probs, all_timesteps = [], [], []
+    n_per = latents[0].numel()
+    for i in range(len(timesteps)):
+        t = timesteps[i]
+        if i == random_timestep:                                               # PF:606-623
+            cur = noise_level
+            all_latents.append(latents)
+        elif random_timestep < i < random_timestep + train_num_steps:
+            cur = noise_level
+        else:
+            cur = 0
+        inp = torch.cat([latents] * 2) if do_cfg else latents                  # PF:625
+        v = self.transformer(hidden_states=inp, timestep=t.expand(inp.shape[0]), encoder_hidden_states=tem_pe,
+                             pooled_projections=tem_ppe, joint_attention_kwargs=joint_attention_kwargs,
+                             return_dict=False)[0]                             # PF:630-637
+        vu, vt = (v[:B], v[B:]) if do_cfg else (v, None)
+        want_f32 = dtype == torch.float32
+        nxt, cast, log_prob, _, _ = sde_step_cfg(                              # PF:640-655 fused
+            self.scheduler, vu, vt, guidance_scale, None, latents, cur,
+            noise=None if noises is None else noises[i], seed=seed + 1 + i, offset=0,
+            out_dtype=None if want_f32 else dtype, want_mean=False, step_index=i)
+        latents = nxt if want_f32 else cast
+        if random_timestep <= i < random_timestep + train_num_steps:           # PF:657-660
+            all_latents.append(latents)
+            all_log_probs.append(log_prob)
+            all_timesteps.append(t.repeat(B))
+    image = self.vae.decode_to_image(latents)                                  # PF:667-670 (rescale, decode, postprocess)
+    return image, all_latents, all_log_probs, all_timesteps

@@ -1,0 +1,45 @@
+"""PickScore scorer on the gfx950 kernels.
+
+Mirror of adv_grpo/pickscore_scorer.py:5-52 (class name, ``__call__(prompt, images) -> scores[N]``).
+Differences that come with the platform, none of which change the number computed:
+  * images may be a device tensor [N,3,H,W] in [0,1] (what the trainer has) -- the uint8 quantisation and
+    PIL-exact CLIPProcessor resize run on the device instead of GPU->CPU->PIL->GPU;  a list of PIL images is
+    still accepted (converted once);
+  * prompts are either strings (needs a ``tokenizer`` callable; no tokenizer files exist on the GPU box) or
+    ready ``input_ids`` [N,77];
+  * weights come from a state dict (``model_sd``) because no checkpoint can be downloaded here.
+"""
+import numpy as np
+import torch
+
+from . import vit
+
+
+class PickScoreScorer(torch.nn.Module):
+    def __init__(self, device="cuda", dtype=torch.float32, model_sd=None, clip_cfg=None, tokenizer=None):
+        super().__init__()
+        if model_sd is None or clip_cfg is None:
+            raise RuntimeError("PickScoreScorer needs model_sd + clip_cfg (no checkpoint download on this platform)")
+        self.device = device
+        self.dtype = dtype
+        self.tokenizer = tokenizer
+        self.model = vit.CLIPModel(model_sd, clip_cfg, device)
+
+    def _images(self, images):
+        if isinstance(images, torch.Tensor):
+            return images.to(self.device)
+        arr = np.stack([np.asarray(im.convert("RGB")) for im in images])        # PIL list
+        return torch.from_numpy(arr).to(self.device).permute(0, 3, 1, 2).float() / 255.0
+
+    def _ids(self, prompt):
+        if isinstance(prompt, torch.Tensor):
+            return prompt
+        if self.tokenizer is None:
+            raise RuntimeError("string prompts need a tokenizer; pass input_ids [N,77] instead")
+        return self.tokenizer(prompt, padding="max_length", truncation=True, max_length=77, return_tensors="pt").input_ids
+
+    @torch.no_grad()
+    def __call__(self, prompt, images):
+        image_embs = self.model.get_image_features(images=self._images(images))
+        text_embs = self.model.get_text_features(self._ids(prompt))
+        return vit.pickscore_scores(image_embs, text_embs, self.model.logit_scale)

@@ -13,15 +13,38 @@ import numpy as np
 import torch
 
 
+_DEVICE = "cpu"
+
+
+class on_device:
+    """Context manager: draw the synthetic weights directly on a device (bench start-up time).  The
+    values then come from that device's generator stream, not the CPU one the parity tests use."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def __enter__(self):
+        global _DEVICE
+        self.prev, _DEVICE = _DEVICE, self.device
+
+    def __exit__(self, *a):
+        global _DEVICE
+        _DEVICE = self.prev
+
+
 def _gen(seed):
-    return torch.Generator().manual_seed(seed)
+    return torch.Generator(device=_DEVICE).manual_seed(seed)
+
+
+def _randn(*shape, generator):
+    return torch.randn(*shape, generator=generator, device=generator.device)
 
 
 def linear_(W, name, out_f, in_f, g, bias=True, std=None):
     std = (1.0 / math.sqrt(in_f)) if std is None else std
-    W[name + ".weight"] = torch.randn(out_f, in_f, generator=g) * std
+    W[name + ".weight"] = _randn(out_f, in_f, generator=g) * std
     if bias:
-        W[name + ".bias"] = torch.randn(out_f, generator=g) * 0.1
+        W[name + ".bias"] = _randn(out_f, generator=g) * 0.1
 
 
 def sincos_pos_embed_2d(dim, grid_size, base_size):
@@ -34,7 +57,7 @@ def sincos_pos_embed_2d(dim, grid_size, base_size):
     gw = np.arange(grid_size, dtype=np.float32) / (grid_size / base_size)
     grid = np.stack(np.meshgrid(gw, gh), axis=0).reshape(2, 1, grid_size, grid_size)
     emb = np.concatenate([emb1d(dim // 2, grid[0]), emb1d(dim // 2, grid[1])], axis=1)
-    return torch.from_numpy(emb).float().unsqueeze(0)
+    return torch.from_numpy(emb).float().unsqueeze(0).to(_DEVICE)
 
 
 def mmdit_weights(cfg, seed=1234):
@@ -42,8 +65,8 @@ def mmdit_weights(cfg, seed=1234):
     g = _gen(seed)
     D, W = cfg.dim, {}
     ps, C = cfg.patch_size, cfg.in_channels
-    W["pos_embed.proj.weight"] = torch.randn(D, C, ps, ps, generator=g) / math.sqrt(C * ps * ps)
-    W["pos_embed.proj.bias"] = torch.randn(D, generator=g) * 0.1
+    W["pos_embed.proj.weight"] = _randn(D, C, ps, ps, generator=g) / math.sqrt(C * ps * ps)
+    W["pos_embed.proj.bias"] = _randn(D, generator=g) * 0.1
     W["pos_embed.pos_embed"] = sincos_pos_embed_2d(D, cfg.pos_embed_max_size, 64)
     linear_(W, "time_text_embed.timestep_embedder.linear_1", D, 256, g)
     linear_(W, "time_text_embed.timestep_embedder.linear_2", D, D, g)
@@ -61,12 +84,12 @@ def mmdit_weights(cfg, seed=1234):
         if not last:
             linear_(W, f"{p}.attn.to_add_out", D, D, g)
         for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
-            W[f"{p}.attn.{n}.weight"] = 1 + 0.1 * torch.randn(cfg.head_dim, generator=g)
+            W[f"{p}.attn.{n}.weight"] = 1 + 0.1 * _randn(cfg.head_dim, generator=g)
         if dual:
             for n in ("to_q", "to_k", "to_v", "to_out.0"):
                 linear_(W, f"{p}.attn2.{n}", D, D, g)
             for n in ("norm_q", "norm_k"):
-                W[f"{p}.attn2.{n}.weight"] = 1 + 0.1 * torch.randn(cfg.head_dim, generator=g)
+                W[f"{p}.attn2.{n}.weight"] = 1 + 0.1 * _randn(cfg.head_dim, generator=g)
         linear_(W, f"{p}.ff.net.0.proj", 4 * D, D, g)
         linear_(W, f"{p}.ff.net.2", D, 4 * D, g)
         if not last:
@@ -79,19 +102,19 @@ def mmdit_weights(cfg, seed=1234):
 
 def prompt_embeddings(seed=7, n_tokens=205, ctx_dim=4096, pooled_dim=2048):
     """Synthetic prompt: (prompt_embeds [1,205,4096], pooled [1,2048], negative ..., negative pooled ...)."""
-    g = _gen(seed)
+    g = torch.Generator().manual_seed(seed)   # inputs always come from the CPU stream
     return (torch.randn(1, n_tokens, ctx_dim, generator=g), torch.randn(1, pooled_dim, generator=g),
             torch.randn(1, n_tokens, ctx_dim, generator=g), torch.randn(1, pooled_dim, generator=g))
 
 
 def conv_(W, name, cout, cin, k, g):
-    W[name + ".weight"] = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
-    W[name + ".bias"] = torch.randn(cout, generator=g) * 0.1
+    W[name + ".weight"] = _randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    W[name + ".bias"] = _randn(cout, generator=g) * 0.1
 
 
 def norm_(W, name, c, g):
-    W[name + ".weight"] = 1 + 0.1 * torch.randn(c, generator=g)
-    W[name + ".bias"] = 0.1 * torch.randn(c, generator=g)
+    W[name + ".weight"] = 1 + 0.1 * _randn(c, generator=g)
+    W[name + ".bias"] = 0.1 * _randn(c, generator=g)
 
 
 def vae_decoder_weights(cfg, seed=4321):
@@ -125,14 +148,14 @@ def vae_decoder_weights(cfg, seed=4321):
 
 
 def _ln(W, name, d, g):
-    W[name + ".weight"] = 1 + 0.1 * torch.randn(d, generator=g)
-    W[name + ".bias"] = 0.1 * torch.randn(d, generator=g)
+    W[name + ".weight"] = 1 + 0.1 * _randn(d, generator=g)
+    W[name + ".bias"] = 0.1 * _randn(d, generator=g)
 
 
 def clip_weights(cfg, seed=777):
     """fp32 CPU weights keyed like transformers CLIPModel.state_dict() (PickScore_v1 architecture)."""
     g = _gen(seed)
-    W = {"logit_scale": torch.tensor(math.log(100.0))}
+    W = {"logit_scale": torch.tensor(math.log(100.0), device=_DEVICE)}
 
     def layers(pfx, n, d, mlp):
         for i in range(n):
@@ -143,17 +166,17 @@ def clip_weights(cfg, seed=777):
             linear_(W, f"{p}.mlp.fc1", mlp, d, g)
             linear_(W, f"{p}.mlp.fc2", d, mlp, g)
     v = "vision_model"
-    W[f"{v}.embeddings.patch_embedding.weight"] = torch.randn(cfg.v_hidden, 3, cfg.patch, cfg.patch, generator=g) / math.sqrt(3 * cfg.patch ** 2)
-    W[f"{v}.embeddings.class_embedding"] = torch.randn(cfg.v_hidden, generator=g) * 0.5
+    W[f"{v}.embeddings.patch_embedding.weight"] = _randn(cfg.v_hidden, 3, cfg.patch, cfg.patch, generator=g) / math.sqrt(3 * cfg.patch ** 2)
+    W[f"{v}.embeddings.class_embedding"] = _randn(cfg.v_hidden, generator=g) * 0.5
     npos = (cfg.image_size // cfg.patch) ** 2 + 1
-    W[f"{v}.embeddings.position_embedding.weight"] = torch.randn(npos, cfg.v_hidden, generator=g) * 0.5
+    W[f"{v}.embeddings.position_embedding.weight"] = _randn(npos, cfg.v_hidden, generator=g) * 0.5
     _ln(W, f"{v}.pre_layrnorm", cfg.v_hidden, g)
     layers(v, cfg.v_layers, cfg.v_hidden, cfg.v_mlp)
     _ln(W, f"{v}.post_layernorm", cfg.v_hidden, g)
     linear_(W, "visual_projection", cfg.proj, cfg.v_hidden, g, bias=False)
     t = "text_model"
-    W[f"{t}.embeddings.token_embedding.weight"] = torch.randn(cfg.vocab, cfg.t_hidden, generator=g) * 0.5
-    W[f"{t}.embeddings.position_embedding.weight"] = torch.randn(cfg.max_pos, cfg.t_hidden, generator=g) * 0.5
+    W[f"{t}.embeddings.token_embedding.weight"] = _randn(cfg.vocab, cfg.t_hidden, generator=g) * 0.5
+    W[f"{t}.embeddings.position_embedding.weight"] = _randn(cfg.max_pos, cfg.t_hidden, generator=g) * 0.5
     layers(t, cfg.t_layers, cfg.t_hidden, cfg.t_mlp)
     _ln(W, f"{t}.final_layer_norm", cfg.t_hidden, g)
     linear_(W, "text_projection", cfg.proj, cfg.t_hidden, g, bias=False)
@@ -164,17 +187,17 @@ def dino_weights(cfg, seed=888):
     """fp32 CPU weights keyed like timm vit_base_patch14_dinov2 state_dict()."""
     g = _gen(seed)
     D = cfg.hidden
-    W = {"patch_embed.proj.weight": torch.randn(D, 3, cfg.patch, cfg.patch, generator=g) / math.sqrt(3 * cfg.patch ** 2),
-         "patch_embed.proj.bias": torch.randn(D, generator=g) * 0.1,
-         "cls_token": torch.randn(1, 1, D, generator=g) * 0.5,
-         "pos_embed": torch.randn(1, (cfg.image_size // cfg.patch) ** 2 + 1, D, generator=g) * 0.5}
+    W = {"patch_embed.proj.weight": _randn(D, 3, cfg.patch, cfg.patch, generator=g) / math.sqrt(3 * cfg.patch ** 2),
+         "patch_embed.proj.bias": _randn(D, generator=g) * 0.1,
+         "cls_token": _randn(1, 1, D, generator=g) * 0.5,
+         "pos_embed": _randn(1, (cfg.image_size // cfg.patch) ** 2 + 1, D, generator=g) * 0.5}
     for i in range(cfg.layers):
         p = f"blocks.{i}"
         _ln(W, f"{p}.norm1", D, g); _ln(W, f"{p}.norm2", D, g)
         linear_(W, f"{p}.attn.qkv", 3 * D, D, g); linear_(W, f"{p}.attn.proj", D, D, g)
         linear_(W, f"{p}.mlp.fc1", cfg.mlp, D, g); linear_(W, f"{p}.mlp.fc2", D, cfg.mlp, g)
-        W[f"{p}.ls1.gamma"] = 0.3 + 0.1 * torch.randn(D, generator=g)
-        W[f"{p}.ls2.gamma"] = 0.3 + 0.1 * torch.randn(D, generator=g)
+        W[f"{p}.ls1.gamma"] = 0.3 + 0.1 * _randn(D, generator=g)
+        W[f"{p}.ls2.gamma"] = 0.3 + 0.1 * _randn(D, generator=g)
     _ln(W, "norm", D, g)
     return W
 
@@ -190,7 +213,7 @@ def dino_head_weights(in_dim=768, hidden=512, seed=999):
 
 def clip_input_ids(n, seed=3, vocab=49408, eos=49407, length=77):
     """Synthetic CLIP token ids: random tokens, EOS at a random position >= 8, pad (= EOS) after."""
-    g = _gen(seed)
+    g = torch.Generator().manual_seed(seed)
     ids = torch.randint(1, eos - 1, (n, length), generator=g)
     pos = torch.randint(8, length, (n,), generator=g)
     for i in range(n):

@@ -30,6 +30,7 @@ class FlowMatchEulerScheduler:
         return s * self.num_train_timesteps
 
     def set_timesteps(self, num_inference_steps, device=None):
+        device = device if device is not None else getattr(self, "device", None)
         t = np.linspace(self._sigma_to_t(self.sigma_max), self._sigma_to_t(self.sigma_min),
                         num_inference_steps)
         sig = t / self.num_train_timesteps
