@@ -238,6 +238,15 @@ static int launch(const GemmParams& p, hipStream_t s) {
     return 0;
 }
 
+// tile variant the dispatcher picks: 0 = 128x128, 1 = 128x64, 2 = 64x128 (+4 for the conv loader)
+static int gemm_variant(int M, int N, int batch, int conv) {
+    const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
+    if (conv) return 4 + (N <= 64 ? 1 : 0);
+    if (N <= 64) return 1;
+    if (t128 >= 256 || M > 2048) return 0;
+    return 2;
+}
+
 int gemm_bf16(const GemmParams& p, hipStream_t s) {
     ADVGRPO_CHECK(p.A && p.W && p.C, "gemm: null operand");
     ADVGRPO_CHECK(p.M > 0 && p.N > 0 && p.K > 0 && p.K % 64 == 0, "gemm: need M,N>0 and K %% 64 == 0 (M=%d N=%d K=%d)",
@@ -246,22 +255,24 @@ int gemm_bf16(const GemmParams& p, hipStream_t s) {
     ADVGRPO_CHECK(p.out_dtype == ADVGRPO_BF16 || p.out_dtype == ADVGRPO_F32, "gemm: bad out dtype");
     ADVGRPO_CHECK(p.batch >= 1, "gemm: batch must be >= 1");
     // tile choice: big tiles when they still fill the 256 CUs, smaller ones for skinny problems
-    const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
+    const int variant = gemm_variant(p.M, p.N, p.batch, p.conv);
     if (p.conv) {
         ADVGRPO_CHECK(p.Cin % 64 == 0 && p.K == 9 * p.Cin && p.zero_page && p.batch == 1,
                       "conv3x3: need Cin %% 64 == 0, K == 9*Cin, a zero page and batch 1 (Cin=%d K=%d)", p.Cin, p.K);
         ADVGRPO_CHECK((p.Hout % (1 << p.ups)) == 0 && (p.Wout % (1 << p.ups)) == 0, "conv3x3: bad upsample shape");
-        if (p.N <= 64) return launch<128, 64, true>(p, s);
+        if (variant == 5) return launch<128, 64, true>(p, s);
         return launch<128, 128, true>(p, s);
     }
-    if (p.N <= 64) return launch<128, 64, false>(p, s);
-    if (t128 >= 256 || p.M > 2048) return launch<128, 128, false>(p, s);
+    if (variant == 1) return launch<128, 64, false>(p, s);
+    if (variant == 0) return launch<128, 128, false>(p, s);
     return launch<64, 128, false>(p, s);
 }
 
 }  // namespace advgrpo
 
 using namespace advgrpo;
+
+extern "C" int advgrpo_gemm_variant(int M, int N, int batch, int conv) { return gemm_variant(M, N, batch < 1 ? 1 : batch, conv); }
 
 extern "C" int advgrpo_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                                  int out_dtype, int M, int N, int K, const void* bias, int act, float alpha,

@@ -1,0 +1,60 @@
+"""Architecture constants of the models on the hot path (public HF configs)."""
+from dataclasses import dataclass
+
+
+@dataclass
+class MMDiTConfig:  # stabilityai/stable-diffusion-3.5-medium transformer ("MMDiT-X")
+    num_layers: int = 24
+    num_heads: int = 24
+    head_dim: int = 64
+    in_channels: int = 16
+    out_channels: int = 16
+    patch_size: int = 2
+    joint_attention_dim: int = 4096
+    pooled_projection_dim: int = 2048
+    pos_embed_max_size: int = 384
+    dual_attention_layers: tuple = tuple(range(13))
+    qk_norm: bool = True
+
+    @property
+    def dim(self):
+        return self.num_heads * self.head_dim
+
+
+@dataclass
+class VaeConfig:  # SD3 VAE
+    latent_channels: int = 16
+    block_out_channels: tuple = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    norm_num_groups: int = 32
+    scaling_factor: float = 1.5305
+    shift_factor: float = 0.0609
+
+
+@dataclass
+class ClipConfig:  # yuvalkirstain/PickScore_v1 = CLIP ViT-H/14
+    v_hidden: int = 1280
+    v_layers: int = 32
+    v_heads: int = 16
+    v_mlp: int = 5120
+    image_size: int = 224
+    patch: int = 14
+    t_hidden: int = 1024
+    t_layers: int = 24
+    t_heads: int = 16
+    t_mlp: int = 4096
+    vocab: int = 49408
+    max_pos: int = 77
+    proj: int = 1024
+    eos_token_id: int = 49407
+    act: str = "gelu"
+
+
+@dataclass
+class DinoConfig:  # timm vit_base_patch14_dinov2.lvd142m
+    hidden: int = 768
+    layers: int = 12
+    heads: int = 12
+    mlp: int = 3072
+    image_size: int = 518
+    patch: int = 14

@@ -7,6 +7,33 @@ from . import _lib
 
 ACT = {None: 0, "none": 0, "gelu_tanh": 1, "gelu": 2, "gelu_erf": 2, "silu": 3}
 
+GEMM_VARIANTS = {0: "gemm_bf16_kernel<128,128,false>", 1: "gemm_bf16_kernel<128,64,false>",
+                 2: "gemm_bf16_kernel<64,128,false>", 4: "gemm_bf16_kernel<128,128,true>",
+                 5: "gemm_bf16_kernel<128,64,true>"}
+# bench.py sets this to a list to collect (kernel name, flops, start event, end event) per GEMM launch;
+# events are recorded on the stream the kernel is launched on (torch's current stream).
+PROFILE = None
+
+
+class _Prof:
+    def __init__(self, M, N, K, batch, conv):
+        self.on = PROFILE is not None
+        if self.on:
+            lib = _lib.load()
+            self.name = GEMM_VARIANTS[lib.advgrpo_gemm_variant(M, N, batch, conv)]
+            self.flops = 2.0 * M * N * K * batch
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.s.record()
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e.record()
+            PROFILE.append((self.name, self.flops, self.s, self.e))
+
 
 def gemm(a, w, bias=None, act=None, alpha=1.0, gate=None, gate_rows=0, residual=None, out=None,
          out_dtype=torch.bfloat16, seg=None, a_seg=None, M=None):
@@ -27,7 +54,8 @@ def gemm(a, w, bias=None, act=None, alpha=1.0, gate=None, gate_rows=0, residual=
     assert out.stride(-1) == 1
     seg_rows, seg_stride, seg_off = seg if seg is not None else (0, 0, 0)
     a_rows, a_stride, a_off = a_seg if a_seg is not None else (0, 0, 0)
-    _lib.check(lib.advgrpo_gemm_bf16(
+    with _Prof(M, N, K, 1, 0):
+      _lib.check(lib.advgrpo_gemm_bf16(
         a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(-2),
         _lib.dtype_code(out.dtype), M, N, K, _lib.ptr(bias), ACT[act], float(alpha),
         gate.data_ptr() if gate is not None else None, gate.stride(0) if gate is not None else 0, int(gate_rows),
@@ -45,7 +73,8 @@ def bmm_nt(a, w, out=None, out_dtype=torch.bfloat16, alpha=1.0):
     assert a.stride(2) == 1 and w.stride(2) == 1
     if out is None:
         out = torch.empty(B, M, N, dtype=out_dtype, device=a.device)
-    _lib.check(lib.advgrpo_gemm_bf16(
+    with _Prof(M, N, K, B, 0):
+      _lib.check(lib.advgrpo_gemm_bf16(
         a.data_ptr(), a.stride(1), w.data_ptr(), w.stride(1), out.data_ptr(), out.stride(1),
         _lib.dtype_code(out.dtype), M, N, K, None, 0, float(alpha), None, 0, 0, None, 0, 0, 0, 0, 0, 0, 0,
         B, a.stride(0), w.stride(0), out.stride(0), _lib.stream_ptr()))
@@ -150,7 +179,8 @@ def conv3x3(x, w, bias=None, upsample=False, act=None, residual=None, out_dtype=
     Cout = w.shape[0]
     Hout, Wout = (Hin * 2, Win * 2) if upsample else (Hin, Win)
     y = torch.empty(B, Hout, Wout, Cout, dtype=out_dtype, device=x.device)
-    _lib.check(lib.advgrpo_conv3x3_nhwc(_lib.ptr(x), _lib.ptr(w), y.data_ptr(), _lib.dtype_code(out_dtype), B, Hout, Wout,
+    with _Prof(B * Hout * Wout, Cout, 9 * Cin, 1, 1):
+      _lib.check(lib.advgrpo_conv3x3_nhwc(_lib.ptr(x), _lib.ptr(w), y.data_ptr(), _lib.dtype_code(out_dtype), B, Hout, Wout,
                                         Cin, Cout, int(upsample), _lib.ptr(bias), ACT[act], _lib.ptr(residual),
                                         zero_page(x.device).data_ptr(), _lib.stream_ptr()))
     return y

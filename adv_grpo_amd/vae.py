@@ -32,7 +32,7 @@ class AutoencoderKLDecoder:
             if v.dim() == 4 and v.shape[-1] == 3:       # conv3x3 [Co,Ci,3,3] -> [Co, (ky,kx,ci)]
                 co, ci = v.shape[:2]
                 if ci % 64:                              # conv_in: pad 16 -> 64 input channels
-                    pad = torch.zeros(co, 64 - ci % 64, 3, 3, dtype=v.dtype)
+                    pad = torch.zeros(co, 64 - ci % 64, 3, 3, dtype=v.dtype, device=v.device)
                     v = torch.cat([v, pad], dim=1)
                 self.w[k] = bf(v.permute(0, 2, 3, 1).reshape(co, -1))
             elif v.dim() == 4:                          # conv1x1 -> linear

@@ -44,7 +44,7 @@ def _pad_patch_weight(w, dev):
     """conv [D,3,14,14] -> [D, 640] bf16 (588 real columns + zero pad, matching the im2col rows)."""
     D = w.shape[0]
     flat = w.reshape(D, -1)
-    out = torch.zeros(D, 640, dtype=torch.float32)
+    out = torch.zeros(D, 640, dtype=torch.float32, device=w.device)
     out[:, :flat.shape[1]] = flat
     return _bf(out, dev)
 

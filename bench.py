@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- sampled+scored images/sec of the Adv-GRPO SD3 rollout hot path on MI355X.
+
+One "step" = one pass of the hot path over one prompt group per rank (BASELINE.json config 2):
+SD3.5-medium shapes, 512x512, 10 denoise steps with CFG 4.5 (transformer batch 16), G = 8 images per prompt,
+SDE window [0, 2) at noise level 0.8 with per-step log-probs, VAE decode, PickScore (CLIP ViT-H/14) reward
+of the 8 generated images, and -- for N > 1 -- the packed all-gather of rewards + group ids over RCCL
+followed by the redundant group-advantage kernel (the path's only exchange step; the G-sample groups are
+sharded across ranks like the reference's DistributedKRepeatSampler, no data-path collective).
+Synthetic seeded weights / prompt embeddings (no checkpoints on the box), inputs resident in HBM.
+
+Prints ONE JSON line (rank 0).  Launch for N > 1:
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    return ap.parse_args()
+
+
+def build(device):
+    from adv_grpo_amd import synthetic, vit
+    from adv_grpo_amd.mmdit import SD3Transformer2DModel
+    from adv_grpo_amd.pipeline import SD3Pipeline
+    from adv_grpo_amd.vae import AutoencoderKLDecoder
+    from adv_grpo_amd.model_configs import ClipConfig, MMDiTConfig, VaeConfig
+    mcfg, vcfg, ccfg = MMDiTConfig(), VaeConfig(), ClipConfig()
+    with synthetic.on_device(device):
+        tr = SD3Transformer2DModel(synthetic.mmdit_weights(mcfg, 1234), mcfg, device)
+        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(vcfg, 4321), vcfg, device)
+        clip = vit.CLIPModel(synthetic.clip_weights(ccfg, 777), ccfg, device)
+    return SD3Pipeline(tr, vae, device), clip
+
+
+def cpu_baseline():
+    """BASELINE config 1 on the host cores through the CPU oracle (kind "port": the reference's wheels --
+    diffusers / timm / peft -- are not installed, so its own Python cannot run): SD3.5-medium shapes, 256x256,
+    4 steps, G=2, CFG, VAE decode, PickScore, fp32, torch CPU threads = all cores."""
+    from adv_grpo_amd import synthetic
+    from oracle import mmdit as o_m
+    from oracle import rewards as o_rw
+    from oracle import rollout as o_r
+    from oracle import vae as o_v
+    from oracle import vit as o_t
+    from oracle.scheduler import FlowMatchEulerScheduler
+    cores = torch.get_num_threads()
+    mcfg, vcfg, ccfg = o_m.MMDiTConfig(), o_v.VaeConfig(), o_t.ClipConfig()
+    Wm = synthetic.mmdit_weights(mcfg, 1234)
+    Wv = synthetic.vae_decoder_weights(vcfg, 4321)
+    Wc = synthetic.clip_weights(ccfg, 777)
+    pe, ppe, npe, nppe = synthetic.prompt_embeddings(7)
+    G, hw, steps = 2, 256, 4
+    ids = synthetic.clip_input_ids(G, 3)
+    tr = lambda x, t, c, p: o_m.mmdit_forward(Wm, mcfg, x, t, c, p)
+    t0 = time.time()
+    with torch.no_grad():
+        img, _, _, _ = o_r.rollout(tr, lambda z: o_v.vae_decode(Wv, vcfg, z), FlowMatchEulerScheduler(), prompt_embeds=pe,
+                                   pooled_prompt_embeds=ppe, negative_prompt_embeds=npe,
+                                   negative_pooled_prompt_embeds=nppe, num_inference_steps=steps, guidance_scale=4.5,
+                                   height=hw, width=hw, noise_level=0.8, mini_num_image_per_prompt=G, train_num_steps=2,
+                                   process_index=0, sample_num_steps=steps, random_timestep=0)
+        px = torch.nn.functional.interpolate(img, size=(224, 224), mode="bicubic", antialias=True)
+        px = (px - torch.tensor(o_rw.CLIP_MEAN)[None, :, None, None]) / torch.tensor(o_rw.CLIP_STD)[None, :, None, None]
+        s = o_rw.pickscore_from_embeddings(o_t.clip_image_features(Wc, ccfg, px), o_t.clip_text_features(Wc, ccfg, ids),
+                                           Wc["logit_scale"])
+    dt = time.time() - t0
+    assert torch.isfinite(s).all()
+    return {"value": G / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"config 1: SD3.5-medium 256x256, 4 steps, G=2, CFG 4.5, VAE decode + PickScore, fp32 torch-CPU "
+                      f"oracle ({dt:.1f} s for {G} images); 512^2/10-step images cost ~6.8x more each"}
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()))
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)      # RCCL over xGMI
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from adv_grpo_amd import ops, stat_tracking, synthetic, vit
+    from adv_grpo_amd.diffusers_patch.sd3_pipeline_with_logprob_fast import pipeline_with_logprob_random
+    from adv_grpo_amd.sampler import DistributedKRepeatSampler
+
+    pipe, clip = build(device)
+    G, STEPS, T, RES = 8, 10, 2, 512
+    sampler = DistributedKRepeatSampler(range(25432), 1, 1, world, rank, seed=42)   # k = 1: one group per rank
+    # synthetic prompts: one embedding set per dataset index is not needed for timing; a fixed set per rank
+    pe, ppe, npe, nppe = (t.to(device=device, dtype=torch.bfloat16) for t in synthetic.prompt_embeddings(7 + rank))
+    ids = synthetic.clip_input_ids(G, 3 + rank).to(device)
+
+    def step(it):
+        sampler.set_epoch(it)
+        prompt_idx = next(iter(sampler))[0]
+        image, lats, lps, tss = pipeline_with_logprob_random(
+            pipe, prompt_embeds=pe, pooled_prompt_embeds=ppe, negative_prompt_embeds=npe,
+            negative_pooled_prompt_embeds=nppe, num_inference_steps=STEPS, guidance_scale=4.5, output_type="pt",
+            height=RES, width=RES, noise_level=0.8, mini_num_image_per_prompt=G, train_num_steps=T,
+            process_index=rank, sample_num_steps=STEPS, random_timestep=0, seed=1000 * it + rank)
+        scores = vit.pickscore_scores(clip.get_image_features(images=image.to(torch.bfloat16)),
+                                      clip.get_text_features(ids), clip.logit_scale)
+        rewards = scores.unsqueeze(1).repeat(1, T)                          # TP:926-928
+        gids = torch.full((G,), prompt_idx, dtype=torch.int32, device=device)
+        if dist is not None:                                               # TP:930-966 packed into one all-gather
+            packed = torch.cat([rewards, gids.view(-1, 1).float()], dim=1).contiguous()
+            gathered = torch.empty(world * G, T + 1, dtype=torch.float32, device=device)
+            dist.all_gather_into_tensor(gathered, packed)
+            rewards, gids = gathered[:, :T].contiguous(), gathered[:, T].to(torch.int32)
+        adv = stat_tracking.group_advantage(rewards, gids, True)            # TP:970 (global_std)
+        return adv.view(world, -1, T)[rank], torch.stack(lps, 1)             # TP:995-999
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        step(it)
+    ops.PROFILE = []
+    sync()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        out = step(args.warmup + it)
+    sync()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all()
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel from the HIP events recorded around every GEMM launch
+        per = {}
+        for name, flops, s, e in prof:
+            a = per.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += flops; a[2] += s.elapsed_time(e) * 1e-3
+        dom = max(per, key=lambda k: per[k][2])
+        n, fl, tsec = per[dom]
+        achieved = fl / tsec / 1e12
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": BF16_DENSE_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": n, "avg_launch_us": round(tsec / n * 1e6, 2),
+                    "algorithmic_flops_per_launch": fl / n, "share_of_step_time": round(tsec / dt, 3)}
+        images = world * G * args.steps
+        # algorithmic FLOPs per sampled+scored image: 10*2*2.219 + 2.51 + 0.38 TFLOP
+        per_image_tflop = 10 * 2 * 2.219 + 2.51 + 0.38
+        res = {
+            "metric": "sampled+scored images/sec (whole node), SD3-med 512^2 10-step G=8 GRPO",
+            "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: SD3.5-medium LoRA-merged 512x512, 10 steps, CFG 4.5, G=8, "
+                                   "SDE window 2 @ noise 0.8, VAE decode, PickScore (CLIP ViT-H/14) reward, "
+                                   "reward all-gather + group advantage", "global_batch": world * G,
+                       "transformer_batch_per_gpu": 2 * G, "parallelism": f"dp{world} (prompt groups sharded)"},
+            "effective_tflops_per_gpu": round(per_image_tflop * images / dt / world, 1),
+            "frac_of_bf16_mfma_peak": round(per_image_tflop * images / dt / world / BF16_DENSE_PEAK_TFLOPS, 4),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -118,6 +118,10 @@ int advgrpo_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, vo
                       int64_t a_seg_stride, int64_t a_seg_off, int batch,
                       int64_t strideA, int64_t strideW, int64_t strideC, void* stream);
 
+/* Which kernel instance the GEMM dispatcher uses for a shape: 0 = gemm_bf16_kernel<128,128>, 1 = <128,64>,
+ * 2 = <64,128>; +4 with the implicit-conv loader.  (For per-kernel accounting in bench.py.) */
+int advgrpo_gemm_variant(int M, int N, int batch, int conv);
+
 /* ------------------------------------------------------------------ row kernels (HBM bound)
  * layernorm_mod: out = (LN(x) [*w + b]) * (1 + scale[m / rows_per_batch]) + shift[...]; optional second
  * output with a second (scale1, shift1) from the same statistics.  Replaces nn.LayerNorm +
