@@ -109,6 +109,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)      # RCCL over xGMI
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    from adv_grpo_amd import distributed as D
     from adv_grpo_amd import ops, stat_tracking, synthetic, vit
     from adv_grpo_amd.diffusers_patch.sd3_pipeline_with_logprob_fast import pipeline_with_logprob_random
     from adv_grpo_amd.sampler import DistributedKRepeatSampler
@@ -132,13 +133,9 @@ def main():
                                       clip.get_text_features(ids), clip.logit_scale)
         rewards = scores.unsqueeze(1).repeat(1, T)                          # TP:926-928
         gids = torch.full((G,), prompt_idx, dtype=torch.int32, device=device)
-        if dist is not None:                                               # TP:930-966 packed into one all-gather
-            packed = torch.cat([rewards, gids.view(-1, 1).float()], dim=1).contiguous()
-            gathered = torch.empty(world * G, T + 1, dtype=torch.float32, device=device)
-            dist.all_gather_into_tensor(gathered, packed)
-            rewards, gids = gathered[:, :T].contiguous(), gathered[:, T].to(torch.int32)
+        rewards, gids = D.gather_rewards(rewards, gids)                     # TP:930-966 packed into one all-gather
         adv = stat_tracking.group_advantage(rewards, gids, True)            # TP:970 (global_std)
-        return adv.view(world, -1, T)[rank], torch.stack(lps, 1)             # TP:995-999
+        return D.ungather(adv, world, rank), torch.stack(lps, 1)            # TP:995-999
 
     def sync():
         if dist is not None:
