@@ -21,6 +21,11 @@
 //     vector loads of bias / gate / residual in the fused epilogue.
 //   * block ids are remapped so each XCD (private 4 MiB L2) walks a contiguous strip of tiles.
 //   * rows >= M / N are clamped on load and masked on store; K must be a multiple of 64.
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
 #include "gemm.hpp"
 
 namespace advgrpo {
@@ -40,25 +45,37 @@ __device__ inline float act_fn(float x, int act) {
     }
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // bijective XCD remap: consecutive remapped ids live on one XCD (observed placement b % 8)
 __device__ inline int xcd_remap(int bid, int nwg) {
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, bool CONV>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParams p) {
     constexpr int BK = 64;
-    constexpr int TM = BM / 2, TN = BN / 2;     // wave tile
+    constexpr int NW = WM * WN;                 // waves per workgroup
+    constexpr int TM = BM / WM, TN = BN / WN;   // wave tile
     constexpr int FM = TM / 16, FN = TN / 16;   // fragments per wave
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INST = BM / 8 / 4, B_INST = BN / 8 / 4;  // DMA instructions per wave per tile
+    constexpr int A_INST = BM / 8 / NW, B_INST = BN / 8 / NW;  // DMA instructions per wave per tile
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int nwg = tiles_m * tiles_n;
@@ -79,7 +96,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     int64_t a_img[A_INST];               // CONV: element offset of the image (b) in the input
 #pragma unroll
     for (int it = 0; it < A_INST; ++it) {
-        int r = m0 + (wave + it * 4) * 8 + lrow;
+        int r = m0 + (wave + it * NW) * 8 + lrow;
         r = r < p.M ? r : p.M - 1;
         if constexpr (CONV) {
             const int hw = p.Hout * p.Wout;
@@ -99,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     }
 #pragma unroll
     for (int it = 0; it < B_INST; ++it) {
-        int r = n0 + (wave + it * 4) * 8 + lrow;
+        int r = n0 + (wave + it * NW) * 8 + lrow;
         r = r < p.N ? r : p.N - 1;
         b_src[it] = W + (int64_t)r * p.ldw + schunk * 8;
     }
@@ -118,18 +135,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
                 const bf16_t* src = ok ? A + a_img[it] + ((int64_t)(yy >> p.ups) * win + (xx >> p.ups)) * p.Cin + c0 +
                                              schunk * 8
                                        : p.zero_page + schunk * 8;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(base + (wave + it * 4) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(base + (wave + it * NW) * 1024), 16, 0, 0);
             }
         } else {
 #pragma unroll
             for (int it = 0; it < A_INST; ++it)
                 __builtin_amdgcn_global_load_lds((gptr_t)(a_src[it] + kt * BK),
-                                                 (lds_ptr_t)(base + (wave + it * 4) * 1024), 16, 0, 0);
+                                                 (lds_ptr_t)(base + (wave + it * NW) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < B_INST; ++it)
             __builtin_amdgcn_global_load_lds((gptr_t)(b_src[it] + kt * BK),
-                                             (lds_ptr_t)(base + A_BYTES + (wave + it * 4) * 1024), 16, 0, 0);
+                                             (lds_ptr_t)(base + A_BYTES + (wave + it * NW) * 1024), 16, 0, 0);
     };
 
     // ---- fragment read offsets (bytes) inside a tile: row (lane&15), swizzled chunk
@@ -170,81 +187,113 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
         __syncthreads();
     }
 
-    // ---- fused epilogue: lane holds C[m][n..n+3], m = frag row (lane&15), n = (lane>>4)*4
+    // ---- fused epilogue: lane holds C[m][n..n+3], m = frag row (lane&15), n = (lane>>4)*4.
+    // Full, 8-byte-aligned quads take the vector path (bf16x4 loads of bias / gate / residual, one bf16x4 or
+    // float4 store); the ragged N edge falls back to predicated scalars.  Fragments are visited with
+    // compile-time indices (static_for) so the accumulators never leave the register file.
     const int mrow = lane & 15, ncol = (lane >> 4) * 4;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
+    const bool vec_ok = ((p.ldc | p.ldr | p.gate_stride) & 3) == 0 && (p.N & 3) == 0;
+    static_for<FM * FN>([&](auto idx) {
+        constexpr int i = decltype(idx)::value / FN, j = decltype(idx)::value % FN;
         const int m = m0 + wm * TM + i * 16 + mrow;
-        if (m >= p.M) continue;
-        // output row mapping (row segments, e.g. image / text tokens into one joint buffer)
+        const int n = n0 + wn * TN + j * 16 + ncol;
+        if (m >= p.M || n >= p.N) return;
         int64_t orow = m;
-        int bidx = 0;
         if (p.seg_rows > 0) {
-            bidx = m / p.seg_rows;
+            const int bidx = m / p.seg_rows;
             orow = (int64_t)bidx * p.seg_stride + p.seg_off + (m - bidx * p.seg_rows);
         }
         const int gb = p.gate_rows > 0 ? m / p.gate_rows : 0;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * TN + j * 16 + ncol;
-            if (n >= p.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            const bool full = (n + 3 < p.N);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (!full && n + r >= p.N) break;
-                float y = v[r] * p.alpha;
+        const bf16_t* grow = p.gate ? p.gate + (int64_t)bz * p.gate_batch_stride + (int64_t)gb * p.gate_stride : nullptr;
+        const bf16_t* rrow = p.residual ? p.residual + (int64_t)bz * p.strideR + orow * p.ldr : nullptr;
+        const int64_t o = (int64_t)bz * p.strideC + orow * p.ldc + n;
+        const f32x4 a4 = acc[i][j];
+        float v0 = a4[0] * p.alpha, v1 = a4[1] * p.alpha, v2 = a4[2] * p.alpha, v3 = a4[3] * p.alpha;
+        if (vec_ok) {
+            if (p.bias) {
+                const uint2 q = *reinterpret_cast<const uint2*>(p.bias + n);
+                v0 += bf2f((bf16_t)(q.x & 0xffffu)); v1 += bf2f((bf16_t)(q.x >> 16));
+                v2 += bf2f((bf16_t)(q.y & 0xffffu)); v3 += bf2f((bf16_t)(q.y >> 16));
+            }
+            if (p.act != ACT_NONE) {
+                v0 = act_fn(v0, p.act); v1 = act_fn(v1, p.act); v2 = act_fn(v2, p.act); v3 = act_fn(v3, p.act);
+            }
+            if (grow) {
+                const uint2 q = *reinterpret_cast<const uint2*>(grow + n);
+                v0 *= bf2f((bf16_t)(q.x & 0xffffu)); v1 *= bf2f((bf16_t)(q.x >> 16));
+                v2 *= bf2f((bf16_t)(q.y & 0xffffu)); v3 *= bf2f((bf16_t)(q.y >> 16));
+            }
+            if (rrow) {
+                const uint2 q = *reinterpret_cast<const uint2*>(rrow + n);
+                v0 += bf2f((bf16_t)(q.x & 0xffffu)); v1 += bf2f((bf16_t)(q.x >> 16));
+                v2 += bf2f((bf16_t)(q.y & 0xffffu)); v3 += bf2f((bf16_t)(q.y >> 16));
+            }
+            if (p.out_dtype == ADVGRPO_BF16) {
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+                pk.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + o) = pk;
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + o) = make_float4(v0, v1, v2, v3);
+            }
+        } else {
+            auto put = [&](int r, float y) {
+                if (n + r >= p.N) return;
                 if (p.bias) y += bf2f(p.bias[n + r]);
                 y = act_fn(y, p.act);
-                if (p.gate) y *= bf2f(p.gate[(int64_t)(bz * p.gate_batch_stride) + (int64_t)gb * p.gate_stride + n + r]);
-                if (p.residual) y += bf2f(p.residual[(int64_t)bz * p.strideR + orow * p.ldr + n + r]);
-                v[r] = y;
-            }
-            const int64_t o = (int64_t)bz * p.strideC + orow * p.ldc + n;
-            if (p.out_dtype == ADVGRPO_BF16) {
-                bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
-                if (full && ((o & 3) == 0)) {
-                    uint2 pk;
-                    pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                    pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(C + o) = pk;
-                } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[o + r] = f2bf(v[r]);
-                }
-            } else {
-                float* C = reinterpret_cast<float*>(p.C);
-                if (full && ((o & 3) == 0)) {
-                    *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[o + r] = v[r];
-                }
-            }
+                if (grow) y *= bf2f(grow[n + r]);
+                if (rrow) y += bf2f(rrow[n + r]);
+                if (p.out_dtype == ADVGRPO_BF16) reinterpret_cast<bf16_t*>(p.C)[o + r] = f2bf(y);
+                else reinterpret_cast<float*>(p.C)[o + r] = y;
+            };
+            put(0, v0); put(1, v1); put(2, v2); put(3, v3);
         }
-    }
+    });
 }
 
-template <int BM, int BN, bool CONV>
+template <int BM, int BN, int WM, int WN, bool CONV>
 static int launch(const GemmParams& p, hipStream_t s) {
     constexpr int lds = 2 * (BM + BN) * 64 * 2;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<BM, BN, CONV>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<BM, BN, WM, WN, CONV>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, CONV>), dim3(tiles, p.batch), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, CONV>), dim3(tiles, p.batch), dim3(WM * WN * 64), lds, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
 
-// tile variant the dispatcher picks: 0 = 128x128, 1 = 128x64, 2 = 64x128 (+4 for the conv loader)
+// ---- tile variants.  id: 0 = 128x128 (4 waves), 1 = 128x64, 2 = 64x128, 3 = 256x256 (8 waves, 128 KB LDS,
+// one workgroup per CU), 6 = 256x128 (8 waves); +conv: 4 = 128x128, 5 = 128x64, 7 = 256x256, 8 = 256x128.
+// The choice maximises (how full the last round of workgroups is) x (measured relative speed of the tile).
+static int g_force_variant = -2;
 static int gemm_variant(int M, int N, int batch, int conv) {
-    const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
-    if (conv) return 4 + (N <= 64 ? 1 : 0);
-    if (N <= 64) return 1;
-    if (t128 >= 256 || M > 2048) return 0;
-    return 2;
+    if (g_force_variant == -2) {
+        const char* e = getenv("ADVGRPO_GEMM_FORCE");   // experiments only
+        g_force_variant = e ? atoi(e) : -1;
+    }
+    auto rounds_eff = [&](int bm, int bn, int capacity) {
+        const double tiles = (double)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
+        const double rounds = (double)(int64_t)((tiles + capacity - 1) / capacity);
+        // useful fraction of the launched tile area x fullness of the rounds
+        const double area = (double)M * N * batch / (tiles * bm * bn);
+        return area * tiles / (rounds * capacity);
+    };
+    if (N <= 64) return conv ? 5 : 1;
+    if (g_force_variant >= 0) {
+        const int f = g_force_variant;
+        if (conv) return f == 3 ? 7 : (f == 6 ? 8 : 4);
+        return f;
+    }
+    const double e3 = rounds_eff(256, 256, 256) * 1.00, e6 = rounds_eff(256, 128, 256) * 0.90,
+                 e0 = rounds_eff(128, 128, 512) * 0.62, e2 = rounds_eff(64, 128, 768) * 0.40;
+    if (conv) return (e3 >= e6 && e3 >= e0) ? 7 : (e6 >= e0 ? 8 : 4);
+    if (e3 >= e6 && e3 >= e0 && e3 >= e2) return 3;
+    if (e6 >= e0 && e6 >= e2) return 6;
+    return e0 >= e2 ? 0 : 2;
 }
 
 int gemm_bf16(const GemmParams& p, hipStream_t s) {
@@ -254,18 +303,25 @@ int gemm_bf16(const GemmParams& p, hipStream_t s) {
     ADVGRPO_CHECK(p.lda % 8 == 0 && p.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8 elements (16 B rows)");
     ADVGRPO_CHECK(p.out_dtype == ADVGRPO_BF16 || p.out_dtype == ADVGRPO_F32, "gemm: bad out dtype");
     ADVGRPO_CHECK(p.batch >= 1, "gemm: batch must be >= 1");
-    // tile choice: big tiles when they still fill the 256 CUs, smaller ones for skinny problems
     const int variant = gemm_variant(p.M, p.N, p.batch, p.conv);
     if (p.conv) {
         ADVGRPO_CHECK(p.Cin % 64 == 0 && p.K == 9 * p.Cin && p.zero_page && p.batch == 1,
                       "conv3x3: need Cin %% 64 == 0, K == 9*Cin, a zero page and batch 1 (Cin=%d K=%d)", p.Cin, p.K);
         ADVGRPO_CHECK((p.Hout % (1 << p.ups)) == 0 && (p.Wout % (1 << p.ups)) == 0, "conv3x3: bad upsample shape");
-        if (variant == 5) return launch<128, 64, true>(p, s);
-        return launch<128, 128, true>(p, s);
     }
-    if (variant == 1) return launch<128, 64, false>(p, s);
-    if (variant == 0) return launch<128, 128, false>(p, s);
-    return launch<64, 128, false>(p, s);
+    switch (variant) {
+        case 0: return launch<128, 128, 2, 2, false>(p, s);
+        case 1: return launch<128, 64, 2, 2, false>(p, s);
+        case 2: return launch<64, 128, 2, 2, false>(p, s);
+        case 3: return launch<256, 256, 2, 4, false>(p, s);
+        case 6: return launch<256, 128, 4, 2, false>(p, s);
+        case 4: return launch<128, 128, 2, 2, true>(p, s);
+        case 5: return launch<128, 64, 2, 2, true>(p, s);
+        case 7: return launch<256, 256, 2, 4, true>(p, s);
+        case 8: return launch<256, 128, 4, 2, true>(p, s);
+    }
+    set_error("gemm: bad variant %d", variant);
+    return -1;
 }
 
 }  // namespace advgrpo

@@ -7,9 +7,11 @@ from . import _lib
 
 ACT = {None: 0, "none": 0, "gelu_tanh": 1, "gelu": 2, "gelu_erf": 2, "silu": 3}
 
-GEMM_VARIANTS = {0: "gemm_bf16_kernel<128,128,false>", 1: "gemm_bf16_kernel<128,64,false>",
-                 2: "gemm_bf16_kernel<64,128,false>", 4: "gemm_bf16_kernel<128,128,true>",
-                 5: "gemm_bf16_kernel<128,64,true>"}
+GEMM_VARIANTS = {0: "gemm_bf16_kernel<128,128,2,2,false>", 1: "gemm_bf16_kernel<128,64,2,2,false>",
+                 2: "gemm_bf16_kernel<64,128,2,2,false>", 3: "gemm_bf16_kernel<256,256,2,4,false>",
+                 6: "gemm_bf16_kernel<256,128,4,2,false>", 4: "gemm_bf16_kernel<128,128,2,2,true>",
+                 5: "gemm_bf16_kernel<128,64,2,2,true>", 7: "gemm_bf16_kernel<256,256,2,4,true>",
+                 8: "gemm_bf16_kernel<256,128,4,2,true>"}
 # bench.py sets this to a list to collect (kernel name, flops, start event, end event) per GEMM launch;
 # events are recorded on the stream the kernel is launched on (torch's current stream).
 PROFILE = None

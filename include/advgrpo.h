@@ -118,8 +118,8 @@ int advgrpo_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, vo
                       int64_t a_seg_stride, int64_t a_seg_off, int batch,
                       int64_t strideA, int64_t strideW, int64_t strideC, void* stream);
 
-/* Which kernel instance the GEMM dispatcher uses for a shape: 0 = gemm_bf16_kernel<128,128>, 1 = <128,64>,
- * 2 = <64,128>; +4 with the implicit-conv loader.  (For per-kernel accounting in bench.py.) */
+/* Which kernel instance the GEMM dispatcher uses for a shape: tile 0 = 128x128, 1 = 128x64, 2 = 64x128,
+ * 3 = 256x256, 6 = 256x128; with the implicit-conv loader 4, 5, 7, 8.  (Per-kernel accounting in bench.py.) */
 int advgrpo_gemm_variant(int M, int N, int batch, int conv);
 
 /* ------------------------------------------------------------------ row kernels (HBM bound)
