@@ -31,6 +31,7 @@ struct AttnParams {
     int H, Sq, Skv;
     float scale_log2e;            // softmax scale * log2(e)
     int causal;
+    float* lse;                   // optional [B,H,Sq]: base-2 log-sum-exp of the scaled scores (for backward)
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         const int qi = q0 + qb * 16 + t;
         if (qi >= p.Sq) continue;
+        if (p.lse && g == 0) p.lse[((int64_t)b * p.H + h) * p.Sq + qi] = m_run[qb] + __builtin_amdgcn_logf(l);
         bf16_t* op = p.o + (int64_t)b * p.bso + (int64_t)qi * p.ldo + h * HD + g * 4;
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
@@ -267,7 +269,7 @@ using namespace advgrpo;
 extern "C" int advgrpo_attention_fwd(const void* q, const void* k, const void* v, void* o, int64_t ldq, int64_t ldk,
                                      int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso,
                                      int B, int H, int Sq, int Skv, int head_dim, float scale, int causal,
-                                     void* stream) {
+                                     float* lse, void* stream) {
     AttnParams p{};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
@@ -275,5 +277,6 @@ extern "C" int advgrpo_attention_fwd(const void* q, const void* k, const void* v
     p.H = H; p.Sq = Sq; p.Skv = Skv;
     p.scale_log2e = scale * 1.4426950408889634f;
     p.causal = causal;
+    p.lse = lse;
     return attention_fwd(p, B, head_dim, as_stream(stream));
 }

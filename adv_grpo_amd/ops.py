@@ -83,7 +83,7 @@ def bmm_nt(a, w, out=None, out_dtype=torch.bfloat16, alpha=1.0):
     return out
 
 
-def attention(q, k, v, num_heads, scale=None, causal=False, out=None):
+def attention(q, k, v, num_heads, scale=None, causal=False, out=None, lse=None):
     """q [B,Sq,H*D], k/v [B,Skv,H*D] bf16 views (last dim contiguous, any row/batch pitch) -> [B,Sq,H*D]."""
     lib = _lib.load()
     B, Sq, HD = q.shape
@@ -97,8 +97,27 @@ def attention(q, k, v, num_heads, scale=None, causal=False, out=None):
     _lib.check(lib.advgrpo_attention_fwd(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(1), k.stride(1), v.stride(1),
         out.stride(1), q.stride(0), k.stride(0), v.stride(0), out.stride(0), B, num_heads, Sq, Skv, D,
-        float(scale), int(causal), _lib.stream_ptr()))
+        float(scale), int(causal), lse.data_ptr() if lse is not None else None, _lib.stream_ptr()))
     return out
+
+
+def attention_bwd(q, k, v, o, d_o, lse, num_heads, dq, dk, dv, scale=None):
+    """Gradients of ops.attention.  q,k,v,o,d_o: [B,S,H*64] bf16 views; lse f32 [B,H,Sq] from the forward;
+    dq/dk/dv: bf16 views of ONE packed buffer (same row / batch pitch)."""
+    lib = _lib.load()
+    B, Sq, HD = q.shape
+    Skv = k.shape[1]
+    D = HD // num_heads
+    if scale is None:
+        scale = D ** -0.5
+    assert dq.stride(1) == dk.stride(1) == dv.stride(1) and dq.stride(0) == dk.stride(0) == dv.stride(0)
+    delta = torch.empty(B, num_heads, Sq, dtype=torch.float32, device=q.device)
+    _lib.check(lib.advgrpo_attention_bwd(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+        dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), q.stride(1), k.stride(1), v.stride(1), o.stride(1),
+        d_o.stride(1), dq.stride(1), q.stride(0), k.stride(0), v.stride(0), o.stride(0), d_o.stride(0), dq.stride(0),
+        B, num_heads, Sq, Skv, D, float(scale), _lib.stream_ptr()))
+    return dq, dk, dv
 
 
 def layernorm_mod(x, out=None, w=None, b=None, scale=None, shift=None, scale2=None, shift2=None,

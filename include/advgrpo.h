@@ -151,12 +151,23 @@ int advgrpo_unpatchify(const void* tokens, void* out, int out_dtype, int B, int 
  * (sd3_pipeline_with_logprob_fast.py:630-637; adv_grpo/rewards.py:397; pickscore_scorer.py:40-44).
  * q/k/v/o are [B, S, H*head_dim]-shaped VIEWS: element (b, s, h, d) at
  * ptr + b*bs + s*ld + h*head_dim + d, so packed QKV GEMM outputs are consumed in place.
- * head_dim: 64.  ld{q,k,v} % 8 == 0, ldo % 4 == 0. */
+ * head_dim: 64 or 80.  ld{q,k,v} % 8 == 0, ldo % 4 == 0.
+ * lse (optional, f32 [B,H,Sq]): base-2 log-sum-exp of the scaled scores, consumed by the backward. */
 int advgrpo_attention_fwd(const void* q, const void* k, const void* v, void* o,
                           int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                           int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso,
                           int B, int H, int Sq, int Skv, int head_dim, float scale, int causal,
-                          void* stream);
+                          float* lse, void* stream);
+
+/* Backward of the fused attention (autograd of the transformer call inside compute_log_prob,
+ * scripts/train_sd3_fast_pickscore.py:233-267, reached from loss.backward() at :1165).  head_dim 64.
+ * d_o: gradient w.r.t. o (same view convention, pitch lddo / bsdo); lse from the forward; delta: f32 [B,H,Sq]
+ * scratch (filled here: rowsum(o * d_o)); dq/dk/dv: bf16 views with pitches lddq / bsdq (one packed buffer). */
+int advgrpo_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                          const float* lse, float* delta, void* dq, void* dk, void* dv,
+                          int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
+                          int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, int64_t bsdo, int64_t bsdq,
+                          int B, int H, int Sq, int Skv, int head_dim, float scale, void* stream);
 
 /* ------------------------------------------------------------------ VAE decoder pieces
  * Replace diffusers AutoencoderKL.decode + VaeImageProcessor.postprocess("pt") as reached at
