@@ -36,7 +36,19 @@ SIGNATURES = {
     "advgrpo_layernorm_mod": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int,
                                       c_int, c_float, _P]),
     "advgrpo_rmsnorm_heads": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int, c_float, c_int, c_int64, c_int64,
-                                      _P]),
+                                      _P, _P]),
+    "advgrpo_gemm_bf16_train": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_int, _P, c_int,
+                                        c_float, _P, c_int64, c_int, _P, c_int64, _P, _P, c_int64, c_int, _P]),
+    "advgrpo_transpose_bf16": (c_int, [_P, _P, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int64, c_int64, _P]),
+    "advgrpo_layernorm_mod_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int, _P, _P, c_int64, c_int,
+                                          c_int, c_float, _P]),
+    "advgrpo_rmsnorm_heads_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int64,
+                                          c_int64, _P]),
+    "advgrpo_gate_mul": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, _P]),
+    "advgrpo_sumsq_f32": (c_int, [_P, c_int64, _P, _P]),
+    "advgrpo_adamw_step": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, _P,
+                                   c_float, c_float, _P]),
+    "advgrpo_ema_step": (c_int, [_P, _P, c_int64, c_float, _P]),
     "advgrpo_timestep_embedding": (c_int, [_P, _P, c_int, c_int, _P]),
     "advgrpo_unary": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "advgrpo_patchify": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),

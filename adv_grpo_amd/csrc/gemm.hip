@@ -44,6 +44,16 @@ __device__ inline float act_fn(float x, int act) {
         default: return x;
     }
 }
+// derivative of the activation at pre-activation u
+__device__ inline float dact_fn(float u, int act) {
+    if (act == ACT_DGELU_TANH) {
+        const float c = 0.7978845608028654f, a = 0.044715f;
+        const float th = tanhf(c * (u + a * u * u * u));
+        return 0.5f * (1.0f + th) + 0.5f * u * (1.0f - th * th) * c * (1.0f + 3.0f * a * u * u);
+    }
+    // exact GELU: Phi(u) + u phi(u)
+    return 0.5f * (1.0f + erff(u * 0.7071067811865476f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+}
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>)
 template <class F, int... Is>
@@ -82,7 +92,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
     const int swz = xcd_remap(blockIdx.x, nwg);
     const int tile_m = swz / tiles_n, tile_n = swz % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int bz = blockIdx.y;
+    const int bz = blockIdx.y / p.splitk, sk = blockIdx.y % p.splitk;
 
     const bf16_t* __restrict__ A = p.A + (int64_t)bz * p.strideA;
     const bf16_t* __restrict__ W = p.W + (int64_t)bz * p.strideW;
@@ -161,12 +171,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
-    stage(0, 0);
+    // k-tile range of this split (whole range when splitk == 1)
+    const int nk_all = p.K / BK;
+    const int kt0 = (int)((int64_t)nk_all * sk / p.splitk), kt1 = (int)((int64_t)nk_all * (sk + 1) / p.splitk);
+    const int nk = kt1 - kt0;
+    if (nk <= 0) return;
+    stage(0, kt0);
     __syncthreads();  // hipcc drains the LDS-DMA (vmcnt 0) before the barrier
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        if (kt + 1 < nk) stage(cur ^ 1, kt0 + kt + 1);
         const char* ta = smem + cur * STAGE + wm * TM * 128;
         const char* tb = smem + cur * STAGE + A_BYTES + wn * TN * 128;
 #pragma unroll
@@ -209,13 +223,31 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
         const int64_t o = (int64_t)bz * p.strideC + orow * p.ldc + n;
         const f32x4 a4 = acc[i][j];
         float v0 = a4[0] * p.alpha, v1 = a4[1] * p.alpha, v2 = a4[2] * p.alpha, v3 = a4[3] * p.alpha;
+        if (p.splitk > 1) {   // partial tile: f32 atomic accumulation (gradient buffers), no other epilogue
+            float* c = reinterpret_cast<float*>(p.C) + o;
+            unsafeAtomicAdd(c, v0);
+            if (n + 1 < p.N) unsafeAtomicAdd(c + 1, v1);
+            if (n + 2 < p.N) unsafeAtomicAdd(c + 2, v2);
+            if (n + 3 < p.N) unsafeAtomicAdd(c + 3, v3);
+            return;
+        }
         if (vec_ok) {
             if (p.bias) {
                 const uint2 q = *reinterpret_cast<const uint2*>(p.bias + n);
                 v0 += bf2f((bf16_t)(q.x & 0xffffu)); v1 += bf2f((bf16_t)(q.x >> 16));
                 v2 += bf2f((bf16_t)(q.y & 0xffffu)); v3 += bf2f((bf16_t)(q.y >> 16));
             }
-            if (p.act != ACT_NONE) {
+            if (p.aux_out) {
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+                pk.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+                *reinterpret_cast<uint2*>(p.aux_out + (int64_t)bz * p.strideC + orow * p.ld_aux + n) = pk;
+            }
+            if (p.act >= ACT_DGELU_TANH) {
+                const uint2 q = *reinterpret_cast<const uint2*>(p.aux_in + (int64_t)bz * p.strideC + orow * p.ld_aux + n);
+                v0 *= dact_fn(bf2f((bf16_t)(q.x & 0xffffu)), p.act); v1 *= dact_fn(bf2f((bf16_t)(q.x >> 16)), p.act);
+                v2 *= dact_fn(bf2f((bf16_t)(q.y & 0xffffu)), p.act); v3 *= dact_fn(bf2f((bf16_t)(q.y >> 16)), p.act);
+            } else if (p.act != ACT_NONE) {
                 v0 = act_fn(v0, p.act); v1 = act_fn(v1, p.act); v2 = act_fn(v2, p.act); v3 = act_fn(v3, p.act);
             }
             if (grow) {
@@ -261,7 +293,7 @@ static int launch(const GemmParams& p, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, CONV>), dim3(tiles, p.batch), dim3(WM * WN * 64), lds, s, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, CONV>), dim3(tiles, p.batch * p.splitk), dim3(WM * WN * 64), lds, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
@@ -270,7 +302,7 @@ static int launch(const GemmParams& p, hipStream_t s) {
 // one workgroup per CU), 6 = 256x128 (8 waves); +conv: 4 = 128x128, 5 = 128x64, 7 = 256x256, 8 = 256x128.
 // The choice maximises (how full the last round of workgroups is) x (measured relative speed of the tile).
 static int g_force_variant = -2;
-static int gemm_variant(int M, int N, int batch, int conv) {
+static int gemm_variant(int M, int N, int batch, int conv) {   // batch includes the split-K factor
     if (g_force_variant == -2) {
         const char* e = getenv("ADVGRPO_GEMM_FORCE");   // experiments only
         g_force_variant = e ? atoi(e) : -1;
@@ -302,8 +334,13 @@ int gemm_bf16(const GemmParams& p, hipStream_t s) {
                   p.M, p.N, p.K);
     ADVGRPO_CHECK(p.lda % 8 == 0 && p.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8 elements (16 B rows)");
     ADVGRPO_CHECK(p.out_dtype == ADVGRPO_BF16 || p.out_dtype == ADVGRPO_F32, "gemm: bad out dtype");
-    ADVGRPO_CHECK(p.batch >= 1, "gemm: batch must be >= 1");
-    const int variant = gemm_variant(p.M, p.N, p.batch, p.conv);
+    ADVGRPO_CHECK(p.batch >= 1 && p.splitk >= 1, "gemm: batch / splitk must be >= 1");
+    ADVGRPO_CHECK(p.splitk == 1 || (p.out_dtype == ADVGRPO_F32 && !p.bias && !p.gate && !p.residual && p.act == 0 &&
+                                    !p.aux_out),
+                  "gemm: split-K accumulates atomically into f32 and takes no other epilogue");
+    ADVGRPO_CHECK(p.act < ACT_DGELU_TANH || p.aux_in, "gemm: d-activation epilogue needs aux_in");
+    ADVGRPO_CHECK(!(p.aux_out || p.aux_in) || ((p.ld_aux & 3) == 0 && (p.N & 3) == 0), "gemm: aux needs N, ld_aux %% 4 == 0");
+    const int variant = gemm_variant(p.M, p.N, p.batch * p.splitk, p.conv);
     if (p.conv) {
         ADVGRPO_CHECK(p.Cin % 64 == 0 && p.K == 9 * p.Cin && p.zero_page && p.batch == 1,
                       "conv3x3: need Cin %% 64 == 0, K == 9*Cin, a zero page and batch 1 (Cin=%d K=%d)", p.Cin, p.K);
@@ -346,6 +383,25 @@ extern "C" int advgrpo_gemm_bf16(const void* A, int64_t lda, const void* W, int6
     p.seg_rows = seg_rows; p.seg_stride = seg_stride; p.seg_off = seg_off;
     p.a_seg_rows = a_seg_rows; p.a_seg_stride = a_seg_stride; p.a_seg_off = a_seg_off;
     p.batch = batch < 1 ? 1 : batch; p.strideA = strideA; p.strideW = strideW; p.strideC = strideC;
+    p.splitk = 1;
+    return gemm_bf16(p, as_stream(stream));
+}
+
+/* training variant: + aux pre-activation output / d-activation input, split-K atomic accumulation */
+extern "C" int advgrpo_gemm_bf16_train(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                                       int out_dtype, int M, int N, int K, const void* bias, int act, float alpha,
+                                       const void* gate, int64_t gate_stride, int gate_rows, const void* residual,
+                                       int64_t ldr, void* aux_out, const void* aux_in, int64_t ld_aux, int splitk,
+                                       void* stream) {
+    GemmParams p{};
+    p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C;
+    p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.out_dtype = out_dtype;
+    p.M = M; p.N = N; p.K = K;
+    p.bias = (const bf16_t*)bias; p.act = act; p.alpha = alpha;
+    p.gate = (const bf16_t*)gate; p.gate_stride = gate_stride; p.gate_rows = gate_rows;
+    p.residual = (const bf16_t*)residual; p.ldr = ldr;
+    p.batch = 1; p.splitk = splitk < 1 ? 1 : splitk;
+    p.aux_out = (bf16_t*)aux_out; p.aux_in = (const bf16_t*)aux_in; p.ld_aux = ld_aux;
     return gemm_bf16(p, as_stream(stream));
 }
 
@@ -362,5 +418,6 @@ extern "C" int advgrpo_conv3x3_nhwc(const void* x, const void* w, void* y, int o
     p.batch = 1;
     p.conv = 1; p.Hout = Hout; p.Wout = Wout; p.Cin = Cin; p.ups = upsample ? 1 : 0;
     p.zero_page = (const bf16_t*)zero_page;
+    p.splitk = 1;
     return gemm_bf16(p, as_stream(stream));
 }

@@ -6,7 +6,8 @@ namespace advgrpo {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
-enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3 };
+enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3,
+       ACT_DGELU_TANH = 5 /* y *= gelu_tanh'(aux_in[m,n]) */, ACT_DGELU_ERF = 6 };
 
 struct GemmParams {
     const bf16_t* A; const bf16_t* W; void* C;
@@ -25,6 +26,9 @@ struct GemmParams {
     // implicit-GEMM 3x3 conv (stride 1, pad 1, optional nearest x2 upsample of the input), NHWC:
     // A = input [B, Hout>>ups, Wout>>ups, Cin], row m = output pixel (b, y, x), k = (ky*3+kx)*Cin + c
     int conv; int Hout, Wout, Cin, ups; const bf16_t* zero_page;
+    // training extras: aux_out[orow, n] = pre-activation (bf16, pitch ldc); aux_in[orow, n] feeds the d-activation
+    // epilogues; splitk > 1: the K range is split over grid.y and partial tiles are atomically added into f32 C
+    bf16_t* aux_out; const bf16_t* aux_in; int64_t ld_aux; int splitk;
 };
 
 int gemm_bf16(const GemmParams& p, hipStream_t stream);

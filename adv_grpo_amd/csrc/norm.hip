@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const LnParams p) {
 __global__ __launch_bounds__(256) void rmsnorm_heads_kernel(bf16_t* __restrict__ buf, int64_t ld, int M, int col0,
                                                             int nheads, const bf16_t* __restrict__ w,
                                                             int heads_per_weight, float eps, int seg_rows,
-                                                            int64_t seg_stride, int64_t seg_off) {
+                                                            int64_t seg_stride, int64_t seg_off, float* __restrict__ rs_out) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void rmsnorm_heads_kernel(bf16_t* __restrict__
         sq += __shfl_xor(sq, 2, 64);
         sq += __shfl_xor(sq, 4, 64);
         const float rs = rsqrtf(sq * (1.0f / 64.0f) + eps);
+        if (rs_out && sub == 0) rs_out[row * nheads + hh] = rs;   // saved for the backward
         unpack8(*reinterpret_cast<const uint4*>(w + (hh / heads_per_weight) * 64 + sub * 8), ww);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = round_bf16(v[k] * rs) * ww[k];  // x.to(bf16) * weight
@@ -228,11 +229,11 @@ extern "C" int advgrpo_layernorm_mod(const void* x, int64_t ldx, void* out0, voi
 
 extern "C" int advgrpo_rmsnorm_heads(void* buf, int64_t ld, int M, int col0, int nheads, const void* weight,
                                      int heads_per_weight, float eps, int seg_rows, int64_t seg_stride,
-                                     int64_t seg_off, void* stream) {
+                                     int64_t seg_off, float* rs_out, void* stream) {
     ADVGRPO_CHECK(buf && weight && M > 0 && nheads > 0 && heads_per_weight > 0, "rmsnorm_heads: bad argument");
     ADVGRPO_CHECK(ld % 8 == 0 && col0 % 8 == 0, "rmsnorm_heads: pitch/offset must be multiples of 8");
     hipLaunchKernelGGL(rmsnorm_heads_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), (bf16_t*)buf, ld, M,
-                       col0, nheads, (const bf16_t*)weight, heads_per_weight, eps, seg_rows, seg_stride, seg_off);
+                       col0, nheads, (const bf16_t*)weight, heads_per_weight, eps, seg_rows, seg_stride, seg_off, rs_out);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,42 @@
+"""One G-step micro-batch: compute_log_prob with gradient -> clipped GRPO loss -> backward into the LoRA grads.
+
+Mirror of the inner training loop body, scripts/train_sd3_fast_pickscore.py:1102-1165 (beta == 0 as in every shipped
+config): compute_log_prob (TP:233-267) = transformer on the CFG batch + CFG combine + SDE step in replay mode;
+loss block TP:1111-1130; accelerator.backward(loss) TP:1165.  The backward is explicit:
+d loss/d log_prob (grpo_loss kernel) -> d/d v_uncond, d/d v_text (sde_step_bwd kernel) -> MMDiT backward."""
+import math
+
+import torch
+
+from . import _lib, losses
+from .diffusers_patch.sd3_sde_with_logprob import sde_step_cfg
+
+
+@torch.no_grad()
+def micro_step(model, scheduler, sample, j, embeds, pooled_embeds, old_log_prob, advantages, *, guidance_scale,
+               noise_level, adv_clip_max, clip_range, loss_scale=1.0):
+    """sample: dict with latents / next_latents [G,T,16,h,w], timesteps [G,T].  embeds / pooled: CFG-concatenated
+    (negative first, TP:1084-1091).  Accumulates into model.grads; returns the diagnostics of TP:1132-1162."""
+    lib = _lib.load()
+    x = sample["latents"][:, j].contiguous()
+    nxt = sample["next_latents"][:, j].contiguous()
+    ts = sample["timesteps"][:, j]
+    G = x.shape[0]
+    v, ctx = model.forward_train(torch.cat([x, x]), torch.cat([ts, ts]).float(), embeds, pooled_embeds)
+    vu, vt = v[:G].contiguous(), v[G:].contiguous()
+    step_index = scheduler.index_for_timestep(float(ts[0]))
+    _, _, log_prob, _, _ = sde_step_cfg(scheduler, vu, vt, guidance_scale, None, x, noise_level, prev_sample=nxt,
+                                        want_mean=False, step_index=step_index)
+    scal, dlp = losses.grpo_loss(log_prob, old_log_prob, advantages, adv_clip_max, clip_range)
+    if loss_scale != 1.0:
+        dlp = dlp * loss_scale
+    gu, gt = torch.empty_like(vu), torch.empty_like(vt)
+    n = vu[0].numel()
+    sig, sigp = scheduler.sigmas[step_index:step_index + 1], scheduler.sigmas[step_index + 1:step_index + 2]
+    _lib.check(lib.advgrpo_sde_step_bwd(vu.data_ptr(), vt.data_ptr(), _lib.dtype_code(vu.dtype), float(guidance_scale),
+                                        x.data_ptr(), _lib.dtype_code(x.dtype), sig.data_ptr(), sigp.data_ptr(), 0,
+                                        float(math.sin(noise_level * math.pi / 2)), nxt.data_ptr(),
+                                        _lib.dtype_code(nxt.dtype), dlp.data_ptr(), gu.data_ptr(), gt.data_ptr(), G, n,
+                                        _lib.stream_ptr()))
+    model.backward(ctx, torch.cat([gu, gt]))
+    return {"log_prob": log_prob, "scalars": scal, **{k: scal[i] for i, k in enumerate(losses.INFO_KEYS)}}

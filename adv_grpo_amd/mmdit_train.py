@@ -1,0 +1,364 @@
+"""LoRA training of the MMDiT on the gfx950 kernels: forward with saved activations, explicit backward, AdamW, EMA.
+
+Replaces, for the G-step (scripts/train_sd3_fast_pickscore.py:1077-1187): peft's LoRA wrapping of the attention
+projections (TP:490-511: r=32, alpha=64, gaussian init, targets attn.{to_q,to_k,to_v,to_out.0,add_q_proj,
+add_k_proj,add_v_proj,to_add_out}), torch autograd through diffusers' SD3Transformer2DModel, DeepSpeed/accelerate
+gradient accumulation + clip_grad_norm_ + AdamW (TP:1165-1171, TP:554-561) and EMAModuleWrapper (adv_grpo/ema.py).
+
+MI355X-first choices:
+  * LoRA is MERGED into the bf16 weights (W_eff = W + (alpha/r) B A, and the transposed copy used by the
+    data-gradient GEMMs); forward and dgrad therefore run at full-GEMM efficiency with no rank-32 side path.  The
+    LoRA weight gradients are recovered from (X, dY) of each adapted Linear:
+        dB = s * dY^T (X A^T),   dA = s * (dY B)^T X
+    as split-K GEMMs over the token axis accumulating atomically into the flat f32 gradient vector.
+  * No activation recomputation: with 288 GB of HBM every tensor the backward needs is kept (~0.6 GB per block per
+    micro-step at batch 16).
+  * Ranks are padded 32 -> 64 (zero rows/columns) so every contraction is a multiple of the 64-deep MFMA k tile;
+    the padding provably stays zero under AdamW.
+  * All LoRA parameters / gradients / Adam moments live in ONE flat f32 vector each: one fused AdamW launch,
+    one sum-of-squares launch for clip_grad_norm_, one RCCL all-reduce of the gradient vector for data parallelism.
+"""
+import math
+
+import torch
+
+from . import _lib, ops
+from .mmdit import SD3Transformer2DModel
+
+RANK, RPAD = 32, 64
+
+
+class _Adapter:
+    __slots__ = ("name", "N", "K", "offA", "offB")
+
+    def __init__(self, name, N, K, offA, offB):
+        self.name, self.N, self.K, self.offA, self.offB = name, N, K, offA, offB
+
+
+class SD3TransformerLoRA(SD3Transformer2DModel):
+    def __init__(self, state_dict, cfg, device="cuda", lora_alpha=64, seed=0, lora_state=None):
+        self._base_sd = {k: v for k, v in state_dict.items()}
+        super().__init__(state_dict, cfg, device)
+        self.scale = lora_alpha / RANK
+        D = cfg.dim
+        # ---- flat parameter vector: per adapter A_pad [64, K] then B_pad [N, 64]
+        self.adapters = {}
+        off = 0
+        for i in range(cfg.num_layers):
+            names = ["to_q", "to_k", "to_v", "to_out.0", "add_q_proj", "add_k_proj", "add_v_proj"]
+            if i != cfg.num_layers - 1:
+                names.append("to_add_out")
+            for n in names:
+                key = f"transformer_blocks.{i}.attn.{n}"
+                self.adapters[key] = _Adapter(key, D, D, off, off + RPAD * D)
+                off += RPAD * D + D * RPAD
+        self.n_params = off
+        dev = self.device
+        self.params = torch.zeros(off, dtype=torch.float32, device=dev)
+        g = torch.Generator().manual_seed(seed)
+        for key, ad in self.adapters.items():
+            if lora_state is not None:
+                A, Bm = lora_state[key + ".lora_A.weight"].float(), lora_state[key + ".lora_B.weight"].float()
+            else:                                                  # init_lora_weights="gaussian": A ~ N(0, 1/r), B = 0
+                A, Bm = torch.randn(RANK, ad.K, generator=g) / RANK, torch.zeros(ad.N, RANK)
+            self.A_view(ad)[:RANK] = A.to(dev)
+            self.B_view(ad)[:, :RANK] = Bm.to(dev)
+        self.grads = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.params_bf16 = self.params.to(torch.bfloat16)
+        self.opt_step = 0
+        self.ema = None
+        self._base_T = {}
+        self._prepare_transposes()
+        self.refresh()
+
+    # ------------------------------------------------------------------ parameter views
+    def A_view(self, ad, src=None):
+        return (self.params if src is None else src)[ad.offA:ad.offA + RPAD * ad.K].view(RPAD, ad.K)
+
+    def B_view(self, ad, src=None):
+        return (self.params if src is None else src)[ad.offB:ad.offB + ad.N * RPAD].view(ad.N, RPAD)
+
+    def lora_state_dict(self):
+        """peft-style names -> [r,K] / [N,r] f32 tensors (unpadded)."""
+        out = {}
+        for key, ad in self.adapters.items():
+            out[key + ".lora_A.weight"] = self.A_view(ad)[:RANK].clone()
+            out[key + ".lora_B.weight"] = self.B_view(ad)[:, :RANK].clone()
+        return out
+
+    def lora_grads(self):
+        out = {}
+        for key, ad in self.adapters.items():
+            out[key + ".lora_A.weight"] = self.A_view(ad, self.grads)[:RANK].clone()
+            out[key + ".lora_B.weight"] = self.B_view(ad, self.grads)[:, :RANK].clone()
+        return out
+
+    # ------------------------------------------------------------------ frozen transposes for the data-gradient GEMMs
+    def _prepare_transposes(self):
+        dev = self.device
+        T = lambda w: w.t().contiguous()
+        for i, b in enumerate(self.blocks):
+            for k in ("ff1", "ff2", "cff1", "cff2", "qkv2", "out2"):
+                if k + ".w" in b:
+                    b[k + ".wT"] = T(b[k + ".w"])
+        self.w["proj_out.wT"] = T(self.w["proj_out.w"])
+        # base (un-merged) copies of the adapted weights and their transposes
+        sd = self._base_sd
+        bf = lambda t: t.to(device=dev, dtype=torch.bfloat16).contiguous()
+        for i in range(self.cfg.num_layers):
+            p = f"transformer_blocks.{i}.attn"
+            last = i == self.cfg.num_layers - 1
+            base = {"qkv": bf(torch.cat([sd[f"{p}.to_q.weight"], sd[f"{p}.to_k.weight"], sd[f"{p}.to_v.weight"]])),
+                    "cqkv": bf(torch.cat([sd[f"{p}.add_q_proj.weight"], sd[f"{p}.add_k_proj.weight"],
+                                          sd[f"{p}.add_v_proj.weight"]])),
+                    "out": bf(sd[f"{p}.to_out.0.weight"])}
+            if not last:
+                base["cout"] = bf(sd[f"{p}.to_add_out.weight"])
+            self._base_T[i] = {k: (v, T(v)) for k, v in base.items()}
+        del self._base_sd
+
+    # ------------------------------------------------------------------ merge LoRA into the working weights
+    @torch.no_grad()
+    def refresh(self):
+        """bf16 copies of A/B, their transposes, and W_eff / W_eff^T of every adapted projection."""
+        self.params_bf16.copy_(self.params)
+        D = self.cfg.dim
+        self._lora = {}
+        for i, b in enumerate(self.blocks):
+            p = f"transformer_blocks.{i}.attn"
+            groups = {"qkv": ["to_q", "to_k", "to_v"], "cqkv": ["add_q_proj", "add_k_proj", "add_v_proj"],
+                      "out": ["to_out.0"]}
+            if not b["last"]:
+                groups["cout"] = ["to_add_out"]
+            for gk, names in groups.items():
+                base, baseT = self._base_T[i][gk]
+                w = b[gk + ".w"]
+                wT = b.get(gk + ".wT")
+                if wT is None:
+                    wT = b[gk + ".wT"] = torch.empty(base.shape[1], base.shape[0], dtype=torch.bfloat16, device=self.device)
+                As, Bts = [], []
+                for j, n in enumerate(names):
+                    ad = self.adapters[f"{p}.{n}"]
+                    A16 = self.A_view(ad, self.params_bf16)                      # [64, K]
+                    B16 = self.B_view(ad, self.params_bf16)                      # [N, 64]
+                    AT = ops.transpose(A16)                                      # [K, 64]
+                    sl = slice(j * D, (j + 1) * D)
+                    # W_eff[n,k] = W + s * B A ;  W_eff^T[k,n] = W^T + s * A^T B^T
+                    ops.gemm(B16, AT, alpha=self.scale, residual=base[sl], out=w[sl])
+                    ops.gemm(AT, B16, alpha=self.scale, residual=baseT[:, sl], out=wT[:, sl])
+                    As.append(A16)
+                    Bts.append(ops.transpose(B16))                               # [64, N]
+                self._lora[(i, gk)] = (torch.cat(As, 0).contiguous(), Bts, [self.adapters[f"{p}.{n}"] for n in names])
+
+    # ------------------------------------------------------------------ forward with saved activations
+    @torch.no_grad()
+    def forward_train(self, hidden_states, timestep, encoder_hidden_states, pooled_projections):
+        """Same arithmetic as __call__, keeping what backward() needs.  Returns (v [B,16,h,w] bf16, ctx)."""
+        cfg, w = self.cfg, self.w
+        D, H = cfg.dim, cfg.num_heads
+        B, C, h, wd = hidden_states.shape
+        hh, ww = h // cfg.patch_size, wd // cfg.patch_size
+        Ni, Nt = hh * ww, encoder_hidden_states.shape[1]
+        S = Ni + Nt
+        dev = hidden_states.device
+        bf16 = torch.bfloat16
+        x = ops.gemm(ops.patchify(hidden_states.contiguous()), w["patch.w"], bias=w["patch.b"], residual=self._pos(B, hh, ww))
+        t1 = "time_text_embed.timestep_embedder.linear_1"; t2 = "time_text_embed.timestep_embedder.linear_2"
+        p1 = "time_text_embed.text_embedder.linear_1"; p2 = "time_text_embed.text_embedder.linear_2"
+        te = ops.gemm(ops.gemm(ops.timestep_embedding(timestep), w[t1 + ".w"], bias=w[t1 + ".b"], act="silu"),
+                      w[t2 + ".w"], bias=w[t2 + ".b"])
+        temb = ops.gemm(ops.gemm(pooled_projections.to(bf16).contiguous(), w[p1 + ".w"], bias=w[p1 + ".b"], act="silu"),
+                        w[p2 + ".w"], bias=w[p2 + ".b"], residual=te)
+        mods = ops.gemm(ops.unary(temb, "silu"), w["mod.w"], bias=w["mod.b"])
+        c = ops.gemm(encoder_hidden_states.to(bf16).reshape(B * Nt, -1).contiguous(), w["context_embedder.w"],
+                     bias=w["context_embedder.b"])
+
+        def mod(key, j):
+            o = self.mod_off[key] + j * D
+            return mods[:, o:o + D]
+        ctx = {"B": B, "Ni": Ni, "Nt": Nt, "h": h, "w": wd, "mods": mods, "blocks": []}
+        for i, b in enumerate(self.blocks):
+            kx, kc = ("x", i), ("c", i)
+            s = {"x_in": x.clone(), "c_in": c.clone()}
+            if b["dual"]:
+                nx, nx2 = ops.layernorm_mod(x, scale=mod(kx, 1), shift=mod(kx, 0), scale2=mod(kx, 7), shift2=mod(kx, 6),
+                                            rows_per_batch=Ni)
+            else:
+                nx = ops.layernorm_mod(x, scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
+            nc = ops.layernorm_mod(c, scale=mod(kc, 0 if b["last"] else 1), shift=mod(kc, 1 if b["last"] else 0),
+                                   rows_per_batch=Nt)
+            qkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
+            qkv3 = qkv.view(B, S, 3 * D)
+            rs = torch.empty(B * S, 2 * H, dtype=torch.float32, device=dev)
+            ops.gemm(nx, b["qkv.w"], bias=b["qkv.b"], out=qkv, seg=(Ni, S, 0))
+            ops.gemm(nc, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni))
+            ops.rmsnorm_heads(qkv, 0, 2 * H, b["rms_x"], H, seg=(Ni, S, 0), M=B * Ni, rs_out=rs)
+            ops.rmsnorm_heads(qkv, 0, 2 * H, b["rms_c"], H, seg=(Nt, S, Ni), M=B * Nt, rs_out=rs)
+            att = torch.empty(B, S, D, dtype=bf16, device=dev)
+            lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+            ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att, lse=lse)
+            att2d = att.view(B * S, D)
+            ops.gemm(att2d, b["out.w"], bias=b["out.b"], gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x,
+                     a_seg=(Ni, S, 0), M=B * Ni)
+            if not b["last"]:
+                ops.gemm(att2d, b["cout.w"], bias=b["cout.b"], gate=mod(kc, 2), gate_rows=Nt, residual=c, out=c,
+                         a_seg=(Nt, S, Ni), M=B * Nt)
+            s.update(nx=nx, nc=nc, qkv=qkv, rs=rs, att=att, lse=lse)
+            if b["dual"]:
+                qkv2 = ops.gemm(nx2, b["qkv2.w"], bias=b["qkv2.b"])
+                rs2 = torch.empty(B * Ni, 2 * H, dtype=torch.float32, device=dev)
+                ops.rmsnorm_heads(qkv2, 0, 2 * H, b["rms_2"], H, rs_out=rs2)
+                q3 = qkv2.view(B, Ni, 3 * D)
+                lse2 = torch.empty(B, H, Ni, dtype=torch.float32, device=dev)
+                o2 = ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], H, lse=lse2)
+                ops.gemm(o2.view(B * Ni, D), b["out2.w"], bias=b["out2.b"], gate=mod(kx, 8), gate_rows=Ni, residual=x, out=x)
+                s.update(qkv2=qkv2, rs2=rs2, att2=o2, lse2=lse2)
+            s["x_mid"] = x.clone()
+            nxm = ops.layernorm_mod(x, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
+            pre = torch.empty(B * Ni, 4 * D, dtype=bf16, device=dev)
+            hmid = ops.gemm_train(nxm, b["ff1.w"], bias=b["ff1.b"], act="gelu_tanh", aux_out=pre)
+            ops.gemm(hmid, b["ff2.w"], bias=b["ff2.b"], gate=mod(kx, 5), gate_rows=Ni, residual=x, out=x)
+            s.update(pre=pre)
+            if not b["last"]:
+                s["c_mid"] = c.clone()
+                ncm = ops.layernorm_mod(c, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
+                cpre = torch.empty(B * Nt, 4 * D, dtype=bf16, device=dev)
+                chid = ops.gemm_train(ncm, b["cff1.w"], bias=b["cff1.b"], act="gelu_tanh", aux_out=cpre)
+                ops.gemm(chid, b["cff2.w"], bias=b["cff2.b"], gate=mod(kc, 5), gate_rows=Nt, residual=c, out=c)
+                s.update(cpre=cpre)
+            ctx["blocks"].append(s)
+        ctx["x_final"] = x
+        nx = ops.layernorm_mod(x, scale=mod(("out",), 0), shift=mod(("out",), 1), rows_per_batch=Ni)
+        tok = ops.gemm(nx, w["proj_out.w"], bias=w["proj_out.b"])
+        out = ops.unpatchify(tok, B, cfg.out_channels, h, wd, bf16)
+        return out, ctx
+
+    # ------------------------------------------------------------------ LoRA weight gradients of one Linear group
+    def _lora_wgrad(self, key, X, x_rows, x_seg, dY, dy_seg):
+        """X: activations (rows via x_seg), dY: [.., n_adapters*D] output gradient (rows via dy_seg)."""
+        A_cat, Bts, ads = self._lora[key]
+        D = self.cfg.dim
+        M = x_rows
+        splitk = max(1, min(32, M // 512))
+        XT = ops.transpose(X, R=M, seg=x_seg)                                   # [K, Mpad]
+        dYT = ops.transpose(dY, R=M, seg=dy_seg)                                # [n*D, Mpad]
+        t = ops.gemm(X, A_cat, a_seg=x_seg, M=M)                                # [M, n*64] = X A^T
+        tT = ops.transpose(t)                                                   # [n*64, Mpad]
+        for j, ad in enumerate(ads):
+            gA, gB = self.A_view(ad, self.grads), self.B_view(ad, self.grads)
+            # dB[N,64] += s * dY_j^T t_j
+            ops.gemm_train(dYT[j * D:(j + 1) * D], tT[j * RPAD:(j + 1) * RPAD], alpha=self.scale, out=gB, splitk=splitk)
+            # u = dY_j B [M,64] ; dA[64,K] += s * u^T X
+            u = ops.gemm(dY[:, j * D:(j + 1) * D], Bts[j], a_seg=dy_seg, M=M)
+            ops.gemm_train(ops.transpose(u), XT, alpha=self.scale, out=gA, splitk=splitk)
+
+    # ------------------------------------------------------------------ explicit backward
+    @torch.no_grad()
+    def backward(self, ctx, dv):
+        """dv: gradient w.r.t. the model output [B,16,h,w] (bf16).  Accumulates LoRA gradients into self.grads."""
+        cfg, w = self.cfg, self.w
+        D, H = cfg.dim, cfg.num_heads
+        B, Ni, Nt = ctx["B"], ctx["Ni"], ctx["Nt"]
+        S = Ni + Nt
+        mods = ctx["mods"]
+        dev = dv.device
+        bf16 = torch.bfloat16
+
+        def mod(key, j):
+            o = self.mod_off[key] + j * D
+            return mods[:, o:o + D]
+        # final layer: v = unpatchify(LNmod(x) Wp^T + b)
+        dtok = self._patch_rows_of_output_grad(dv)                              # [B*Ni, 64]
+        dnx = ops.gemm(dtok, w["proj_out.wT"])                                  # [B*Ni, D]
+        dx = ops.layernorm_mod_bwd(ctx["x_final"], dnx, scale0=mod(("out",), 0), rows_per_batch=Ni)
+        dc = None
+        for i in reversed(range(cfg.num_layers)):
+            b, s = self.blocks[i], ctx["blocks"][i]
+            kx, kc = ("x", i), ("c", i)
+            # ---- image MLP
+            dyg = ops.gate_mul(dx, mod(kx, 5), Ni)
+            dpre = ops.gemm_train(dyg, b["ff2.wT"], act="dgelu_tanh", aux_in=s["pre"])
+            dnxm = ops.gemm(dpre, b["ff1.wT"])
+            dx1 = ops.layernorm_mod_bwd(s["x_mid"], dnxm, scale0=mod(kx, 4), dres=dx, rows_per_batch=Ni)
+            # ---- text MLP
+            if not b["last"]:
+                dcyg = ops.gate_mul(dc, mod(kc, 5), Nt)
+                dcpre = ops.gemm_train(dcyg, b["cff2.wT"], act="dgelu_tanh", aux_in=s["cpre"])
+                dncm = ops.gemm(dcpre, b["cff1.wT"])
+                dc1 = ops.layernorm_mod_bwd(s["c_mid"], dncm, scale0=mod(kc, 4), dres=dc, rows_per_batch=Nt)
+            # ---- second (image-only) attention of the dual blocks
+            dnx2 = None
+            if b["dual"]:
+                dy2 = ops.gate_mul(dx1, mod(kx, 8), Ni)
+                datt2 = ops.gemm(dy2, b["out2.wT"]).view(B, Ni, D)
+                q3 = s["qkv2"].view(B, Ni, 3 * D)
+                dqkv2 = torch.empty(B * Ni, 3 * D, dtype=bf16, device=dev)
+                d3 = dqkv2.view(B, Ni, 3 * D)
+                ops.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], s["att2"], datt2, s["lse2"], H,
+                                  d3[:, :, :D], d3[:, :, D:2 * D], d3[:, :, 2 * D:])
+                ops.rmsnorm_heads_bwd(dqkv2, s["qkv2"], s["rs2"], 0, 2 * H, b["rms_2"], H)
+                dnx2 = ops.gemm(dqkv2, b["qkv2.wT"])
+            # ---- joint attention
+            datt = torch.zeros(B * S, D, dtype=bf16, device=dev) if b["last"] else torch.empty(B * S, D, dtype=bf16, device=dev)
+            dyo = ops.gate_mul(dx1, mod(kx, 2), Ni)                             # grad of to_out.0 output
+            ops.gemm(dyo, b["out.wT"], out=datt, seg=(Ni, S, 0))
+            att2d = s["att"].view(B * S, D)
+            self._lora_wgrad((i, "out"), att2d, B * Ni, (Ni, S, 0), dyo, None)
+            if not b["last"]:
+                dyc = ops.gate_mul(dc1, mod(kc, 2), Nt)
+                ops.gemm(dyc, b["cout.wT"], out=datt, seg=(Nt, S, Ni))
+                self._lora_wgrad((i, "cout"), att2d, B * Nt, (Nt, S, Ni), dyc, None)
+            q3 = s["qkv"].view(B, S, 3 * D)
+            dqkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
+            d3 = dqkv.view(B, S, 3 * D)
+            ops.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], s["att"], datt.view(B, S, D), s["lse"], H,
+                              d3[:, :, :D], d3[:, :, D:2 * D], d3[:, :, 2 * D:])
+            ops.rmsnorm_heads_bwd(dqkv, s["qkv"], s["rs"], 0, 2 * H, b["rms_x"], H, seg=(Ni, S, 0), M=B * Ni)
+            ops.rmsnorm_heads_bwd(dqkv, s["qkv"], s["rs"], 0, 2 * H, b["rms_c"], H, seg=(Nt, S, Ni), M=B * Nt)
+            dnx = ops.gemm(dqkv, b["qkv.wT"], a_seg=(Ni, S, 0), M=B * Ni)
+            dnc = ops.gemm(dqkv, b["cqkv.wT"], a_seg=(Nt, S, Ni), M=B * Nt)
+            self._lora_wgrad((i, "qkv"), s["nx"], B * Ni, None, dqkv, (Ni, S, 0))
+            self._lora_wgrad((i, "cqkv"), s["nc"], B * Nt, None, dqkv, (Nt, S, Ni))
+            # ---- first norms
+            dx = ops.layernorm_mod_bwd(s["x_in"], dnx, scale0=mod(kx, 1), dy1=dnx2, scale1=mod(kx, 7) if b["dual"] else None,
+                                       dres=dx1, rows_per_batch=Ni)
+            if b["last"]:
+                dc = ops.layernorm_mod_bwd(s["c_in"], dnc, scale0=mod(kc, 0), rows_per_batch=Nt)
+            else:
+                dc = ops.layernorm_mod_bwd(s["c_in"], dnc, scale0=mod(kc, 1), dres=dc1, rows_per_batch=Nt)
+        return dx, dc
+
+    def _patch_rows_of_output_grad(self, dv):
+        """inverse of unpatchify: [B,C,H,W] -> token rows [B*(H/2)*(W/2), 4*C] with column (py*2+px)*C + c."""
+        B, C, Hh, Ww = dv.shape
+        x = dv.view(B, C, Hh // 2, 2, Ww // 2, 2).permute(0, 2, 4, 3, 5, 1)     # index plumbing (one strided copy)
+        return x.reshape(B * (Hh // 2) * (Ww // 2), 4 * C).contiguous()
+
+    # ------------------------------------------------------------------ optimiser
+    @torch.no_grad()
+    def optimizer_step(self, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, max_grad_norm=1.0, grad_scale=1.0):
+        """clip_grad_norm_(max_grad_norm) + AdamW.step() + zero_grad() (TP:1166-1171), then re-merge."""
+        lib = _lib.load()
+        self.opt_step += 1
+        sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        _lib.check(lib.advgrpo_sumsq_f32(self.grads.data_ptr(), self.n_params, sumsq.data_ptr(), _lib.stream_ptr()))
+        _lib.check(lib.advgrpo_adamw_step(self.params.data_ptr(), self.params_bf16.data_ptr(), self.grads.data_ptr(),
+                                          self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.n_params, lr, betas[0],
+                                          betas[1], eps, weight_decay, self.opt_step, sumsq.data_ptr(), max_grad_norm,
+                                          grad_scale, _lib.stream_ptr()))
+        self.refresh()
+        return sumsq
+
+    @torch.no_grad()
+    def ema_step(self, optimization_step, decay=0.9, update_step_interval=8):
+        """EMAModuleWrapper.step (adv_grpo/ema.py:39-52)."""
+        if self.ema is None:
+            self.ema = self.params.clone()
+        if (optimization_step + 1) % update_step_interval != 0:
+            return
+        d = min((1 + optimization_step) / (10 + optimization_step), decay)
+        lib = _lib.load()
+        _lib.check(lib.advgrpo_ema_step(self.ema.data_ptr(), self.params.data_ptr(), self.n_params, 1.0 - d,
+                                        _lib.stream_ptr()))

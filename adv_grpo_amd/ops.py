@@ -139,14 +139,15 @@ def layernorm_mod(x, out=None, w=None, b=None, scale=None, shift=None, scale2=No
     return (out, out2) if scale2 is not None else out
 
 
-def rmsnorm_heads(buf, col0, nheads, weight, heads_per_weight, eps=1e-6, seg=None, M=None):
-    """In place on buf [rows, ld] bf16; weight [(nheads/heads_per_weight), 64] bf16."""
+def rmsnorm_heads(buf, col0, nheads, weight, heads_per_weight, eps=1e-6, seg=None, M=None, rs_out=None):
+    """In place on buf [rows, ld] bf16; weight [(nheads/heads_per_weight), 64] bf16.
+    rs_out: optional f32 [rows, nheads] receiving 1/rms (indexed by the mapped row) for the backward."""
     lib = _lib.load()
     seg_rows, seg_stride, seg_off = seg if seg is not None else (0, 0, 0)
     M = buf.shape[0] if M is None else M
     _lib.check(lib.advgrpo_rmsnorm_heads(buf.data_ptr(), buf.stride(0), M, col0, nheads, weight.data_ptr(),
                                          heads_per_weight, float(eps), int(seg_rows), int(seg_stride), int(seg_off),
-                                         _lib.stream_ptr()))
+                                         rs_out.data_ptr() if rs_out is not None else None, _lib.stream_ptr()))
     return buf
 
 
@@ -242,3 +243,78 @@ def image_postprocess(y):
     _lib.check(lib.advgrpo_image_postprocess(_lib.ptr(y), _lib.dtype_code(y.dtype), ldc, img.data_ptr(), B, H, W,
                                              _lib.stream_ptr()))
     return img
+
+
+# ------------------------------------------------------------------ G-step (training) ops
+ACT_D = {"dgelu_tanh": 5, "dgelu": 6}
+
+
+def gemm_train(a, w, bias=None, act=None, alpha=1.0, gate=None, gate_rows=0, residual=None, out=None,
+               out_dtype=torch.bfloat16, aux_out=None, aux_in=None, splitk=1, M=None):
+    """GEMM with the training extras (see advgrpo_gemm_bf16_train): aux_out = pre-activation copy,
+    act in {"dgelu_tanh","dgelu"} multiplies by the activation derivative at aux_in, splitk > 1 accumulates
+    atomically into an f32 `out` (which must be given and hold the running sum)."""
+    lib = _lib.load()
+    K = a.shape[1]
+    M = a.shape[0] if M is None else M
+    N = w.shape[0]
+    if out is None:
+        assert splitk == 1
+        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    aux = aux_out if aux_out is not None else aux_in
+    code = ACT_D[act] if act in ACT_D else ACT[act]
+    with _Prof(M, N, K, splitk, 0):
+      _lib.check(lib.advgrpo_gemm_bf16_train(
+        a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), _lib.dtype_code(out.dtype),
+        M, N, K, _lib.ptr(bias), code, float(alpha), gate.data_ptr() if gate is not None else None,
+        gate.stride(0) if gate is not None else 0, int(gate_rows), residual.data_ptr() if residual is not None else None,
+        residual.stride(0) if residual is not None else 0, aux_out.data_ptr() if aux_out is not None else None,
+        aux_in.data_ptr() if aux_in is not None else None, aux.stride(0) if aux is not None else 0, int(splitk),
+        _lib.stream_ptr()))
+    return out
+
+
+def transpose(x, R=None, seg=None, pad_to=64, out=None):
+    """x [rows, C] bf16 (row pitch = stride(0)) -> [C, Rpad] with Rpad = R rounded up to `pad_to` (zero filled).
+    R rows are taken through the row-segment map `seg` = (seg_rows, seg_stride, seg_off) when given."""
+    lib = _lib.load()
+    C = x.shape[1]
+    R = x.shape[0] if R is None else R
+    Rpad = (R + pad_to - 1) // pad_to * pad_to
+    out = torch.empty(C, Rpad, dtype=torch.bfloat16, device=x.device) if out is None else out
+    sr, ss, so = seg if seg is not None else (0, 0, 0)
+    _lib.check(lib.advgrpo_transpose_bf16(x.data_ptr(), out.data_ptr(), R, C, x.stride(0), out.stride(0), Rpad, int(sr),
+                                          int(ss), int(so), _lib.stream_ptr()))
+    return out
+
+
+def layernorm_mod_bwd(x, dy0, scale0=None, dy1=None, scale1=None, dres=None, rows_per_batch=0, eps=1e-6, out=None):
+    lib = _lib.load()
+    M, D = x.shape
+    out = torch.empty(M, D, dtype=torch.bfloat16, device=x.device) if out is None else out
+    ms = scale0.stride(0) if scale0 is not None else 0
+    dp = lambda t: t.data_ptr() if t is not None else None
+    _lib.check(lib.advgrpo_layernorm_mod_bwd(x.data_ptr(), x.stride(0), dy0.data_ptr(), dp(dy1), dy0.stride(0), dp(scale0),
+                                             dp(scale1), ms, int(rows_per_batch), dp(dres), out.data_ptr(), out.stride(0),
+                                             M, D, float(eps), _lib.stream_ptr()))
+    return out
+
+
+def rmsnorm_heads_bwd(dy, y, rs, col0, nheads, weight, heads_per_weight, seg=None, M=None):
+    lib = _lib.load()
+    seg_rows, seg_stride, seg_off = seg if seg is not None else (0, 0, 0)
+    M = dy.shape[0] if M is None else M
+    _lib.check(lib.advgrpo_rmsnorm_heads_bwd(dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), rs.data_ptr(), M, col0,
+                                             nheads, weight.data_ptr(), heads_per_weight, int(seg_rows), int(seg_stride),
+                                             int(seg_off), _lib.stream_ptr()))
+    return dy
+
+
+def gate_mul(x, gate, rows_per_batch, out=None):
+    """out[m,:] = gate[m // rows_per_batch, :] * x[m,:]; gate a [G,D] bf16 view (row pitch stride(0))."""
+    lib = _lib.load()
+    M, D = x.shape
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(lib.advgrpo_gate_mul(x.data_ptr(), gate.data_ptr(), out.data_ptr(), M, D, int(rows_per_batch), gate.stride(0),
+                                    _lib.stream_ptr()))
+    return out

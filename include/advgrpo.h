@@ -136,7 +136,8 @@ int advgrpo_layernorm_mod(const void* x, int64_t ldx, void* out0, void* out1, in
  * through (seg_rows, seg_stride, seg_off) like the GEMM output map. */
 int advgrpo_rmsnorm_heads(void* buf, int64_t ld, int M, int col0, int nheads, const void* weight,
                           int heads_per_weight, float eps, int seg_rows, int64_t seg_stride,
-                          int64_t seg_off, void* stream);
+                          int64_t seg_off, float* rs_out /* optional f32 [rows, nheads]: 1/rms, for the backward */,
+                          void* stream);
 /* diffusers Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0): t f32 [B] -> bf16 [B, dim]. */
 int advgrpo_timestep_embedding(const float* t, void* out, int B, int dim, void* stream);
 /* y = act(x [+ x2]) on bf16, n % 8 == 0 (act 0 none, 3 SiLU). */
@@ -219,6 +220,40 @@ int advgrpo_dino_head_combine(const void* hidden, const void* w2, const void* b2
 /* PickScore (pickscore_scorer.py:40-52): scores[b] = logit_scale_exp * cos(text_b, image_b) / 26. */
 int advgrpo_pickscore_pairs(const void* image_embs, const void* text_embs, int B, int P, float logit_scale_exp,
                             float* scores, void* stream);
+
+/* ------------------------------------------------------------------ G-step (training) kernels
+ * The update half of the path: loss.backward() / clip_grad_norm_ / AdamW / EMA at
+ * scripts/train_sd3_fast_pickscore.py:1165-1171,1186-1187 and adv_grpo/ema.py:39-52; the backward of the
+ * transformer call inside compute_log_prob (TP:233-267) is assembled from these + advgrpo_attention_bwd. */
+/* GEMM with training extras: aux_out[orow,n] = pre-activation (bf16, pitch ld_aux); act 5/6 = multiply by
+ * GELU-tanh' / GELU-erf' evaluated at aux_in[orow,n]; splitk > 1: contraction split over workgroups, partial
+ * tiles atomically added into an f32 C (LoRA weight gradients, whose contraction runs over all tokens). */
+int advgrpo_gemm_bf16_train(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                            int out_dtype, int M, int N, int K, const void* bias, int act, float alpha,
+                            const void* gate, int64_t gate_stride, int gate_rows, const void* residual,
+                            int64_t ldr, void* aux_out, const void* aux_in, int64_t ld_aux, int splitk,
+                            void* stream);
+/* out[c, r] = in[row(r), c] for r < R, zero for R <= r < Rpad (row(r) = the GEMM row-segment map when seg_rows > 0). */
+int advgrpo_transpose_bf16(const void* in, void* out, int R, int C, int64_t ldi, int64_t ldo, int Rpad,
+                           int seg_rows, int64_t seg_stride, int64_t seg_off, void* stream);
+/* dx = dres + d/dx [ LN(x)*(1+scale0)+shift0 -> dy0  (+ LN(x)*(1+scale1)+shift1 -> dy1) ]; all bf16. */
+int advgrpo_layernorm_mod_bwd(const void* x, int64_t ldx, const void* dy0, const void* dy1, int64_t lddy,
+                              const void* scale0, const void* scale1, int64_t mod_stride, int rows_per_batch,
+                              const void* dres, void* dx, int64_t lddx, int M, int D, float eps, void* stream);
+/* in place: dy (grad of the normalised+weighted q|k heads) -> grad of the un-normalised heads. */
+int advgrpo_rmsnorm_heads_bwd(void* dy, int64_t lddy, const void* y, int64_t ldy, const float* rs, int M,
+                              int col0, int nheads, const void* weight, int heads_per_weight, int seg_rows,
+                              int64_t seg_stride, int64_t seg_off, void* stream);
+int advgrpo_gate_mul(const void* x, const void* gate, void* y, int M, int D, int rows_per_batch,
+                     int64_t gate_stride, void* stream);
+int advgrpo_sumsq_f32(const float* g, int64_t n, float* out /* += */, void* stream);
+/* torch.optim.AdamW step on a flat f32 vector (+ bf16 copy), with clip_grad_norm_ folded in
+ * (grad_sumsq = device scalar sum of squares of the UNSCALED grads; grad_scale multiplies every grad, e.g.
+ * 1/accumulation steps); grads are zeroed. */
+int advgrpo_adamw_step(float* param_f32, void* param_bf16, float* grad, float* exp_avg, float* exp_avg_sq,
+                       int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                       const float* grad_sumsq, float max_grad_norm, float grad_scale, void* stream);
+int advgrpo_ema_step(float* ema, const float* param, int64_t n, float one_minus_decay, void* stream);
 
 #ifdef __cplusplus
 }

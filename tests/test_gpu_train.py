@@ -1,0 +1,180 @@
+"""GPU parity of the G-step: LoRA gradients of the MMDiT backward (explicit HIP backward vs torch autograd on the
+fp32 oracle), the full compute_log_prob -> GRPO loss -> backward chain, AdamW / clip / EMA vs torch."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos(a, b):
+    return (torch.dot(a.flatten().double(), b.flatten().double()) / (a.double().norm() * b.double().norm() + 1e-30)).item()
+
+
+def _setup(cfg, seed, B, hw, Nt):
+    from adv_grpo_amd import synthetic
+    from oracle import lora as o_lora
+    W = {k: v.to(torch.bfloat16) for k, v in synthetic.mmdit_weights(cfg, seed).items()}
+    lora = {k: v.to(torch.bfloat16).float() for k, v in o_lora.init_lora(cfg, seed=seed + 1, zero_b=False).items()}
+    g = torch.Generator().manual_seed(seed + 2)
+    lat = torch.randn(B, 16, hw, hw, generator=g).to(torch.bfloat16)
+    t = torch.full((B,), 913.3488, dtype=torch.float32)
+    ctx = torch.randn(B, Nt, cfg.joint_attention_dim, generator=g).to(torch.bfloat16)
+    pooled = torch.randn(B, cfg.pooled_projection_dim, generator=g).to(torch.bfloat16)
+    return W, lora, lat, t, ctx, pooled, g
+
+
+def test_row_op_backwards_match_autograd():
+    from adv_grpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(0)
+    M, D, Bn = 96, 256, 3
+    x = torch.randn(M, D, device="cuda", generator=g).to(torch.bfloat16)
+    mods = torch.randn(Bn, 4 * D, device="cuda", generator=g).to(torch.bfloat16)
+    dy0 = torch.randn(M, D, device="cuda", generator=g).to(torch.bfloat16)
+    dy1 = torch.randn(M, D, device="cuda", generator=g).to(torch.bfloat16)
+    dres = torch.randn(M, D, device="cuda", generator=g).to(torch.bfloat16)
+    sc0, sc1 = mods[:, :D], mods[:, 2 * D:3 * D]
+    dx = ops.layernorm_mod_bwd(x, dy0, scale0=sc0, dy1=dy1, scale1=sc1, dres=dres, rows_per_batch=M // Bn)
+    xf = x.float().requires_grad_(True)
+    idx = torch.arange(M, device="cuda") // (M // Bn)
+    ln = torch.nn.functional.layer_norm(xf, (D,), eps=1e-6)
+    (ln * (1 + sc0.float()[idx]) * dy0.float() + ln * (1 + sc1.float()[idx]) * dy1.float()).sum().backward()
+    ref = xf.grad + dres.float()
+    assert ((dx.float() - ref).norm() / ref.norm()).item() < 1e-2
+    # rmsnorm heads backward
+    H = 4
+    buf = torch.randn(40, 3 * H * 64, device="cuda", generator=g).to(torch.bfloat16)
+    wq = (1 + 0.1 * torch.randn(2, 64, device="cuda", generator=g)).to(torch.bfloat16)
+    pre = buf.clone()
+    rs = torch.empty(40, 2 * H, dtype=torch.float32, device="cuda")
+    ops.rmsnorm_heads(buf, 0, 2 * H, wq, H, rs_out=rs)
+    dy = torch.randn(40, 3 * H * 64, device="cuda", generator=g).to(torch.bfloat16)
+    d_in = dy.clone()
+    ops.rmsnorm_heads_bwd(d_in, buf, rs, 0, 2 * H, wq, H)
+    pf = pre[:, :2 * H * 64].float().view(40, 2, H, 64).requires_grad_(True)
+    y = pf * torch.rsqrt(pf.pow(2).mean(-1, keepdim=True) + 1e-6) * wq.float()[None, :, None, :]
+    (y * dy[:, :2 * H * 64].float().view(40, 2, H, 64)).sum().backward()
+    assert ((d_in[:, :2 * H * 64].float().view(40, 2, H, 64) - pf.grad).norm() / pf.grad.norm()).item() < 2e-2
+    assert torch.equal(d_in[:, 2 * H * 64:], dy[:, 2 * H * 64:])           # v slice untouched
+    # transpose with segment gather + zero pad
+    src = torch.randn(5 * 20, 48, device="cuda", generator=g).to(torch.bfloat16)
+    tr = ops.transpose(src, R=5 * 7, seg=(7, 20, 3))
+    want = src.view(5, 20, 48)[:, 3:10].reshape(35, 48).t()
+    assert tr.shape == (48, 64) and torch.equal(tr[:, :35], want) and (tr[:, 35:] == 0).all()
+
+
+def test_split_k_atomic_gemm_and_dgelu_epilogue():
+    from adv_grpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = torch.randn(64, 4096, device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randn(1536, 4096, device="cuda", generator=g).to(torch.bfloat16)
+    acc = torch.ones(64, 1536, dtype=torch.float32, device="cuda")
+    ops.gemm_train(a, w, alpha=0.5, out=acc, splitk=16)
+    ref = 1 + 0.5 * (a.float() @ w.float().T)
+    assert (acc - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    x = torch.randn(256, 128, device="cuda", generator=g).to(torch.bfloat16)
+    w1 = (torch.randn(512, 128, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    pre = torch.empty(256, 512, dtype=torch.bfloat16, device="cuda")
+    h = ops.gemm_train(x, w1, act="gelu_tanh", aux_out=pre)
+    pf = x.float() @ w1.float().T
+    assert (pre.float() - pf).abs().max().item() < 2e-2
+    assert (h.float() - torch.nn.functional.gelu(pf, approximate="tanh")).abs().max().item() < 2e-2
+    dh = torch.randn(256, 64, device="cuda", generator=g).to(torch.bfloat16)
+    w2T = (torch.randn(512, 64, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    dpre = ops.gemm_train(dh, w2T, act="dgelu_tanh", aux_in=pre)
+    p32 = pre.float().requires_grad_(True)
+    torch.nn.functional.gelu(p32, approximate="tanh").backward(dh.float() @ w2T.float().T)
+    assert ((dpre.float() - p32.grad).norm() / p32.grad.norm()).item() < 1e-2
+
+
+@pytest.mark.parametrize("layers,dual", [(3, (0,)), (4, (0, 1))])
+def test_mmdit_lora_backward_vs_autograd(layers, dual):
+    from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
+    from oracle import lora as o_lora
+    from oracle import mmdit as o
+    cfg = o.MMDiTConfig(num_layers=layers, num_heads=4, joint_attention_dim=128, pooled_projection_dim=64,
+                        pos_embed_max_size=96, dual_attention_layers=dual)
+    W, lora, lat, t, ctx, pooled, g = _setup(cfg, 31, B=4, hw=16, Nt=13)
+    model = SD3TransformerLoRA(W, cfg, "cuda", lora_state=lora)
+    v, saved = model.forward_train(lat.cuda(), t.cuda(), ctx.cuda(), pooled.cuda())
+    (v_inf,) = model(lat.cuda(), t.cuda(), ctx.cuda(), pooled.cuda())
+    assert torch.equal(v, v_inf)                                              # training forward == rollout forward
+    dv = torch.randn(v.shape, generator=g).to(torch.bfloat16)
+    model.backward(saved, dv.cuda())
+    grads = model.lora_grads()
+    # oracle: fp32 autograd through W + s*B*A
+    W32 = {k: x.float().cuda() for k, x in W.items()}
+    lo = {k: x.cuda().requires_grad_(True) for k, x in lora.items()}
+    out = o.mmdit_forward(o_lora.effective_weights(W32, lo), cfg, lat.float().cuda(), t.cuda(), ctx.float().cuda(),
+                          pooled.float().cuda())
+    assert ((v.float() - out).norm() / out.norm()).item() < 3e-2
+    (out * dv.float().cuda()).sum().backward()
+    worst = 1.0
+    for k, gr in grads.items():
+        ref = lo[k].grad
+        if ref.norm().item() == 0:          # add_q_proj of the last (context_pre_only) block: text queries are discarded
+            assert gr.abs().max().item() == 0, k
+            continue
+        c = _cos(gr, ref)
+        ratio = (gr.norm() / ref.norm()).item()
+        worst = min(worst, c)
+        assert c > 0.97 and 0.9 < ratio < 1.1, (k, c, ratio)
+    print("worst LoRA-grad cosine", worst)
+
+
+def test_g_step_chain_log_prob_loss_backward_adamw():
+    """compute_log_prob (TP:233-267) -> GRPO loss (TP:1111-1130) -> backward -> clip + AdamW (TP:1165-1171)."""
+    from adv_grpo_amd import g_step
+    from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
+    from adv_grpo_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from oracle import lora as o_lora
+    from oracle import losses as o_loss
+    from oracle import mmdit as o
+    from oracle import rollout as o_roll
+    from oracle.scheduler import FlowMatchEulerScheduler
+    cfg = o.MMDiTConfig(num_layers=3, num_heads=4, joint_attention_dim=128, pooled_projection_dim=64,
+                        pos_embed_max_size=96, dual_attention_layers=(0,))
+    G = 4
+    W, lora, _, _, _, _, g = _setup(cfg, 41, B=2 * G, hw=16, Nt=13)
+    sch = FlowMatchEulerDiscreteScheduler(device="cuda"); sch.set_timesteps(10)
+    osch = FlowMatchEulerScheduler(); osch.device = "cuda"; osch.set_timesteps(10)
+    x = torch.randn(G, 16, 16, 16, generator=g).to(torch.bfloat16)
+    nxt = (x.float() * 0.95 + 0.3 * torch.randn(G, 16, 16, 16, generator=g)).to(torch.bfloat16)
+    embeds = torch.randn(2 * G, 13, 128, generator=g).to(torch.bfloat16)
+    pooled = torch.randn(2 * G, 64, generator=g).to(torch.bfloat16)
+    adv = torch.randn(G, generator=g)
+    sample = {"latents": x[:, None].cuda(), "next_latents": nxt[:, None].cuda(),
+              "timesteps": sch.timesteps[1].repeat(G)[:, None]}
+    model = SD3TransformerLoRA(W, cfg, "cuda", lora_state=lora)
+    # reference pass for old log-probs (oracle, no grad), perturbed so that ratio != 1
+    W32 = {k: t.float().cuda() for k, t in W.items()}
+    lo = {k: t.cuda().requires_grad_(True) for k, t in lora.items()}
+    tr = lambda xx, tt, cc, pp: o.mmdit_forward(o_lora.effective_weights(W32, lo), cfg, xx.float(), tt, cc.float(), pp.float())
+    osample = {k: v for k, v in sample.items()}
+    _, lp_ref, _, _ = o_roll.compute_log_prob(tr, osch, osample, 0, embeds.cuda(), pooled.cuda(), guidance_scale=4.5,
+                                              noise_level=0.8)
+    old = (lp_ref.detach() + 2e-5 * torch.randn(G, generator=g).cuda())
+    loss_ref, _ = o_loss.grpo_loss(lp_ref, old, adv.cuda(), 5, 1e-4)
+    loss_ref.backward()
+    info = g_step.micro_step(model, sch, sample, 0, embeds.cuda(), pooled.cuda(), old, adv.cuda(), guidance_scale=4.5,
+                             noise_level=0.8, adv_clip_max=5, clip_range=1e-4)
+    # log-prob is a mean of 4096 squared differences of O(1): bf16 transformer vs fp32 oracle
+    assert torch.allclose(info["log_prob"], lp_ref.detach(), rtol=3e-2)
+    grads = model.lora_grads()
+    cs = [_cos(grads[k], lo[k].grad) for k in grads if lo[k].grad.norm() > 0]
+    print("G-step LoRA-grad cosines: min", min(cs), "mean", sum(cs) / len(cs))
+    assert min(cs) > 0.9 and sum(cs) / len(cs) > 0.97
+    # optimiser: clip + AdamW on the flat vector vs torch.optim.AdamW on the same gradients
+    p0, g0 = model.params.clone(), model.grads.clone()
+    ref_p = p0.clone().requires_grad_(True)
+    ref_p.grad = g0.clone()
+    torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+    opt = torch.optim.AdamW([ref_p], lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    opt.step()
+    model.optimizer_step(lr=3e-4, weight_decay=1e-4, max_grad_norm=1.0)
+    assert torch.allclose(model.params, ref_p.detach(), rtol=1e-5, atol=1e-7)
+    assert (model.grads == 0).all()
+    model.ema_step(7)
+    assert model.ema is not None
