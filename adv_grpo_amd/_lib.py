@@ -49,6 +49,9 @@ SIGNATURES = {
     "advgrpo_adamw_step": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, _P,
                                    c_float, c_float, _P]),
     "advgrpo_ema_step": (c_int, [_P, _P, c_int64, c_float, _P]),
+    "advgrpo_gather_rows": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "advgrpo_dino_head_loss": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    "advgrpo_dino_head_dpre": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "advgrpo_timestep_embedding": (c_int, [_P, _P, c_int, c_int, _P]),
     "advgrpo_unary": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "advgrpo_patchify": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
@@ -59,7 +62,7 @@ SIGNATURES = {
     "advgrpo_latents_to_nhwc": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
     "advgrpo_image_postprocess": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _P]),
     "advgrpo_clip_preprocess_patches": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P,
-                                                _P, c_int, POINTER(c_float), POINTER(c_float), _P]),
+                                                _P, c_int, POINTER(c_float), POINTER(c_float), c_int, _P]),
     "advgrpo_dino_preprocess_patches": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_float),
                                                 POINTER(c_float), _P]),
     "advgrpo_gather_l2norm_rows": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),

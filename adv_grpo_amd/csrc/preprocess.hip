@@ -25,7 +25,8 @@ __device__ inline float ld_img(const void* img, int dt, int64_t i) {
 
 // ---- CLIP: quantise + horizontal PIL pass.  img [B,3,H,W] -> tmp u8 [B,3,H,OW]
 __global__ void clip_resize_h_kernel(const void* __restrict__ img, int dt, uint8_t* __restrict__ tmp, int64_t rows, int W,
-                                     int OW, const int* __restrict__ bounds, const int* __restrict__ coefs, int ksize) {
+                                     int OW, const int* __restrict__ bounds, const int* __restrict__ coefs, int ksize,
+                                     int trunc) {
     const int64_t total = rows * OW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int ox = i % OW;
@@ -35,7 +36,8 @@ __global__ void clip_resize_h_kernel(const void* __restrict__ img, int dt, uint8
         for (int k = 0; k < cnt; ++k) {
             float v = ld_img(img, dt, row * W + xmin + k) * 255.0f;
             if (dt == ADVGRPO_BF16) v = round_bf16(v);   // the product is a bf16 torch op when images are bf16
-            const int q = (int)fminf(fmaxf(rintf(v), 0.f), 255.f);  // (x*255).round().clamp(0,255).to(uint8)
+            // (x*255).round().clamp(0,255).to(uint8) (rewards.py:567)  |  (x*255).astype(uint8) (tensor_to_pil_list, TD:135-149)
+            const int q = (int)fminf(fmaxf(trunc ? truncf(v) : rintf(v), 0.f), 255.f);
             ss += q * coefs[ox * ksize + k];
         }
         ss >>= 22;
@@ -184,13 +186,14 @@ using namespace advgrpo;
 extern "C" int advgrpo_clip_preprocess_patches(const void* image, int image_dtype, void* patches, uint8_t* tmp, int B,
                                                int H, int W, int OH, int OW, const int* bounds_h, const int* coefs_h,
                                                int ksize_h, const int* bounds_v, const int* coefs_v, int ksize_v,
-                                               const float* mean3_host, const float* std3_host, void* stream) {
+                                               const float* mean3_host, const float* std3_host, int quant_trunc,
+                                               void* stream) {
     ADVGRPO_CHECK(image && patches && tmp && bounds_h && coefs_h && bounds_v && coefs_v && mean3_host && std3_host,
                   "clip_preprocess: null pointer");
     ADVGRPO_CHECK(OH % PATCH == 0 && OW % PATCH == 0 && B > 0, "clip_preprocess: output must be a multiple of 14");
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(clip_resize_h_kernel, dim3(2048), dim3(256), 0, s, image, image_dtype, tmp, (int64_t)B * 3 * H, W,
-                       OW, bounds_h, coefs_h, ksize_h);
+                       OW, bounds_h, coefs_h, ksize_h, quant_trunc);
     ADVGRPO_LAUNCH_CHECK();
     hipLaunchKernelGGL(clip_resize_v_patches_kernel, dim3(2048), dim3(256), 0, s, tmp, (bf16_t*)patches, B, H, OH, OW,
                        bounds_v, coefs_v, ksize_v, make_float3(mean3_host[0], mean3_host[1], mean3_host[2]),

@@ -305,3 +305,110 @@ extern "C" int advgrpo_ema_step(float* ema, const float* param, int64_t n, float
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------ DINO discriminator head (D-step)
+// train_dino, scripts/train_sd3_fast_dino_patch.py:156-232, on backbone features: rows are [cls, n sampled
+// patches] per image, real images first then fake.  head = Linear(D,Hd) -> GELU(erf) -> Linear(Hd,1).
+namespace advgrpo {
+
+// rows[b*(1+n) + 0] = feats[b,0,:], rows[b*(1+n)+1+j] = feats[b, 1+idx[b,j], :]   (no normalisation)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ feats, const int64_t* __restrict__ idx,
+                                                          bf16_t* __restrict__ out, int B, int T, int D, int n) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * (1 + n)) return;
+    const int b = row / (1 + n), j = row % (1 + n);
+    const int tok = j == 0 ? 0 : 1 + (int)idx[(int64_t)b * n + j - 1];
+    const bf16_t* src = feats + ((int64_t)b * T + tok) * D;
+    for (int d = lane * 8; d < D; d += 512)
+        *reinterpret_cast<uint4*>(out + (int64_t)row * D + d) = *reinterpret_cast<const uint4*>(src + d);
+}
+
+// per row: logit = h . w2 + b2 ; hinge loss / accuracy / d loss / d logit.  One wave per row.
+// stats[0] += loss, stats[1] += correct real cls, stats[2] += correct fake cls, stats[3] += sum(dl) (= d b2)
+__global__ __launch_bounds__(256) void dino_head_loss_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ w2,
+                                                             const bf16_t* __restrict__ b2, int R, int Hd, int n, int Breal,
+                                                             int Btot, float patch_w, float* __restrict__ logits,
+                                                             float* __restrict__ dl, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    float acc = 0.f;
+    for (int d = lane; d < Hd; d += 64) acc += bf2f(h[(int64_t)row * Hd + d]) * bf2f(w2[d]);
+    acc = wave_sum(acc);
+    if (lane != 0) return;
+    const float logit = round_bf16(acc + bf2f(b2[0]));
+    const int b = row / (1 + n), j = row % (1 + n);
+    const bool real = b < Breal, cls = j == 0;
+    const float y = real ? 1.f : -1.f;
+    const int nb = real ? Breal : (Btot - Breal);
+    // d_loss = 0.5*(mean_real relu(1-l) + mean_fake relu(1+l)) + patch_w * (same over patches)
+    const float wgt = cls ? 0.5f / (float)nb : patch_w * 0.5f / ((float)nb * (float)n);
+    const float margin = 1.0f - y * logit;
+    const float g = margin > 0.f ? -y * wgt : 0.f;
+    logits[row] = logit;
+    dl[row] = g;
+    atomicAdd(&stats[0], margin > 0.f ? margin * wgt : 0.f);
+    if (cls) atomicAdd(&stats[real ? 1 : 2], (y * logit > 0.f) ? 1.f : 0.f);
+    atomicAdd(&stats[3], g);
+}
+
+// dpre[r,c] = dl[r] * w2[c] * gelu_erf'(pre[r,c]) (bf16);  g_w2[c] += dl[r] * h[r,c];  g_b1[c] += dpre[r,c]
+__global__ __launch_bounds__(256) void dino_head_dpre_kernel(const bf16_t* __restrict__ pre, const bf16_t* __restrict__ h,
+                                                             const bf16_t* __restrict__ w2, const float* __restrict__ dl,
+                                                             bf16_t* __restrict__ dpre, float* __restrict__ g_w2,
+                                                             float* __restrict__ g_b1, int R, int Hd) {
+    // block = 256 columns x 32 rows
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Hd) return;
+    const int r0 = blockIdx.y * 32, r1 = min(R, r0 + 32);
+    const float w = bf2f(w2[c]);
+    float sw = 0.f, sb = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const float u = bf2f(pre[(int64_t)r * Hd + c]);
+        const float d = dl[r];
+        const float dg = 0.5f * (1.0f + erff(u * 0.7071067811865476f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+        const float v = d * w * dg;
+        dpre[(int64_t)r * Hd + c] = f2bf(v);
+        sb += v;
+        sw += d * bf2f(h[(int64_t)r * Hd + c]);
+    }
+    atomicAdd(&g_w2[c], sw);
+    atomicAdd(&g_b1[c], sb);
+}
+
+}  // namespace advgrpo
+
+extern "C" int advgrpo_gather_rows(const void* feats, const int64_t* idx, void* out, int B, int T, int D, int n,
+                                   void* stream) {
+    ADVGRPO_CHECK(feats && out && (n == 0 || idx) && B > 0 && D % 8 == 0, "gather_rows: bad argument");
+    const int rows = B * (1 + n);
+    hipLaunchKernelGGL(advgrpo::gather_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, advgrpo::as_stream(stream),
+                       (const advgrpo::bf16_t*)feats, idx, (advgrpo::bf16_t*)out, B, T, D, n);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_dino_head_loss(const void* hidden, const void* w2, const void* b2, int R, int Hd, int n, int B_real,
+                                      int B_total, float patch_loss_weight, float* logits, float* dlogits, float* stats4,
+                                      void* stream) {
+    ADVGRPO_CHECK(hidden && w2 && b2 && logits && dlogits && stats4 && R == B_total * (1 + n) && B_real > 0 &&
+                      B_total > B_real, "dino_head_loss: bad argument");
+    hipStream_t s = advgrpo::as_stream(stream);
+    if (hipMemsetAsync(stats4, 0, 4 * sizeof(float), s) != hipSuccess) { advgrpo::set_error("memset failed"); return -2; }
+    hipLaunchKernelGGL(advgrpo::dino_head_loss_kernel, dim3((R + 3) / 4), dim3(256), 0, s, (const advgrpo::bf16_t*)hidden,
+                       (const advgrpo::bf16_t*)w2, (const advgrpo::bf16_t*)b2, R, Hd, n, B_real, B_total, patch_loss_weight,
+                       logits, dlogits, stats4);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_dino_head_dpre(const void* pre, const void* hidden, const void* w2, const float* dlogits, void* dpre,
+                                      float* grad_w2, float* grad_b1, int R, int Hd, void* stream) {
+    ADVGRPO_CHECK(pre && hidden && w2 && dlogits && dpre && grad_w2 && grad_b1 && R > 0 && Hd > 0, "dino_head_dpre: bad argument");
+    hipLaunchKernelGGL(advgrpo::dino_head_dpre_kernel, dim3((Hd + 255) / 256, (R + 31) / 32), dim3(256), 0,
+                       advgrpo::as_stream(stream), (const advgrpo::bf16_t*)pre, (const advgrpo::bf16_t*)hidden,
+                       (const advgrpo::bf16_t*)w2, dlogits, (advgrpo::bf16_t*)dpre, grad_w2, grad_b1, R, Hd);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}

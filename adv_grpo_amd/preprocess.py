@@ -72,7 +72,13 @@ def _f3(v):
 
 
 def clip_patches(images, size=224):
-    """images [B,3,H,W] in [0,1] (f32 or bf16, device) -> bf16 [B*(size/14)^2, 640] patch rows."""
+    """images [B,3,H,W] in [0,1] (f32 or bf16, device) -> bf16 [B*(size/14)^2, 640] patch rows (CLIPProcessor)."""
+    return pil_patches(images, size, CLIP_MEAN, CLIP_STD, trunc=False)
+
+
+def pil_patches(images, size, mean, std, trunc=False):
+    """uint8 quantisation (round, or truncation as np.astype does) -> Pillow antialiased BICUBIC resize to
+    size x size -> /255 -> (x-mean)/std -> 14x14 patch rows, all on the device and bit-exact with PIL."""
     lib = _lib.load()
     B, C, H, W = images.shape
     assert C == 3
@@ -84,7 +90,7 @@ def clip_patches(images, size=224):
     tmp = torch.empty(B * 3 * H * size, dtype=torch.uint8, device=dev)
     _lib.check(lib.advgrpo_clip_preprocess_patches(
         _lib.ptr(images.contiguous()), _lib.dtype_code(images.dtype), patches.data_ptr(), tmp.data_ptr(), B, H, W, size,
-        size, bh.data_ptr(), ch.data_ptr(), kh, bv.data_ptr(), cv.data_ptr(), kv, _f3(CLIP_MEAN), _f3(CLIP_STD),
+        size, bh.data_ptr(), ch.data_ptr(), kh, bv.data_ptr(), cv.data_ptr(), kv, _f3(mean), _f3(std), int(trunc),
         _lib.stream_ptr()))
     return patches
 

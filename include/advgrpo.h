@@ -199,12 +199,14 @@ int advgrpo_image_postprocess(const void* y, int y_dtype, int ldc, float* image,
  * rescale 1/255, normalise, and im2col for the 14x14 patch embedding: patches bf16 [B*(OH/14)*(OW/14), 640]
  * (column = c*196 + iy*14 + ix; 588..639 zero).  bounds_{h,v}: int [out, 2] = (first tap, taps);
  * coefs_{h,v}: int [out, ksize] 22-bit fixed point (device; built on the host, adv_grpo_amd/preprocess.py).
- * tmp: B*3*H*OW bytes.  mean3_host/std3_host: HOST float[3]. */
+ * tmp: B*3*H*OW bytes.  mean3_host/std3_host: HOST float[3].  quant_trunc != 0: uint8 by truncation
+ * ((x*255).astype(uint8), tensor_to_pil_list of the D-step, train_sd3_fast_dino_patch.py:135-149) instead of round. */
 int advgrpo_clip_preprocess_patches(const void* image, int image_dtype, void* patches, uint8_t* tmp,
                                     int B, int H, int W, int OH, int OW,
                                     const int* bounds_h, const int* coefs_h, int ksize_h,
                                     const int* bounds_v, const int* coefs_v, int ksize_v,
-                                    const float* mean3_host, const float* std3_host, void* stream);
+                                    const float* mean3_host, const float* std3_host, int quant_trunc,
+                                    void* stream);
 /* DINO path (adv_grpo/rewards.py:379-391): F.interpolate(bicubic, align_corners=False) to OH x OW on
  * bf16-rounded pixels, bf16 round, (x-mean)/std in f32, bf16; same im2col output. */
 int advgrpo_dino_preprocess_patches(const void* image, int image_dtype, void* patches, int B, int H, int W,
@@ -254,6 +256,21 @@ int advgrpo_adamw_step(float* param_f32, void* param_bf16, float* grad, float* e
                        int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                        const float* grad_sumsq, float max_grad_norm, float grad_scale, void* stream);
 int advgrpo_ema_step(float* ema, const float* param, int64_t n, float one_minus_decay, void* stream);
+
+/* ------------------------------------------------------------------ D-step, DINO variant
+ * train_dino (scripts/train_sd3_fast_dino_patch.py:156-232) on frozen-backbone features: hinge loss on the CLS logit
+ * + 0.3 x hinge on n sampled patch logits; head = Linear(D,Hd) -> GELU -> Linear(Hd,1) (TD:592-603).
+ * Rows are [cls, n patches] per image, B_real real images first.  The two Linears run on advgrpo_gemm_bf16_train
+ * (pre-activation kept), these kernels do the rest; weight gradients of the first Linear are a split-K GEMM. */
+int advgrpo_gather_rows(const void* feats, const int64_t* idx, void* out, int B, int T, int D, int n, void* stream);
+/* logits[r] = hidden[r,:].w2 + b2; dlogits = d loss / d logit; stats4 = {loss, #real cls correct, #fake cls correct,
+ * sum(dlogits) = grad b2}. */
+int advgrpo_dino_head_loss(const void* hidden, const void* w2, const void* b2, int R, int Hd, int n, int B_real,
+                           int B_total, float patch_loss_weight, float* logits, float* dlogits, float* stats4,
+                           void* stream);
+/* dpre = dlogits (x) w2 * GELU'(pre) (bf16); grad_w2[c] += sum_r dlogits[r] hidden[r,c]; grad_b1[c] += sum_r dpre[r,c]. */
+int advgrpo_dino_head_dpre(const void* pre, const void* hidden, const void* w2, const float* dlogits, void* dpre,
+                           float* grad_w2, float* grad_b1, int R, int Hd, void* stream);
 
 #ifdef __cplusplus
 }

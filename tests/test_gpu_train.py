@@ -178,3 +178,51 @@ def test_g_step_chain_log_prob_loss_backward_adamw():
     assert (model.grads == 0).all()
     model.ema_step(7)
     assert model.ema is not None
+
+
+def test_dino_d_step_vs_reference_golden_and_autograd():
+    """train_dino (TD:156-232): loss / accuracy / Adam-updated head against the golden made by running the
+    reference function (tests/golden/losses.npz 'dino/*'), on its stand-in features."""
+    import os
+    from adv_grpo_amd.d_step import DinoHeadTrainable
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "losses.npz"))
+    d = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith("dino/")}
+    D, Hd = 24, 16
+    flat = torch.from_numpy(d["head"])
+    sd = {"layers.0.weight": flat[:Hd * D].view(Hd, D), "layers.0.bias": flat[Hd * D:Hd * D + Hd],
+          "layers.2.weight": flat[Hd * D + Hd:Hd * D + 2 * Hd].view(1, Hd), "layers.2.bias": flat[Hd * D + 2 * Hd:]}
+    # the GEMM needs K % 64 == 0: zero-pad the feature dimension 24 -> 64 (zeros do not change any product)
+    pad = lambda t: torch.nn.functional.pad(t, (0, 64 - D))
+    sdp = dict(sd); sdp["layers.0.weight"] = pad(sd["layers.0.weight"])
+    head = DinoHeadTrainable(sdp, in_dim=64, hidden_dim=Hd, device="cuda")
+    fr = pad(torch.from_numpy(d["feats_real"])).to(torch.bfloat16).cuda()
+    ff = pad(torch.from_numpy(d["feats_fake"])).to(torch.bfloat16).cuda()
+    loss, acc = head.loss_and_grads(fr, ff, torch.from_numpy(d["idx_real"]).cuda(), torch.from_numpy(d["idx_fake"]).cuda())
+    # bf16 features / activations vs the reference's fp32 run: 1e-2 relative on the loss; accuracy is a count
+    assert abs(loss.item() - float(d["d_loss"])) < 1e-2 * abs(float(d["d_loss"]))
+    assert acc.item() == float(d["acc"])
+    head.adam_step(1e-3)
+    after = head.state_dict()
+    ref = torch.from_numpy(d["head_after"])
+    got = torch.cat([after["layers.0.weight"][:, :D].reshape(-1).cpu(), after["layers.0.bias"].cpu(),
+                     after["layers.2.weight"].reshape(-1).cpu(), after["layers.2.bias"].cpu()])
+    # first Adam step moves every weight by lr * sign(grad) (+-1e-3): a sign flip would show as 2e-3.
+    # The last entry (b2) is excluded from the tight check: with every hinge active its gradient is
+    # sum(-w_real) + sum(+w_fake) = 0 up to rounding noise (|g| ~ 3e-7 in the reference run), which Adam turns into a
+    # noise-determined step of at most lr.
+    assert (got[:-1] - ref[:-1]).abs().max().item() < 3e-4
+    assert abs(got[-1] - ref[-1]).item() <= 1.1e-3
+
+
+def test_dino_d_step_full_size_runs_and_learns():
+    from adv_grpo_amd import synthetic, vit
+    from adv_grpo_amd.d_step import DinoHeadTrainable, train_dino
+    from adv_grpo_amd.model_configs import DinoConfig
+    cfg = DinoConfig(layers=2)
+    scorer = vit.DinoV2({k: v.to(torch.bfloat16) for k, v in synthetic.dino_weights(cfg, 3).items()}, cfg, "cuda")
+    head = DinoHeadTrainable(device="cuda", seed=1)
+    g = torch.Generator().manual_seed(0)
+    real = torch.rand(4, 3, 512, 512, generator=g).cuda()
+    fake = (torch.rand(4, 3, 512, 512, generator=g) * 0.5).cuda()
+    losses = [train_dino(scorer, head, None, real, fake, lr=1e-3)[0] for _ in range(6)]
+    assert all(math.isfinite(x) for x in losses) and losses[-1] < losses[0]
