@@ -1,0 +1,121 @@
+"""Experiment configurations of the Adv-GRPO SD3 trainers, kept as data.
+
+Field names, defaults and the seven named experiments follow the reference's config/base.py:4-113 and
+config/grpo.py:7-427 (the entry point `--config config/grpo.py:<name>` is kept: see config/grpo.py at the repo
+root).  Each experiment is the defaults + the shared SD3.5-medium "fast" preset + a per-experiment delta.
+`gpu_number` is a parameter here (the reference hard-codes 8, grpo.py:316) so a 1-GPU run gets a consistent
+num_batches_per_epoch.  Paths the reference hard-codes to its authors' cluster default to None.
+"""
+import os
+
+from .config_dict import ConfigDict
+
+DEFAULTS = {
+    "run_name": "", "seed": 42, "logdir": "logs", "save_freq": 20, "eval_freq": 20, "num_checkpoint_limit": 5,
+    "mixed_precision": "fp16", "allow_tf32": True, "use_lora": True, "dataset": "", "resolution": 768,
+    "pretrained": {"model": "runwayml/stable-diffusion-v1-5", "revision": "main"},
+    "sample": {"num_steps": 40, "eval_num_steps": 40, "guidance_scale": 4.5, "train_batch_size": 1,
+               "num_image_per_prompt": 1, "test_batch_size": 1, "num_batches_per_epoch": 2, "global_std": True,
+               "noise_level": 0.7, "same_latent": False},
+    "train": {"batch_size": 1, "use_8bit_adam": False, "learning_rate": 3e-4, "adam_beta1": 0.9, "adam_beta2": 0.999,
+              "adam_weight_decay": 1e-4, "adam_epsilon": 1e-8, "gradient_accumulation_steps": 1, "max_grad_norm": 1.0,
+              "num_inner_epochs": 1, "cfg": True, "adv_clip_max": 5, "clip_range": 1e-4, "timestep_fraction": 1.0,
+              "beta": 0.0, "lora_path": None, "ema": False},
+    "prompt_fn": "imagenet_animals", "prompt_fn_kwargs": {}, "reward_fn": {}, "save_dir": "",
+    "per_prompt_stat_tracking": True,
+}
+
+COMPRESSIBILITY = {
+    "pretrained": {"model": "stabilityai/stable-diffusion-3.5-medium"}, "use_lora": True,
+    "sample": {"batch_size": 8, "num_batches_per_epoch": 4}, "train": {"batch_size": 4, "gradient_accumulation_steps": 2},
+    "prompt_fn": "general_ocr", "reward_fn": {"jpeg_compressibility": 1}, "per_prompt_stat_tracking": True,
+}
+
+
+def _fast_preset(gpu_number, num_image_per_prompt, mini):
+    nb = int(48 / (gpu_number * mini / num_image_per_prompt))
+    return {
+        "mixed_precision": "bf16", "resolution": 512,
+        "pretrained": {"model": "stabilityai/stable-diffusion-3.5-medium"},
+        "sample": {"num_steps": 10, "train_num_steps": 2, "eval_num_steps": 40, "guidance_scale": 4.5,
+                   "train_batch_size": 1, "num_image_per_prompt": num_image_per_prompt,
+                   "mini_num_image_per_prompt": mini, "num_batches_per_epoch": nb, "test_batch_size": 16,
+                   "random_timestep": 0, "global_std": True, "noise_level": 0.8},
+        "train": {"batch_size": mini, "gradient_accumulation_steps": nb // 2, "num_inner_epochs": 1,
+                  "timestep_fraction": 0.99, "clip_range": 1e-5, "beta": 0.0, "ema": True, "lora_path": None},
+        "save_freq": 60, "eval_freq": 60, "discriminator": "pickscore", "train_d": True, "weight_path": None,
+        "json_path": None, "reference_image_path": None, "test_reference_image_path": None,
+        "prompt_fn": "general_ocr", "per_prompt_stat_tracking": True,
+    }
+
+
+# name -> (num_image_per_prompt, mini, delta)
+EXPERIMENTS = {
+    "dino_cotrain_sd3_fast": (16, 8, {
+        "wandb_init": True, "d_times": 10, "d_lr": 1e-4, "tune_layer": -2,
+        "case_name": "fast_dino_cotrain_16_8", "save_dir": "logs/dino/sd3.5-M-fast_dino_cotrain_16_8",
+        "reward_fn": {"dino_cotrain": 1}, "eval_reward_fn": {"pickscore": 1, "image_similarity": 1}}),
+    "dino_cotrain_sd3_patch_fast": (16, 8, {
+        "wandb_init": True, "d_times": 10, "d_lr": 1e-4, "tune_layer": -2, "limit": None,
+        "case_name": "fast_dino_cotrain_16_8_patch", "save_dir": "logs/dino/sd3.5-M-fast_dino_cotrain_16_8_patch",
+        "reward_fn": {"dino_patch_cotrain": 1}, "eval_reward_fn": {"pickscore": 1, "image_similarity": 1}}),
+    "dino_cotrain_sd3_multi_fast": (8, 8, {
+        "wandb_init": False, "d_times": 10, "d_lr": 1e-4, "tune_layer": (11,), "temperature": 2,
+        "case_name": "fast_dino_cotrain_multi", "save_dir": "logs/dino/sd3.5-M-fast_dino_cotrain_multi",
+        "reward_fn": {"dino_multi_cotrain": 1}, "eval_reward_fn": {"pickscore": 1, "image_similarity": 1}}),
+    "eval_sd3_fast": (8, 8, {
+        "wandb_init": False, "d_times": 10, "d_lr": 1e-4, "tune_layer": -2, "sample": {"repeat": 1},
+        "train": {"lora_path": ""}, "save_folder": None,
+        "reward_fn": {"dino_cotrain": 1}, "eval_reward_fn": {"pickscore": 1}}),
+    "pickscore_cotrain_sd3_fast": (16, 8, {
+        "wandb_init": True, "d_times": 20, "d_lr": 5e-6, "tune_layer": -1,
+        "case_name": "fast_pickscore_cotrain_lr_5e6_last1_16_8",
+        "save_dir": "logs/pickscore/sd3.5-M-fast_pickscore_cotrain_lr_5e6_last1_16_8",
+        "reward_fn": {"pickscore_cotrain": 1}, "eval_reward_fn": {"pickscore": 1}}),
+    "pickscore_sd3_fast": (16, 8, {
+        "wandb_init": True, "case_name": "fast_1node_16_8_multireward_11", "dataset": "dataset/ocr",
+        "sample": {"random_timestep": None}, "external_image_path": None,
+        "save_dir": "logs/pickscore_again/sd3.5-M-fast_1node_16_8_multireward_11_ocr_pickscore",
+        "reward_fn": {"pickscore": 0.5, "ocr": 0.5}, "_drop": ["discriminator", "train_d", "weight_path", "json_path",
+                                                              "reference_image_path", "test_reference_image_path"]}),
+}
+
+
+def base_config():
+    return ConfigDict(DEFAULTS)
+
+
+def compressibility():
+    cfg = base_config().update(COMPRESSIBILITY)
+    cfg.dataset = os.path.join(os.getcwd(), "dataset/pickscore")
+    return cfg
+
+
+def get_config(name, gpu_number=8):
+    """config/grpo.py:432-433 `get_config(name)`; `gpu_number` defaults to the reference's hard-coded 8."""
+    if name == "compressibility":
+        return compressibility()
+    if name not in EXPERIMENTS:
+        raise KeyError(f"unknown experiment '{name}' (have: compressibility, {', '.join(EXPERIMENTS)})")
+    nipp, mini, delta = EXPERIMENTS[name]
+    cfg = compressibility().update(_fast_preset(gpu_number, nipp, mini))
+    delta = dict(delta)
+    drop = delta.pop("_drop", [])
+    cfg.update(delta)
+    if not os.path.isabs(cfg.dataset):
+        cfg.dataset = os.path.join(os.getcwd(), cfg.dataset)
+    for k in drop:
+        cfg._fields.pop(k, None)
+    return cfg
+
+
+def parse_config_flag(value, **kw):
+    """`--config path/to/grpo.py:<name>` (ml_collections config_flags syntax, TP:44) -> ConfigDict."""
+    path, _, name = value.partition(":")
+    if not name:
+        raise ValueError("expected --config <file>:<experiment name>")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("advgrpo_user_config", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.get_config(name, **kw) if kw else mod.get_config(name)

@@ -1,0 +1,220 @@
+"""The Adv-GRPO epoch loop on the gfx950 kernels: sample -> score -> gather -> advantage -> D-step | G-step.
+
+Host loop standing in for ``main()`` of scripts/train_sd3_fast_{pickscore,dino_patch}.py (TP:709-1191, TD identical
+unless noted); one process per GPU, torch.distributed (RCCL) only at the path's exchange steps:
+  * packed all-gather of rewards + group ids once per epoch                       (TP:926-966)
+  * all-reduce of the flat LoRA gradient vector once per optimizer step           (TP:1165, DeepSpeed/DDP)
+  * all-reduce of the discriminator-head gradient vector once per D-step          (TD:749 DDP(head))
+The D/G gate is computed from all-gathered data, so every rank takes the same branch (TP:1008-1025, TD:1091-1097).
+
+Data enters through a ``DataProvider`` (prompt embeddings, CLIP ids and per-prompt reference images by dataset
+index): the text encoders and the reference-image files (f4) are outside the accelerated path, so the
+default provider is synthetic and seeded by the dataset index.
+"""
+import json
+import os
+import time
+
+import torch
+
+from . import distributed as D
+from . import g_step, rewards, stat_tracking
+from .d_step import train_dino
+from .diffusers_patch.sd3_pipeline_with_logprob_fast import pipeline_with_logprob_random
+from .sampler import DistributedKRepeatSampler
+
+
+class SyntheticData:
+    """Seeded stand-in for the prompt dataset + text encoders + reference-image store."""
+
+    def __init__(self, n_prompts=25432, n_tokens=205, ctx_dim=4096, pooled_dim=2048, resolution=512, device="cuda",
+                 dtype=torch.bfloat16):
+        self.n, self.nt, self.cd, self.pd, self.res = n_prompts, n_tokens, ctx_dim, pooled_dim, resolution
+        self.device, self.dtype = device, dtype
+        g = torch.Generator().manual_seed(99)
+        self.neg = (torch.randn(1, n_tokens, ctx_dim, generator=g).to(dtype).to(device),
+                    torch.randn(1, pooled_dim, generator=g).to(dtype).to(device))
+
+    def __len__(self):
+        return self.n
+
+    def prompt(self, idx):
+        g = torch.Generator().manual_seed(1_000_003 * idx + 7)
+        return (torch.randn(1, self.nt, self.cd, generator=g).to(self.dtype).to(self.device),
+                torch.randn(1, self.pd, generator=g).to(self.dtype).to(self.device))
+
+    def clip_ids(self, idx, n):
+        from .synthetic import clip_input_ids
+        return clip_input_ids(1, seed=idx).repeat(n, 1).to(self.device)
+
+    def reference_images(self, idx, n):
+        g = torch.Generator().manual_seed(2_000_003 * idx + 11)
+        return torch.rand(n, 3, self.res, self.res, generator=g).to(self.device)
+
+
+class JsonlLogger:
+    """wandb stand-in: one JSON object per log call (same metric names as TP:941-955,975-988,1132-1183)."""
+
+    def __init__(self, path, enabled=True):
+        self.path, self.enabled = path, enabled
+        if enabled and path:
+            os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+
+    def log(self, metrics, step):
+        if not self.enabled or not self.path:
+            return
+        rec = {"step": step, "time": time.time()}
+        rec.update({k: (v.item() if hasattr(v, "item") else v) for k, v in metrics.items()})
+        with open(self.path, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+
+
+class Trainer:
+    def __init__(self, config, pipeline, data, scorer, head=None, rank=0, world=1, log_path=None):
+        """pipeline.transformer: SD3TransformerLoRA; scorer: PickScoreScorer (pickscore variants) or vit.DinoV2 (DINO
+        variants) with ``head`` a d_step.DinoHeadTrainable."""
+        self.cfg, self.pipe, self.data, self.scorer, self.head = config, pipeline, data, scorer, head
+        self.rank, self.world = rank, world
+        self.device = pipeline.device
+        c = config
+        self.variant = "dino" if any(k.startswith("dino") for k in c.reward_fn.keys()) else "pickscore"
+        self.reward_key = next(iter(c.reward_fn.keys()))
+        self.reward_fn = rewards.multi_score(self.device, c.reward_fn.to_dict())
+        k = c.sample.num_image_per_prompt // c.sample.mini_num_image_per_prompt          # TP:577
+        self.sampler = DistributedKRepeatSampler(range(len(data)), c.sample.train_batch_size, k, world, rank, seed=c.seed)
+        self.stat_tracker = stat_tracking.PerPromptStatTracker(c.sample.global_std, device=self.device)
+        self.epoch, self.global_step = 0, 0
+        self.logger = JsonlLogger(log_path, enabled=(rank == 0))
+        self.timers = {}
+
+    def _tick(self, name, t0):
+        torch.cuda.synchronize()
+        self.timers[name] = self.timers.get(name, 0.0) + time.perf_counter() - t0
+
+    # ------------------------------------------------------------------ hot loop 1: sampling + scoring
+    def sample_epoch(self):
+        c = self.cfg
+        G, T = c.sample.mini_num_image_per_prompt, c.sample.train_num_steps
+        neg_pe, neg_ppe = self.data.neg
+        out = []
+        for i in range(c.sample.num_batches_per_epoch):
+            self.sampler.set_epoch(self.epoch * c.sample.num_batches_per_epoch + i)        # TP:729
+            idx = next(iter(self.sampler))[0]
+            pe, ppe = self.data.prompt(idx)
+            t0 = time.perf_counter()
+            images, lats, lps, tss = pipeline_with_logprob_random(
+                self.pipe, prompt_embeds=pe, pooled_prompt_embeds=ppe, negative_prompt_embeds=neg_pe,
+                negative_pooled_prompt_embeds=neg_ppe, num_inference_steps=c.sample.num_steps,
+                guidance_scale=c.sample.guidance_scale, output_type="pt", height=c.resolution, width=c.resolution,
+                noise_level=c.sample.noise_level, mini_num_image_per_prompt=G, train_num_steps=T,
+                process_index=self.rank, sample_num_steps=c.sample.num_steps, random_timestep=c.sample.random_timestep,
+                seed=(self.epoch * 1000 + i) * 64 + self.rank)                             # TP:755-772
+            self._tick("sample", t0)
+            ref = self.data.reference_images(idx, G)                                       # TP:773-801
+            t0 = time.perf_counter()
+            prompts = self.data.clip_ids(idx, G)
+            r, _ = self.reward_fn(images.to(torch.bfloat16), prompts, [{}] * G, scorer=self.scorer, head=self.head,
+                                  only_strict=True)                                        # TP:816
+            rr, _ = self.reward_fn(ref.to(torch.bfloat16), prompts, [{}] * G, scorer=self.scorer, head=self.head,
+                                   only_strict=True)                                       # TP:817
+            self._tick("score", t0)
+            lat = torch.stack(lats, dim=1)
+            out.append({"group": torch.full((G,), idx, dtype=torch.int32, device=self.device),
+                        "prompt_embeds": pe.repeat(G, 1, 1), "pooled_prompt_embeds": ppe.repeat(G, 1),
+                        "timesteps": torch.stack(tss, dim=1), "latents": lat[:, :-1], "next_latents": lat[:, 1:],
+                        "log_probs": torch.stack(lps, dim=1), "rewards": torch.as_tensor(r["avg"]).float(),
+                        "reference_rewards": torch.as_tensor(rr["avg"]).float(), "images": images, "ref_images": ref})
+        return {k: torch.cat([s[k] for s in out], dim=0) for k in out[0]}
+
+    # ------------------------------------------------------------------ one epoch
+    def run_epoch(self):
+        c = self.cfg
+        T = c.sample.train_num_steps
+        samples = self.sample_epoch()
+        # ---- gather rewards + group ids (one packed all-gather), advantages on the device
+        t0 = time.perf_counter()
+        rew = samples["rewards"].unsqueeze(1).repeat(1, T)                                  # TP:926-928
+        all_rew, all_gid = D.gather_rewards(rew, samples["group"])
+        adv = self.stat_tracker.update(all_gid, all_rew) if c.per_prompt_stat_tracking else \
+            ((all_rew - all_rew.mean()) / (all_rew.std() + 1e-4)).double()
+        group_size, n_hist = self.stat_tracker.get_stats()
+        self.stat_tracker.clear()
+        samples["advantages"] = D.ungather(adv, self.world, self.rank).float()              # TP:995-999
+        mean_gen = D.all_mean(samples["rewards"])                                           # TP:1008
+        mean_ref = D.all_mean(samples["reference_rewards"])                                 # TP:1011
+        self._tick("gather+advantage", t0)
+        self.logger.log({"epoch": self.epoch, "reward_avg": all_rew[:, 0].mean(), "reference_reward_avg": mean_ref,
+                         "group_size": group_size, "trained_prompt_num": n_hist}, self.global_step)
+        # ---- D or G (identical on every rank: derived from gathered data / the epoch counter)
+        if self.variant == "dino":
+            do_d = c.train_d and (self.epoch + 1) % c.d_times != 0                          # TD:1097
+        else:
+            do_d = c.train_d and bool(mean_ref < mean_gen)                                  # TP:1025
+        if do_d:
+            t0 = time.perf_counter()
+            info = self.d_step(samples)
+            self._tick("d_step", t0)
+            self.logger.log(info, self.global_step)
+            self.global_step += 1
+            self.epoch += 1
+            return {"phase": "D", **info}
+        t0 = time.perf_counter()
+        info = self.g_step(samples)
+        self._tick("g_step", t0)
+        self.epoch += 1
+        return {"phase": "G", **info}
+
+    def d_step(self, samples):
+        if self.variant != "dino":
+            raise NotImplementedError("PickScore discriminator update (CLIP last-layer backward) is not built yet; "
+                                      "run with train_d=False or a dino_* reward (see DESIGN.md section 7)")
+        reduce = None
+        if self.world > 1:
+            import torch.distributed as dist
+
+            def reduce(g):
+                dist.all_reduce(g)
+                g /= self.world
+        d_loss, acc = train_dino(self.scorer, self.head, None, samples["ref_images"], samples["images"], lr=self.cfg.d_lr,
+                                 all_reduce=reduce)
+        return {"train/d_loss": d_loss, "train/acc": acc}
+
+    def g_step(self, samples):
+        c = self.cfg
+        model = self.pipe.transformer
+        G, T, nb = c.sample.mini_num_image_per_prompt, c.sample.train_num_steps, c.sample.num_batches_per_epoch
+        GA = max(1, c.train.gradient_accumulation_steps)
+        neg_pe, neg_ppe = self.data.neg
+        agg = {}
+        n_acc = 0
+        for inner in range(c.train.num_inner_epochs):
+            for i in range(nb):
+                sl = slice(i * G, (i + 1) * G)
+                s = {k: samples[k][sl] for k in ("latents", "next_latents", "timesteps", "log_probs", "advantages",
+                                                 "prompt_embeds", "pooled_prompt_embeds")}
+                embeds = torch.cat([neg_pe.repeat(G, 1, 1), s["prompt_embeds"]])            # TP:1084-1091
+                pooled = torch.cat([neg_ppe.repeat(G, 1), s["pooled_prompt_embeds"]])
+                for j in range(T):
+                    info = g_step.micro_step(model, self.pipe.scheduler, s, j, embeds, pooled, s["log_probs"][:, j],
+                                             s["advantages"][:, j], guidance_scale=c.sample.guidance_scale,
+                                             noise_level=c.sample.noise_level, adv_clip_max=c.train.adv_clip_max,
+                                             clip_range=c.train.clip_range, loss_scale=1.0 / (GA * T))
+                    for k in ("loss", "approx_kl", "clipfrac", "clipfrac_gt_one", "clipfrac_lt_one", "policy_loss"):
+                        agg[k] = agg.get(k, 0) + info[k]
+                    n_acc += 1
+                if (i + 1) % GA == 0:                                                       # sync_gradients, TP:1166-1185
+                    if self.world > 1:
+                        import torch.distributed as dist
+                        dist.all_reduce(model.grads)
+                        model.grads /= self.world
+                    model.optimizer_step(lr=c.train.learning_rate, betas=(c.train.adam_beta1, c.train.adam_beta2),
+                                         eps=c.train.adam_epsilon, weight_decay=c.train.adam_weight_decay,
+                                         max_grad_norm=c.train.max_grad_norm)
+                    out = {k: v / n_acc for k, v in agg.items()}
+                    out.update({"epoch": self.epoch, "inner_epoch": inner})
+                    self.logger.log(out, self.global_step)
+                    self.global_step += 1
+                    agg, n_acc = {}, 0
+                if c.train.ema:
+                    model.ema_step(self.global_step)                                        # TP:1186-1187
+        return {"global_step": self.global_step}

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Launcher of the Adv-GRPO epoch loop (stand-in for scripts/train_sd3_fast_{pickscore,dino_patch}.py upstream):
+
+  python scripts/train_sd3_fast.py --config config/grpo.py:dino_cotrain_sd3_patch_fast [--epochs N] [--layers L]
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_sd3_fast.py --config ...
+
+No checkpoints / tokenizers / reference images exist on this platform: models get seeded synthetic weights of the
+real architecture and data comes from trainer.SyntheticData."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", required=True)
+    ap.add_argument("--epochs", type=int, default=2)
+    ap.add_argument("--layers", type=int, default=None, help="reduce the MMDiT depth (smoke runs)")
+    ap.add_argument("--batches", type=int, default=None, help="override sample.num_batches_per_epoch")
+    ap.add_argument("--log", default="logs/train.jsonl")
+    args = ap.parse_args()
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    from adv_grpo_amd import synthetic, vit
+    from adv_grpo_amd.config.experiments import parse_config_flag
+    from adv_grpo_amd.d_step import DinoHeadTrainable
+    from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
+    from adv_grpo_amd.model_configs import ClipConfig, DinoConfig, MMDiTConfig, VaeConfig
+    from adv_grpo_amd.pickscore_scorer import PickScoreScorer
+    from adv_grpo_amd.pipeline import SD3Pipeline
+    from adv_grpo_amd.trainer import SyntheticData, Trainer
+    from adv_grpo_amd.vae import AutoencoderKLDecoder
+    cfg = parse_config_flag(args.config, gpu_number=world)
+    if args.batches:
+        cfg.sample.num_batches_per_epoch = args.batches
+        cfg.train.gradient_accumulation_steps = max(1, args.batches // 2)
+    mcfg = MMDiTConfig() if args.layers is None else MMDiTConfig(num_layers=args.layers,
+                                                                 dual_attention_layers=tuple(range(min(13, args.layers))))
+    with synthetic.on_device(device):
+        tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, device, seed=cfg.seed)
+        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321), VaeConfig(), device)
+        head = None
+        if any(k.startswith("dino") for k in cfg.reward_fn.keys()):
+            scorer = vit.DinoV2(synthetic.dino_weights(DinoConfig(), 888), DinoConfig(), device)
+            head = DinoHeadTrainable(device=device, seed=cfg.seed)
+        else:
+            scorer = PickScoreScorer(device, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
+    pipe = SD3Pipeline(tr, vae, device)
+    data = SyntheticData(resolution=cfg.resolution, device=device)
+    trainer = Trainer(cfg, pipe, data, scorer, head, rank, world, log_path=args.log)
+    for _ in range(args.epochs):
+        info = trainer.run_epoch()
+        if rank == 0:
+            print(json.dumps({"epoch": trainer.epoch, **{k: (v if not hasattr(v, "item") else v.item()) for k, v in info.items()},
+                              "timers_s": {k: round(v, 3) for k, v in trainer.timers.items()}}))
+
+
+if __name__ == "__main__":
+    main()
