@@ -51,6 +51,11 @@ SIGNATURES = {
     "advgrpo_ema_step": (c_int, [_P, _P, c_int64, c_float, _P]),
     "advgrpo_gather_rows": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "advgrpo_dino_head_loss": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    "advgrpo_cls_attention_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "advgrpo_cls_attention_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "advgrpo_clip_pair_loss": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
+    "advgrpo_colsum_bf16": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
+    "advgrpo_ln_affine_grads": (c_int, [_P, c_int64, _P, c_int64, c_int, c_int, c_float, _P, _P, _P]),
     "advgrpo_dino_head_dpre": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "advgrpo_timestep_embedding": (c_int, [_P, _P, c_int, c_int, _P]),
     "advgrpo_unary": (c_int, [_P, _P, _P, c_int64, c_int, _P]),

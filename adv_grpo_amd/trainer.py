@@ -20,6 +20,7 @@ import torch
 from . import distributed as D
 from . import g_step, rewards, stat_tracking
 from .d_step import train_dino
+from .d_step_pickscore import ClipLastLayerTrainable, train_pickscore
 from .diffusers_patch.sd3_pipeline_with_logprob_fast import pipeline_with_logprob_random
 from .sampler import DistributedKRepeatSampler
 
@@ -83,6 +84,11 @@ class Trainer:
         k = c.sample.num_image_per_prompt // c.sample.mini_num_image_per_prompt          # TP:577
         self.sampler = DistributedKRepeatSampler(range(len(data)), c.sample.train_batch_size, k, world, rank, seed=c.seed)
         self.stat_tracker = stat_tracking.PerPromptStatTracker(c.sample.global_std, device=self.device)
+        self.clip_trainable = None
+        if self.variant == "pickscore" and c.get("train_d", False):
+            if c.tune_layer != -1:
+                raise NotImplementedError("PickScore D-step is built for tune_layer = -1 (the shipped config)")
+            self.clip_trainable = ClipLastLayerTrainable(scorer.model)                    # TP:1016-1020
         self.epoch, self.global_step = 0, 0
         self.logger = JsonlLogger(log_path, enabled=(rank == 0))
         self.timers = {}
@@ -123,7 +129,8 @@ class Trainer:
                         "prompt_embeds": pe.repeat(G, 1, 1), "pooled_prompt_embeds": ppe.repeat(G, 1),
                         "timesteps": torch.stack(tss, dim=1), "latents": lat[:, :-1], "next_latents": lat[:, 1:],
                         "log_probs": torch.stack(lps, dim=1), "rewards": torch.as_tensor(r["avg"]).float(),
-                        "reference_rewards": torch.as_tensor(rr["avg"]).float(), "images": images, "ref_images": ref})
+                        "reference_rewards": torch.as_tensor(rr["avg"]).float(), "images": images, "ref_images": ref,
+                        "clip_ids": prompts})
         return {k: torch.cat([s[k] for s in out], dim=0) for k in out[0]}
 
     # ------------------------------------------------------------------ one epoch
@@ -165,9 +172,6 @@ class Trainer:
         return {"phase": "G", **info}
 
     def d_step(self, samples):
-        if self.variant != "dino":
-            raise NotImplementedError("PickScore discriminator update (CLIP last-layer backward) is not built yet; "
-                                      "run with train_d=False or a dino_* reward (see DESIGN.md section 7)")
         reduce = None
         if self.world > 1:
             import torch.distributed as dist
@@ -175,6 +179,10 @@ class Trainer:
             def reduce(g):
                 dist.all_reduce(g)
                 g /= self.world
+        if self.variant != "dino":
+            d_loss = train_pickscore(self.clip_trainable, samples["clip_ids"], samples["ref_images"], samples["images"],
+                                     lr=self.cfg.d_lr, all_reduce=reduce)                   # TP:1025-1037
+            return {"train/d_loss": d_loss}
         d_loss, acc = train_dino(self.scorer, self.head, None, samples["ref_images"], samples["images"], lr=self.cfg.d_lr,
                                  all_reduce=reduce)
         return {"train/d_loss": d_loss, "train/acc": acc}

@@ -272,6 +272,24 @@ int advgrpo_dino_head_loss(const void* hidden, const void* w2, const void* b2, i
 int advgrpo_dino_head_dpre(const void* pre, const void* hidden, const void* w2, const float* dlogits, void* dpre,
                            float* grad_w2, float* grad_b1, int R, int Hd, void* stream);
 
+/* ------------------------------------------------------------------ D-step, PickScore (CLIP) variant
+ * train_pickscore (scripts/train_sd3_fast_pickscore.py:151-183) + CLIPCriterion (adv_grpo/pick_score_training.py:
+ * 89-224), trainable = vision_model.encoder.layers[-1] (TP:1016-1020 with tune_layer = -1).  CLIP pools the CLS
+ * token, so the last layer's attention is differentiated for ONE query per image. */
+/* qkv [Bt,S,3*H*hd] bf16 -> o_cls [Bt,H*hd] bf16 (attention output of token 0), probs [Bt,H,S] f32. */
+int advgrpo_cls_attention_fwd(const void* qkv, void* o_cls, float* probs, int Bt, int S, int H, int head_dim,
+                              float scale, void* stream);
+/* d o_cls -> dqkv [Bt,S,3*H*hd] bf16 (fully written; dq non-zero on token 0 only). */
+int advgrpo_cls_attention_bwd(const void* qkv, const float* probs, const void* do_cls, void* dqkv, int Bt, int S,
+                              int H, int head_dim, float scale, void* stream);
+/* loss = mean_i softplus(s (cos(t_i, e_{B+i}) - cos(t_i, e_i))) over pairs (real e_i, fake e_{B+i}) and its gradient
+ * w.r.t. the un-normalised image embeddings e [2B,P]; == CLIPCriterion.calc_loss with label_0 = 1, label_1 = 0. */
+int advgrpo_clip_pair_loss(const void* image_embs, const void* text_embs, int B, int P, float logit_scale_exp,
+                           float* loss, void* d_image_embs, void* stream);
+int advgrpo_colsum_bf16(const void* x, int64_t ld, int R, int C, float* out /* += */, void* stream);
+int advgrpo_ln_affine_grads(const void* x, int64_t ldx, const void* dy, int64_t lddy, int M, int D, float eps,
+                            float* grad_w /* += */, float* grad_b /* += */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

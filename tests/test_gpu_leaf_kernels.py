@@ -197,6 +197,7 @@ def test_grpo_loss_vs_reference_golden(dev, case):
                            torch.from_numpy(g["adv"]).to(dev), 5, float(g["clip"]))
     scal = scal.cpu().numpy()
     for i, k in enumerate(INFO_KEYS):
-        # expf on device vs CPU: <= 2 ulp -> 1e-6 relative on the loss; fractions are exact counts
-        np.testing.assert_allclose(scal[i], g[k], rtol=2e-6, atol=1e-9, err_msg=k)
+        # loss = mean of signed terms of magnitude |A|*ratio <= 5: f32 summation order + device expf (<= 2 ulp)
+        # give an absolute error of a few 1e-7; the clip fractions are exact counts
+        np.testing.assert_allclose(scal[i], g[k], rtol=2e-6, atol=1e-6, err_msg=k)
     np.testing.assert_allclose(grad.cpu().numpy(), g["grad"], rtol=2e-6, atol=1e-9)

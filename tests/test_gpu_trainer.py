@@ -57,3 +57,16 @@ def test_pickscore_variant_g_step():
     p0 = model.params.clone()
     b = tr_.run_epoch()
     assert b["phase"] == "G" and not torch.equal(model.params, p0) and torch.isfinite(model.params).all()
+
+
+def test_pickscore_variant_d_step_gate():
+    """mean(reference reward) < mean(generated reward) -> D-step on the CLIP scorer's last layer (TP:1025-1037)."""
+    tr_, model, _ = _build("pickscore", train_d=True)
+    w0 = tr_.scorer.model.v_enc.layers[-1]["fc1.w"].clone()
+    p0 = model.params.clone()
+    phases = [tr_.run_epoch()["phase"] for _ in range(2)]
+    assert set(phases) <= {"D", "G"}
+    if "D" in phases:
+        assert not torch.equal(tr_.scorer.model.v_enc.layers[-1]["fc1.w"], w0)
+    if "G" in phases:
+        assert not torch.equal(model.params, p0)
