@@ -32,7 +32,7 @@ SIGNATURES = {
     "advgrpo_gemm_bf16": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_int, _P, c_int,
                                   c_float, _P, c_int64, c_int, _P, c_int64, c_int, c_int64, c_int64, c_int, c_int64,
                                   c_int64, c_int, c_int64, c_int64, c_int64, _P]),
-    "advgrpo_gemm_variant": (c_int, [c_int, c_int, c_int, c_int]),
+    "advgrpo_gemm_variant": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "advgrpo_layernorm_mod": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int,
                                       c_int, c_float, _P]),
     "advgrpo_rmsnorm_heads": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int, c_float, c_int, c_int64, c_int64,

@@ -36,8 +36,9 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 __device__ inline float act_fn(float x, int act) {
     switch (act) {
         case ACT_GELU_TANH: {
-            const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-            return 0.5f * x * (1.0f + tanhf(u));
+            // 0.5 x (1 + tanh u) == x * sigmoid(2u): one v_exp + one v_rcp instead of a tanhf expansion
+            const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);
+            return x * __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
         }
         case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
         case ACT_SILU: return x / (1.0f + __expf(-x));
@@ -69,6 +70,92 @@ __device__ __forceinline__ void static_for(F&& f) {
 __device__ inline int xcd_remap(int bid, int nwg) {
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ---- fused epilogue shared by the kernel variants
+template <int FM, int FN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[FM][FN], int m0, int n0, int wm, int wn,
+                                              int bz, int lane) {
+    // lane holds C[m][n..n+3], m = frag row (lane&15), n = (lane>>4)*4.
+    // Full, 8-byte-aligned quads take the vector path (bf16x4 loads of bias / gate / residual, one bf16x4 or
+    // float4 store); the ragged N edge falls back to predicated scalars.  Fragments are visited with
+    // compile-time indices (static_for) so the accumulators never leave the register file.
+    const int mrow = lane & 15, ncol = (lane >> 4) * 4;
+    const bool vec_ok = ((p.ldc | p.ldr | p.gate_stride) & 3) == 0 && (p.N & 3) == 0;
+    static_for<FM * FN>([&](auto idx) {
+        constexpr int i = decltype(idx)::value / FN, j = decltype(idx)::value % FN;
+        const int m = m0 + wm * TM + i * 16 + mrow;
+        const int n = n0 + wn * TN + j * 16 + ncol;
+        if (m >= p.M || n >= p.N) return;
+        int64_t orow = m;
+        if (p.seg_rows > 0) {
+            const int bidx = m / p.seg_rows;
+            orow = (int64_t)bidx * p.seg_stride + p.seg_off + (m - bidx * p.seg_rows);
+        }
+        const int gb = p.gate_rows > 0 ? m / p.gate_rows : 0;
+        const bf16_t* grow = p.gate ? p.gate + (int64_t)bz * p.gate_batch_stride + (int64_t)gb * p.gate_stride : nullptr;
+        const bf16_t* rrow = p.residual ? p.residual + (int64_t)bz * p.strideR + orow * p.ldr : nullptr;
+        const int64_t o = (int64_t)bz * p.strideC + orow * p.ldc + n;
+        const f32x4 a4 = acc[i][j];
+        float v0 = a4[0] * p.alpha, v1 = a4[1] * p.alpha, v2 = a4[2] * p.alpha, v3 = a4[3] * p.alpha;
+        if (p.splitk > 1) {   // partial tile: f32 atomic accumulation (gradient buffers), no other epilogue
+            float* c = reinterpret_cast<float*>(p.C) + o;
+            unsafeAtomicAdd(c, v0);
+            if (n + 1 < p.N) unsafeAtomicAdd(c + 1, v1);
+            if (n + 2 < p.N) unsafeAtomicAdd(c + 2, v2);
+            if (n + 3 < p.N) unsafeAtomicAdd(c + 3, v3);
+            return;
+        }
+        if (vec_ok) {
+            if (p.bias) {
+                const uint2 q = *reinterpret_cast<const uint2*>(p.bias + n);
+                v0 += bf2f((bf16_t)(q.x & 0xffffu)); v1 += bf2f((bf16_t)(q.x >> 16));
+                v2 += bf2f((bf16_t)(q.y & 0xffffu)); v3 += bf2f((bf16_t)(q.y >> 16));
+            }
+            if (p.aux_out) {
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+                pk.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+                *reinterpret_cast<uint2*>(p.aux_out + (int64_t)bz * p.strideC + orow * p.ld_aux + n) = pk;
+            }
+            if (p.act >= ACT_DGELU_TANH) {
+                const uint2 q = *reinterpret_cast<const uint2*>(p.aux_in + (int64_t)bz * p.strideC + orow * p.ld_aux + n);
+                v0 *= dact_fn(bf2f((bf16_t)(q.x & 0xffffu)), p.act); v1 *= dact_fn(bf2f((bf16_t)(q.x >> 16)), p.act);
+                v2 *= dact_fn(bf2f((bf16_t)(q.y & 0xffffu)), p.act); v3 *= dact_fn(bf2f((bf16_t)(q.y >> 16)), p.act);
+            } else if (p.act != ACT_NONE) {
+                v0 = act_fn(v0, p.act); v1 = act_fn(v1, p.act); v2 = act_fn(v2, p.act); v3 = act_fn(v3, p.act);
+            }
+            if (grow) {
+                const uint2 q = *reinterpret_cast<const uint2*>(grow + n);
+                v0 *= bf2f((bf16_t)(q.x & 0xffffu)); v1 *= bf2f((bf16_t)(q.x >> 16));
+                v2 *= bf2f((bf16_t)(q.y & 0xffffu)); v3 *= bf2f((bf16_t)(q.y >> 16));
+            }
+            if (rrow) {
+                const uint2 q = *reinterpret_cast<const uint2*>(rrow + n);
+                v0 += bf2f((bf16_t)(q.x & 0xffffu)); v1 += bf2f((bf16_t)(q.x >> 16));
+                v2 += bf2f((bf16_t)(q.y & 0xffffu)); v3 += bf2f((bf16_t)(q.y >> 16));
+            }
+            if (p.out_dtype == ADVGRPO_BF16) {
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+                pk.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + o) = pk;
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + o) = make_float4(v0, v1, v2, v3);
+            }
+        } else {
+            auto put = [&](int r, float y) {
+                if (n + r >= p.N) return;
+                if (p.bias) y += bf2f(p.bias[n + r]);
+                y = act_fn(y, p.act);
+                if (grow) y *= bf2f(grow[n + r]);
+                if (rrow) y += bf2f(rrow[n + r]);
+                if (p.out_dtype == ADVGRPO_BF16) reinterpret_cast<bf16_t*>(p.C)[o + r] = f2bf(y);
+                else reinterpret_cast<float*>(p.C)[o + r] = y;
+            };
+            put(0, v0); put(1, v1); put(2, v2); put(3, v3);
+        }
+    });
 }
 
 template <int BM, int BN, int WM, int WN, bool CONV>
@@ -201,86 +288,126 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
         __syncthreads();
     }
 
-    // ---- fused epilogue: lane holds C[m][n..n+3], m = frag row (lane&15), n = (lane>>4)*4.
-    // Full, 8-byte-aligned quads take the vector path (bf16x4 loads of bias / gate / residual, one bf16x4 or
-    // float4 store); the ragged N edge falls back to predicated scalars.  Fragments are visited with
-    // compile-time indices (static_for) so the accumulators never leave the register file.
-    const int mrow = lane & 15, ncol = (lane >> 4) * 4;
-    const bool vec_ok = ((p.ldc | p.ldr | p.gate_stride) & 3) == 0 && (p.N & 3) == 0;
-    static_for<FM * FN>([&](auto idx) {
-        constexpr int i = decltype(idx)::value / FN, j = decltype(idx)::value % FN;
-        const int m = m0 + wm * TM + i * 16 + mrow;
-        const int n = n0 + wn * TN + j * 16 + ncol;
-        if (m >= p.M || n >= p.N) return;
-        int64_t orow = m;
-        if (p.seg_rows > 0) {
-            const int bidx = m / p.seg_rows;
-            orow = (int64_t)bidx * p.seg_stride + p.seg_off + (m - bidx * p.seg_rows);
+    gemm_epilogue<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Deep-pipelined variant for short-K problems (the MMDiT's K = 1536 Linears): BK = 32, a 4-slot LDS ring, LDS-DMA
+// for three tiles kept in flight ACROSS the workgroup barrier (counted s_waitcnt vmcnt + raw s_barrier, guide
+// section 5 "Pipelining across barriers").  The 2-stage kernel above drains the DMA queue before every barrier
+// (hipcc's __syncthreads), which exposes the HBM/L2 latency of each 64-deep tile once per iteration; here a tile
+// is requested three iterations before it is consumed.  Same fragment layout, swizzle idea and epilogue.
+//   LDS tile image: rows of 32 k = 64 B = 4 chunks; one DMA instruction (1 KiB) covers 16 rows; chunk c of row r
+//   sits at slot c ^ ((-(r >> 2)) & 3), which spreads each ds_read_b128 service group over all 16 bank slots.
+template <int BM, int BN, int NS, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_pipe_kernel(const GemmParams p) {
+    constexpr int BK = 32, AHEAD = NS - 2;   // tiles kept in flight beyond the one being consumed
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INST = BM / 16 / NW, B_INST = BN / 16 / NW;     // 16-row DMA instructions per wave
+    static_assert(A_INST >= 1 && B_INST >= 1, "tile too small for the wave count");
+    constexpr int LOADS = A_INST + B_INST;                        // per wave per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int swz = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (swz / tiles_n) * BM, n0 = (swz % tiles_n) * BN;
+    const int bz = blockIdx.y;
+    const bf16_t* __restrict__ A = p.A + (int64_t)bz * p.strideA;
+    const bf16_t* __restrict__ W = p.W + (int64_t)bz * p.strideW;
+
+    const int lrow = lane >> 2;                           // row inside the 16-row instruction
+    // chunk c of row r sits at slot c ^ h(r), h = (-(r >> 2)) & 3: with ds_read_b128's 16-lane service groups
+    // ({0-3,12-15,20-27}, ...) every group then touches 16 distinct 16-byte bank slots
+    const int schunk = (lane & 3) ^ ((0 - (lrow >> 2)) & 3);
+    const bf16_t* a_src[A_INST];
+    const bf16_t* b_src[B_INST];
+#pragma unroll
+    for (int it = 0; it < A_INST; ++it) {
+        int r = m0 + (wave + it * NW) * 16 + lrow;
+        r = r < p.M ? r : p.M - 1;
+        int64_t ar = r;
+        if (p.a_seg_rows > 0) {
+            const int bi = r / p.a_seg_rows;
+            ar = (int64_t)bi * p.a_seg_stride + p.a_seg_off + (r - bi * p.a_seg_rows);
         }
-        const int gb = p.gate_rows > 0 ? m / p.gate_rows : 0;
-        const bf16_t* grow = p.gate ? p.gate + (int64_t)bz * p.gate_batch_stride + (int64_t)gb * p.gate_stride : nullptr;
-        const bf16_t* rrow = p.residual ? p.residual + (int64_t)bz * p.strideR + orow * p.ldr : nullptr;
-        const int64_t o = (int64_t)bz * p.strideC + orow * p.ldc + n;
-        const f32x4 a4 = acc[i][j];
-        float v0 = a4[0] * p.alpha, v1 = a4[1] * p.alpha, v2 = a4[2] * p.alpha, v3 = a4[3] * p.alpha;
-        if (p.splitk > 1) {   // partial tile: f32 atomic accumulation (gradient buffers), no other epilogue
-            float* c = reinterpret_cast<float*>(p.C) + o;
-            unsafeAtomicAdd(c, v0);
-            if (n + 1 < p.N) unsafeAtomicAdd(c + 1, v1);
-            if (n + 2 < p.N) unsafeAtomicAdd(c + 2, v2);
-            if (n + 3 < p.N) unsafeAtomicAdd(c + 3, v3);
-            return;
-        }
-        if (vec_ok) {
-            if (p.bias) {
-                const uint2 q = *reinterpret_cast<const uint2*>(p.bias + n);
-                v0 += bf2f((bf16_t)(q.x & 0xffffu)); v1 += bf2f((bf16_t)(q.x >> 16));
-                v2 += bf2f((bf16_t)(q.y & 0xffffu)); v3 += bf2f((bf16_t)(q.y >> 16));
-            }
-            if (p.aux_out) {
-                uint2 pk;
-                pk.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
-                pk.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
-                *reinterpret_cast<uint2*>(p.aux_out + (int64_t)bz * p.strideC + orow * p.ld_aux + n) = pk;
-            }
-            if (p.act >= ACT_DGELU_TANH) {
-                const uint2 q = *reinterpret_cast<const uint2*>(p.aux_in + (int64_t)bz * p.strideC + orow * p.ld_aux + n);
-                v0 *= dact_fn(bf2f((bf16_t)(q.x & 0xffffu)), p.act); v1 *= dact_fn(bf2f((bf16_t)(q.x >> 16)), p.act);
-                v2 *= dact_fn(bf2f((bf16_t)(q.y & 0xffffu)), p.act); v3 *= dact_fn(bf2f((bf16_t)(q.y >> 16)), p.act);
-            } else if (p.act != ACT_NONE) {
-                v0 = act_fn(v0, p.act); v1 = act_fn(v1, p.act); v2 = act_fn(v2, p.act); v3 = act_fn(v3, p.act);
-            }
-            if (grow) {
-                const uint2 q = *reinterpret_cast<const uint2*>(grow + n);
-                v0 *= bf2f((bf16_t)(q.x & 0xffffu)); v1 *= bf2f((bf16_t)(q.x >> 16));
-                v2 *= bf2f((bf16_t)(q.y & 0xffffu)); v3 *= bf2f((bf16_t)(q.y >> 16));
-            }
-            if (rrow) {
-                const uint2 q = *reinterpret_cast<const uint2*>(rrow + n);
-                v0 += bf2f((bf16_t)(q.x & 0xffffu)); v1 += bf2f((bf16_t)(q.x >> 16));
-                v2 += bf2f((bf16_t)(q.y & 0xffffu)); v3 += bf2f((bf16_t)(q.y >> 16));
-            }
-            if (p.out_dtype == ADVGRPO_BF16) {
-                uint2 pk;
-                pk.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
-                pk.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + o) = pk;
-            } else {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + o) = make_float4(v0, v1, v2, v3);
-            }
-        } else {
-            auto put = [&](int r, float y) {
-                if (n + r >= p.N) return;
-                if (p.bias) y += bf2f(p.bias[n + r]);
-                y = act_fn(y, p.act);
-                if (grow) y *= bf2f(grow[n + r]);
-                if (rrow) y += bf2f(rrow[n + r]);
-                if (p.out_dtype == ADVGRPO_BF16) reinterpret_cast<bf16_t*>(p.C)[o + r] = f2bf(y);
-                else reinterpret_cast<float*>(p.C)[o + r] = y;
-            };
-            put(0, v0); put(1, v1); put(2, v2); put(3, v3);
-        }
-    });
+        a_src[it] = A + ar * p.lda + schunk * 8;
+    }
+#pragma unroll
+    for (int it = 0; it < B_INST; ++it) {
+        int r = n0 + (wave + it * NW) * 16 + lrow;
+        r = r < p.N ? r : p.N - 1;
+        b_src[it] = W + (int64_t)r * p.ldw + schunk * 8;
+    }
+    auto stage = [&](int slot, int kt) __attribute__((always_inline)) {
+        char* base = smem + slot * STAGE;
+#pragma unroll
+        for (int it = 0; it < A_INST; ++it)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[it] + kt * BK), (lds_ptr_t)(base + (wave + it * NW) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int it = 0; it < B_INST; ++it)
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[it] + kt * BK),
+                                             (lds_ptr_t)(base + A_BYTES + (wave + it * NW) * 1024), 16, 0, 0);
+    };
+    // fragment byte offset inside a tile: row (lane&15) * 64 B + swizzled chunk (lane>>4)
+    const int frow = lane & 15;
+    const int frag_off = frow * 64 + ((((lane >> 4)) ^ ((0 - (frow >> 2)) & 3)) << 4);
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    // prologue: NS-1 tiles in flight
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) stage(t, t);
+    int slot = 0;                      // slot of tile kt
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt must have landed: allow the younger tiles (at most AHEAD) to stay in flight
+        const int ahead = min(nk - 1 - kt, AHEAD);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // the slot of tile kt-1 is free now (every wave passed the barrier after reading it): refill it
+        const int fill = slot == 0 ? NS - 1 : slot - 1;
+        if (kt + NS - 1 < nk) stage(fill, kt + NS - 1);
+        const char* ta = smem + slot * STAGE + wm * TM * 64;
+        const char* tb = smem + slot * STAGE + A_BYTES + wn * TN * 64;
+        slot = slot == NS - 1 ? 0 : slot + 1;
+        bf16x8_t af[FM], bf[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(ta + i * 1024 + frag_off);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(tb + j * 1024 + frag_off);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    gemm_epilogue<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane);
+}
+
+template <int BM, int BN, int NS, int WM, int WN>
+static int launch_pipe(const GemmParams& p, hipStream_t s) {
+    constexpr int lds = NS * (BM + BN) * 32 * 2;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pipe_kernel<BM, BN, NS, WM, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, NS, WM, WN>), dim3(tiles, p.batch), dim3(WM * WN * 64), lds, s, p);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
 }
 
 template <int BM, int BN, int WM, int WN, bool CONV>
@@ -302,7 +429,7 @@ static int launch(const GemmParams& p, hipStream_t s) {
 // one workgroup per CU), 6 = 256x128 (8 waves); +conv: 4 = 128x128, 5 = 128x64, 7 = 256x256, 8 = 256x128.
 // The choice maximises (how full the last round of workgroups is) x (measured relative speed of the tile).
 static int g_force_variant = -2;
-static int gemm_variant(int M, int N, int batch, int conv) {   // batch includes the split-K factor
+static int gemm_variant(int M, int N, int K, int batch, int conv, int plain) {   // batch includes the split-K factor
     if (g_force_variant == -2) {
         const char* e = getenv("ADVGRPO_GEMM_FORCE");   // experiments only
         g_force_variant = e ? atoi(e) : -1;
@@ -320,12 +447,17 @@ static int gemm_variant(int M, int N, int batch, int conv) {   // batch includes
         if (conv) return f == 3 ? 7 : (f == 6 ? 8 : 4);
         return f;
     }
-    const double e3 = rounds_eff(256, 256, 256) * 1.00, e6 = rounds_eff(256, 128, 256) * 0.90,
-                 e0 = rounds_eff(128, 128, 512) * 0.62, e2 = rounds_eff(64, 128, 768) * 0.40;
-    if (conv) return (e3 >= e6 && e3 >= e0) ? 7 : (e6 >= e0 ? 8 : 4);
-    if (e3 >= e6 && e3 >= e0 && e3 >= e2) return 3;
-    if (e6 >= e0 && e6 >= e2) return 6;
-    return e0 >= e2 ? 0 : 2;
+    if (g_force_variant == -3) return conv ? 4 : 0;   // (experiments: ADVGRPO_GEMM_FORCE=-3 = always 128x128 2-stage)
+    // measured on MI355X (scripts/bench_gemm.py, random data): the 4-wave 128x128 tile wins on the MMDiT / ViT
+    // shapes (M = 16384 / 3280, N, K in {1536, 4608, 6144}); the 8-wave 256x256 tile only on large square problems.
+    (void)rounds_eff;
+    if (conv) return 4;
+    if (M >= 4096 && N >= 8192 && rounds_eff(256, 256, 256) > 0.85) return 3;
+    if (M <= 64) return 2;
+    // short contractions (the K = 1536 Linears): the deep-pipelined 8-wave kernel (3 workgroups x 8 waves per CU)
+    // hides the per-iteration DMA / barrier latency better; long contractions amortise it and prefer BK = 64.
+    if (plain && K <= 3072) return 13;
+    return 0;
 }
 
 int gemm_bf16(const GemmParams& p, hipStream_t s) {
@@ -340,7 +472,7 @@ int gemm_bf16(const GemmParams& p, hipStream_t s) {
                   "gemm: split-K accumulates atomically into f32 and takes no other epilogue");
     ADVGRPO_CHECK(p.act < ACT_DGELU_TANH || p.aux_in, "gemm: d-activation epilogue needs aux_in");
     ADVGRPO_CHECK(!(p.aux_out || p.aux_in) || ((p.ld_aux & 3) == 0 && (p.N & 3) == 0), "gemm: aux needs N, ld_aux %% 4 == 0");
-    const int variant = gemm_variant(p.M, p.N, p.batch * p.splitk, p.conv);
+    const int variant = gemm_variant(p.M, p.N, p.K, p.batch * p.splitk, p.conv, p.splitk == 1 && !p.conv);
     if (p.conv) {
         ADVGRPO_CHECK(p.Cin % 64 == 0 && p.K == 9 * p.Cin && p.zero_page && p.batch == 1,
                       "conv3x3: need Cin %% 64 == 0, K == 9*Cin, a zero page and batch 1 (Cin=%d K=%d)", p.Cin, p.K);
@@ -356,6 +488,11 @@ int gemm_bf16(const GemmParams& p, hipStream_t s) {
         case 5: return launch<128, 64, 2, 2, true>(p, s);
         case 7: return launch<256, 256, 2, 4, true>(p, s);
         case 8: return launch<256, 128, 4, 2, true>(p, s);
+        case 9: return launch_pipe<128, 128, 4, 2, 2>(p, s);
+        case 10: return launch_pipe<128, 128, 3, 2, 2>(p, s);
+        case 11: return launch_pipe<128, 128, 3, 4, 2>(p, s);
+        case 12: return launch_pipe<128, 128, 4, 4, 2>(p, s);
+        case 13: return launch_pipe<128, 128, 3, 2, 4>(p, s);
     }
     set_error("gemm: bad variant %d", variant);
     return -1;
@@ -365,7 +502,9 @@ int gemm_bf16(const GemmParams& p, hipStream_t s) {
 
 using namespace advgrpo;
 
-extern "C" int advgrpo_gemm_variant(int M, int N, int batch, int conv) { return gemm_variant(M, N, batch < 1 ? 1 : batch, conv); }
+extern "C" int advgrpo_gemm_variant(int M, int N, int K, int batch, int conv) {
+    return gemm_variant(M, N, K, batch < 1 ? 1 : batch, conv, !conv);
+}
 
 extern "C" int advgrpo_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                                  int out_dtype, int M, int N, int K, const void* bias, int act, float alpha,

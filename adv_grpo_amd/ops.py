@@ -11,7 +11,9 @@ GEMM_VARIANTS = {0: "gemm_bf16_kernel<128,128,2,2,false>", 1: "gemm_bf16_kernel<
                  2: "gemm_bf16_kernel<64,128,2,2,false>", 3: "gemm_bf16_kernel<256,256,2,4,false>",
                  6: "gemm_bf16_kernel<256,128,4,2,false>", 4: "gemm_bf16_kernel<128,128,2,2,true>",
                  5: "gemm_bf16_kernel<128,64,2,2,true>", 7: "gemm_bf16_kernel<256,256,2,4,true>",
-                 8: "gemm_bf16_kernel<256,128,4,2,true>"}
+                 8: "gemm_bf16_kernel<256,128,4,2,true>", 9: "gemm_bf16_pipe_kernel<128,128,4,2,2>", 10: "gemm_bf16_pipe_kernel<128,128,3,2,2>",
+                 11: "gemm_bf16_pipe_kernel<128,128,3,4,2>", 12: "gemm_bf16_pipe_kernel<128,128,4,4,2>",
+                 13: "gemm_bf16_pipe_kernel<128,128,3,2,4>"}
 # bench.py sets this to a list to collect (kernel name, flops, start event, end event) per GEMM launch;
 # events are recorded on the stream the kernel is launched on (torch's current stream).
 PROFILE = None
@@ -22,8 +24,9 @@ class _Prof:
         self.on = PROFILE is not None
         if self.on:
             lib = _lib.load()
-            self.name = GEMM_VARIANTS[lib.advgrpo_gemm_variant(M, N, batch, conv)]
+            self.name = GEMM_VARIANTS[lib.advgrpo_gemm_variant(M, N, K, batch, conv)]
             self.flops = 2.0 * M * N * K * batch
+            self.shape = (M, N, K, batch, conv)
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
 
@@ -34,7 +37,7 @@ class _Prof:
     def __exit__(self, *a):
         if self.on:
             self.e.record()
-            PROFILE.append((self.name, self.flops, self.s, self.e))
+            PROFILE.append((self.name, self.flops, self.s, self.e, self.shape))
 
 
 def gemm(a, w, bias=None, act=None, alpha=1.0, gate=None, gate_rows=0, residual=None, out=None,

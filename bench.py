@@ -161,7 +161,7 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel from the HIP events recorded around every GEMM launch
         per = {}
-        for name, flops, s, e in prof:
+        for name, flops, s, e, _shape in prof:
             a = per.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1; a[1] += flops; a[2] += s.elapsed_time(e) * 1e-3
         dom = max(per, key=lambda k: per[k][2])

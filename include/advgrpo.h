@@ -118,9 +118,10 @@ int advgrpo_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, vo
                       int64_t a_seg_stride, int64_t a_seg_off, int batch,
                       int64_t strideA, int64_t strideW, int64_t strideC, void* stream);
 
-/* Which kernel instance the GEMM dispatcher uses for a shape: tile 0 = 128x128, 1 = 128x64, 2 = 64x128,
- * 3 = 256x256, 6 = 256x128; with the implicit-conv loader 4, 5, 7, 8.  (Per-kernel accounting in bench.py.) */
-int advgrpo_gemm_variant(int M, int N, int batch, int conv);
+/* Which kernel instance the GEMM dispatcher uses for a shape: tile 0 = 128x128 (BK 64, 2 stages), 1 = 128x64,
+ * 2 = 64x128, 3 = 256x256, 6 = 256x128; with the implicit-conv loader 4, 5, 7, 8; 9..13 = deep-pipelined BK 32
+ * variants (13 = 128x128, 3 stages, 8 waves).  (Per-kernel accounting in bench.py.) */
+int advgrpo_gemm_variant(int M, int N, int K, int batch, int conv);
 
 /* ------------------------------------------------------------------ row kernels (HBM bound)
  * layernorm_mod: out = (LN(x) [*w + b]) * (1 + scale[m / rows_per_batch]) + shift[...]; optional second

@@ -1,6 +1,6 @@
 """GEMM micro-benchmark per tile variant (ADVGRPO_GEMM_FORCE=<id> python scripts/bench_gemm.py)."""
 import os, sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adv_grpo_amd import ops
 def bench(M,N,K,iters=20, epi=False):
     a=torch.randn(M,K,device='cuda').to(torch.bfloat16); w=torch.randn(N,K,device='cuda').to(torch.bfloat16)

@@ -1,6 +1,6 @@
 """Timing of one G-step micro-batch (CFG batch 16, SD3.5-medium, 512^2) and of the optimizer step."""
 import sys, time, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adv_grpo_amd import synthetic, g_step
 from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
 from adv_grpo_amd.model_configs import MMDiTConfig

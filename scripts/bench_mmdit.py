@@ -1,5 +1,5 @@
 import sys, torch, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adv_grpo_amd import synthetic
 from adv_grpo_amd.mmdit import SD3Transformer2DModel
 from oracle.mmdit import MMDiTConfig   # config dataclass only
