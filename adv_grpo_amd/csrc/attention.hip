@@ -19,6 +19,8 @@
 //     tile's MFMAs and written to the other LDS buffer afterwards (one barrier per tile).
 //   * O is kept transposed in the accumulators (lane = one query, 4 consecutive d): the online
 //     softmax rescale is a per-lane scalar and the epilogue is an 8-byte bf16x4 store per lane.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "gemm.hpp"
 
@@ -249,6 +251,194 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Head dim 64, LDS-DMA variant: K/V tiles go HBM -> LDS with global_load_lds_dwordx4 into a 3-slot ring and stay
+// in flight across the workgroup barrier (counted s_waitcnt vmcnt + raw s_barrier), so a tile is requested two
+// iterations before it is consumed and no VGPRs are spent on staging.  The padded pitch of the register-staged
+// kernel is impossible with DMA (lane-linear 1 KiB destinations), so bank conflicts are removed by swizzling the
+// per-lane SOURCE chunk and un-swizzling on the read:
+//   K (ds_read_b128 fragments): 16-byte chunk c of row r sits at slot c ^ (r & 7)       (as in gemm.hip)
+//   V (ds_read_b64_tr_b16):     32-byte segment s of row r sits at slot s ^ ((r >> 1) & 3): the 8 rows a 32-lane
+//                               service group touches land on 8 disjoint 8-bank ranges.
+typedef __attribute__((address_space(3))) void* att_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* att_gptr_t;
+
+__global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnParams p) {
+    constexpr int HD = 64, NS = 3, TILE_B = ATT_KB * 128;   // 8 KiB per K or V tile
+    constexpr int LOADS = 4;                                 // DMA instructions per wave per tile (2 K + 2 V)
+    __shared__ __attribute__((aligned(16))) char smem[NS * 2 * TILE_B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, t = lane & 15;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * ATT_QB + wave * 32;
+    const bf16_t* qp = p.q + (int64_t)b * p.bsq + h * HD;
+    const bf16_t* kp = p.k + (int64_t)b * p.bsk + h * HD;
+    const bf16_t* vp = p.v + (int64_t)b * p.bsv + h * HD;
+
+    bf16x8_t qf[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        int qr = q0 + qb * 16 + t;
+        qr = qr < p.Sq ? qr : p.Sq - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[qb][ks] = *reinterpret_cast<const bf16x8_t*>(qp + (int64_t)qr * p.ldq + ks * 32 + g * 8);
+    }
+    // DMA: instruction j (0..7) of a tile covers rows 8j..8j+7; this wave issues j = wave and wave + 4
+    const int lrow = lane >> 3, pch = lane & 7;
+    const int k_src_chunk = pch ^ lrow;                                   // K: chunk ^ (row & 7)
+    auto stage = [&](int slot, int kv0) __attribute__((always_inline)) {
+        char* base = smem + slot * 2 * TILE_B;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = wave + i * 4;
+            const int rl = j * 8 + lrow;                                 // row inside the tile
+            int r = kv0 + rl;
+            r = r < p.Skv ? r : p.Skv - 1;
+            const int v_src_chunk = ((((pch >> 1) ^ ((rl >> 1) & 3)) << 1) | (pch & 1));
+            __builtin_amdgcn_global_load_lds((att_gptr_t)(kp + (int64_t)r * p.ldk + k_src_chunk * 8),
+                                             (att_lds_ptr_t)(base + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((att_gptr_t)(vp + (int64_t)r * p.ldv + v_src_chunk * 8),
+                                             (att_lds_ptr_t)(base + TILE_B + j * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 o[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+    int kv_end = p.Skv;
+    if (p.causal) kv_end = min(kv_end, min(blockIdx.x * ATT_QB + ATT_QB, p.Sq));
+    const int nt = (kv_end + ATT_KB - 1) / ATT_KB;
+    // fragment read offsets (bytes)
+    int k_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) k_off[ks] = t * 128 + (((ks * 4 + g) ^ (t & 7)) << 4);
+    const int v_row = g * 4 + (t >> 2);                   // + (2*kpair[+1])*16
+    const int v_sw = (g * 2 + (t >> 3)) & 3;              // ((row >> 1) & 3) for that row (16 | row base)
+    const int v_base = v_row * 128 + (t & 3) * 8;
+
+    stage(0, 0);
+    if (nt > 1) stage(1, ATT_KB);
+    int slot = 0;
+    for (int it = 0; it < nt; ++it) {
+        const int kv0 = it * ATT_KB;
+        if (it + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int fill = slot == 0 ? NS - 1 : slot - 1;   // slot of tile it-1: free after this barrier
+        if (it + 2 < nt) stage(fill, kv0 + 2 * ATT_KB);
+        const char* Kt = smem + slot * 2 * TILE_B;
+        const char* Vt = Kt + TILE_B;
+        slot = slot == NS - 1 ? 0 : slot + 1;
+
+        f32x4 s[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t kf[4];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) kf[kb] = *reinterpret_cast<const bf16x8_t*>(Kt + kb * 2048 + k_off[ks]);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+                    s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb][ks], s[kb][qb], 0, 0, 0);
+        }
+        const bool edge = (kv0 + ATT_KB > p.Skv) || p.causal;
+        if (edge) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kv0 + kb * 16 + g * 4 + r;
+                        const int qi = q0 + qb * 16 + t;
+                        if (key >= p.Skv || (p.causal && key > qi)) s[kb][qb][r] = -INFINITY;
+                    }
+        }
+        bf16x8_t pf[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qb], mx * p.scale_log2e);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
+            m_run[qb] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[kb][qb][r] * p.scale_log2e - m_use);
+                    s[kb][qb][r] = e;
+                    psum += e;
+                }
+            l_run[qb] = l_run[qb] * alpha + psum;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) o[db][qb] *= alpha;
+#pragma unroll
+            for (int kpair = 0; kpair < 2; ++kpair) {
+                bf16x8_t f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f[r] = (__bf16)s[2 * kpair][qb][r];
+                    f[4 + r] = (__bf16)s[2 * kpair + 1][qb][r];
+                }
+                pf[qb][kpair] = f;
+            }
+        }
+#pragma unroll
+        for (int kpair = 0; kpair < 2; ++kpair) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const char* a0 = Vt + (2 * kpair) * 2048 + v_base + ((db ^ v_sw) << 5);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(a0 + 2048));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, both);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][kpair], o[db][qb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float l = l_run[qb];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        const int qi = q0 + qb * 16 + t;
+        if (qi >= p.Sq) continue;
+        if (p.lse && g == 0) p.lse[((int64_t)b * p.H + h) * p.Sq + qi] = m_run[qb] + __builtin_amdgcn_logf(l);
+        bf16_t* op = p.o + (int64_t)b * p.bso + (int64_t)qi * p.ldo + h * HD + g * 4;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const f32x4 v = o[db][qb] * inv;
+            uint2 pk;
+            pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(op + db * 16) = pk;
+        }
+    }
+}
+
 int attention_fwd(const AttnParams& p, int B, int head_dim, hipStream_t s) {
     ADVGRPO_CHECK(head_dim == 64 || head_dim == 80, "attention: head_dim %d not supported (64, 80)", head_dim);
     ADVGRPO_CHECK(p.q && p.k && p.v && p.o, "attention: null pointer");
@@ -256,7 +446,10 @@ int attention_fwd(const AttnParams& p, int B, int head_dim, hipStream_t s) {
     ADVGRPO_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0,
                   "attention: row pitches must keep 16-byte (q,k,v) / 8-byte (o) alignment");
     dim3 grid((p.Sq + ATT_QB - 1) / ATT_QB, p.H, B);
-    if (head_dim == 64) hipLaunchKernelGGL(attention_fwd_kernel<64>, grid, dim3(256), 0, s, p);
+    static int use_glds = -1;
+    if (use_glds < 0) { const char* e = getenv("ADVGRPO_ATTN_REGSTAGE"); use_glds = (e && atoi(e)) ? 0 : 1; }
+    if (head_dim == 64 && use_glds) hipLaunchKernelGGL(attention_fwd_glds_kernel, grid, dim3(256), 0, s, p);
+    else if (head_dim == 64) hipLaunchKernelGGL(attention_fwd_kernel<64>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attention_fwd_kernel<80>, grid, dim3(256), 0, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
