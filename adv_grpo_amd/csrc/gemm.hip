@@ -451,13 +451,14 @@ static int gemm_variant(int M, int N, int K, int batch, int conv, int plain) {  
     // measured on MI355X (scripts/bench_gemm.py, random data): the 4-wave 128x128 tile wins on the MMDiT / ViT
     // shapes (M = 16384 / 3280, N, K in {1536, 4608, 6144}); the 8-wave 256x256 tile only on large square problems.
     (void)rounds_eff;
-    if (conv) return 4;
+    if (conv) return 18;
     if (M >= 4096 && N >= 8192 && rounds_eff(256, 256, 256) > 0.85) return 3;
     if (M <= 64) return 2;
-    // short contractions (the K = 1536 Linears): the deep-pipelined 8-wave kernel (3 workgroups x 8 waves per CU)
-    // hides the per-iteration DMA / barrier latency better; long contractions amortise it and prefer BK = 64.
-    if (plain && K <= 3072) return 13;
-    return 0;
+    // measured (scripts/bench_gemm.py): 8 waves per workgroup (16 waves per CU) beat 4 on every MMDiT / ViT shape;
+    // wide outputs (QKV, FF1: N >= 4096 with M = 16384) prefer the deep-pipelined 256x128 ring kernel.
+    (void)K;
+    if (plain && M >= 8192 && N >= 4096) return 17;
+    return plain ? 15 : 0;
 }
 
 int gemm_bf16(const GemmParams& p, hipStream_t s) {
@@ -493,6 +494,11 @@ int gemm_bf16(const GemmParams& p, hipStream_t s) {
         case 11: return launch_pipe<128, 128, 3, 4, 2>(p, s);
         case 12: return launch_pipe<128, 128, 4, 4, 2>(p, s);
         case 13: return launch_pipe<128, 128, 3, 2, 4>(p, s);
+        case 14: return launch<128, 128, 2, 4, false>(p, s);
+        case 18: return launch<128, 128, 4, 2, true>(p, s);
+        case 15: return launch<128, 128, 4, 2, false>(p, s);
+        case 16: return launch_pipe<128, 256, 3, 2, 4>(p, s);
+        case 17: return launch_pipe<256, 128, 3, 4, 2>(p, s);
     }
     set_error("gemm: bad variant %d", variant);
     return -1;
