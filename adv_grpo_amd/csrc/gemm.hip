@@ -72,10 +72,125 @@ __device__ inline int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Grouped tile order inside an XCD's contiguous id range: ids walk down group_m (4, measured best of 1..16) row-tiles before moving to the next
+// column-tile, so the ~32-64 tiles an XCD runs at once form a near-square patch of C and share their A / W panels
+// in that XCD's 4 MB L2 (a row-major order gives a 1 x 48 strip for the wide QKV / FF1 outputs: every W panel of
+// the layer streams through every XCD for each row of tiles).
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+    const int per_group = group_m * tiles_n;
+    const int g = id / per_group, r = id - g * per_group;
+    const int first_m = g * group_m;
+    const int gsz = min(tiles_m - first_m, group_m);
+    tn = r / gsz;
+    tm = first_m + (r - tn * gsz);
+}
+
 // ---- fused epilogue shared by the kernel variants
+// Row-coalesced path.  In the MFMA accumulator layout a lane owns 4 consecutive columns of ONE row and the 16
+// lanes of a quarter-wave own 16 DIFFERENT rows, so storing straight from the accumulators issues 64 separate
+// 8-byte writes per instruction (measured: 0.8 TB/s for the whole epilogue).  Instead each wave bounces one
+// 16-row slab of its tile at a time through a private LDS scratch (f32, rows padded by 16 B) and comes back with
+// 8 consecutive columns per lane and TN/8 consecutive lanes per row: every bias / gate / residual / aux read and
+// every output store is a 16-byte access and a row's lanes cover whole 128-byte lines.
+// The arithmetic and its order are the same as in the fragment-layout path below (bit-identical results).
 template <int FM, int FN, int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[FM][FN], int m0, int n0, int wm, int wn,
-                                              int bz, int lane) {
+__device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4 (&acc)[FM][FN], int m0, int n0, int wm,
+                                                   int wn, int bz, int lane, char* scratch) {
+    constexpr int RS = TN * 4 + 16;            // scratch row stride in bytes
+    constexpr int LPR = TN / 8;                // lanes per row on the way out
+    constexpr int RPP = 64 / LPR;              // rows per pass
+    constexpr int PASSES = 16 / RPP;
+    static_assert(PASSES >= 1 && LPR >= 1, "wave tile too wide for the row epilogue");
+    const int mrow = lane & 15, ncol = (lane >> 4) * 4;
+    const int orow_l = lane / LPR, c8 = (lane % LPR) * 8;
+    auto unpack8 = [](const uint4& q, float (&f)[8]) __attribute__((always_inline)) {
+        f[0] = bf2f((bf16_t)(q.x & 0xffffu)); f[1] = bf2f((bf16_t)(q.x >> 16));
+        f[2] = bf2f((bf16_t)(q.y & 0xffffu)); f[3] = bf2f((bf16_t)(q.y >> 16));
+        f[4] = bf2f((bf16_t)(q.z & 0xffffu)); f[5] = bf2f((bf16_t)(q.z >> 16));
+        f[6] = bf2f((bf16_t)(q.w & 0xffffu)); f[7] = bf2f((bf16_t)(q.w >> 16));
+    };
+    auto pack8 = [](const float (&v)[8]) __attribute__((always_inline)) {
+        uint4 pk;
+        pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        pk.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+        pk.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        return pk;
+    };
+    const int n = n0 + wn * TN + c8;
+    float bias8[8];
+    if (p.bias && n < p.N) unpack8(*reinterpret_cast<const uint4*>(p.bias + n), bias8);
+    static_for<FM>([&](auto idx) {
+        constexpr int i = decltype(idx)::value;
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+            *reinterpret_cast<f32x4*>(scratch + mrow * RS + (j * 16 + ncol) * 4) = acc[i][j];
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int row = ps * RPP + orow_l;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(scratch + row * RS + c8 * 4);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(scratch + row * RS + c8 * 4 + 16);
+            const int m = m0 + wm * TM + i * 16 + row;
+            if (m >= p.M || n >= p.N) continue;
+            int64_t orow = m;
+            if (p.seg_rows > 0) {
+                const int bidx = m / p.seg_rows;
+                orow = (int64_t)bidx * p.seg_stride + p.seg_off + (m - bidx * p.seg_rows);
+            }
+            float v[8] = {lo[0] * p.alpha, lo[1] * p.alpha, lo[2] * p.alpha, lo[3] * p.alpha,
+                          hi[0] * p.alpha, hi[1] * p.alpha, hi[2] * p.alpha, hi[3] * p.alpha};
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+            }
+            if (p.aux_out)
+                *reinterpret_cast<uint4*>(p.aux_out + (int64_t)bz * p.strideC + orow * p.ld_aux + n) = pack8(v);
+            if (p.act >= ACT_DGELU_TANH) {
+                float z[8];
+                unpack8(*reinterpret_cast<const uint4*>(p.aux_in + (int64_t)bz * p.strideC + orow * p.ld_aux + n), z);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= dact_fn(z[e], p.act);
+            } else if (p.act != ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = act_fn(v[e], p.act);
+            }
+            if (p.gate) {
+                const int gb = p.gate_rows > 0 ? m / p.gate_rows : 0;
+                float g[8];
+                unpack8(*reinterpret_cast<const uint4*>(p.gate + (int64_t)bz * p.gate_batch_stride +
+                                                        (int64_t)gb * p.gate_stride + n), g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= g[e];
+            }
+            if (p.residual) {
+                float r[8];
+                unpack8(*reinterpret_cast<const uint4*>(p.residual + (int64_t)bz * p.strideR + orow * p.ldr + n), r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+            }
+            const int64_t o = (int64_t)bz * p.strideC + orow * p.ldc + n;
+            if (p.out_dtype == ADVGRPO_BF16) {
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + o) = pack8(v);
+            } else {
+                float* c = reinterpret_cast<float*>(p.C) + o;
+                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        }
+    });
+}
+
+// true when every operand of the epilogue can be accessed as aligned 16-byte row segments
+__device__ __forceinline__ bool epilogue_rows_ok(const GemmParams& p) {
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    return p.splitk == 1 && (p.N & 7) == 0 && ((p.ldc | p.ldr | p.gate_stride | p.ld_aux | p.strideC | p.strideR |
+                                                p.gate_batch_stride) & 7) == 0 &&
+           a16(p.C) && a16(p.bias) && a16(p.gate) && a16(p.residual) && a16(p.aux_out) && a16(p.aux_in);
+}
+
+template <int FM, int FN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_frag(const GemmParams& p, f32x4 (&acc)[FM][FN], int m0, int n0, int wm,
+                                                   int wn, int bz, int lane) {
     // lane holds C[m][n..n+3], m = frag row (lane&15), n = (lane>>4)*4.
     // Full, 8-byte-aligned quads take the vector path (bf16x4 loads of bias / gate / residual, one bf16x4 or
     // float4 store); the ragged N edge falls back to predicated scalars.  Fragments are visited with
@@ -158,6 +273,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     });
 }
 
+// all waves of the workgroup must be past their last main-loop LDS read when this is called (it syncs itself)
+template <int FM, int FN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[FM][FN], int m0, int n0, int wm, int wn,
+                                              int bz, int lane, char* smem, int wave) {
+    if (epilogue_rows_ok(p) && !(p.debug & 16)) {
+        __syncthreads();
+        gemm_epilogue_rows<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane, smem + wave * (16 * (TN * 4 + 16)));
+    } else {
+        gemm_epilogue_frag<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane);
+    }
+}
+
 template <int BM, int BN, int WM, int WN, bool CONV>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParams p) {
     constexpr int BK = 64;
@@ -177,7 +304,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int nwg = tiles_m * tiles_n;
     const int swz = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = swz / tiles_n, tile_n = swz % tiles_n;
+    int tile_m, tile_n;
+    tile_coords(swz, tiles_m, tiles_n, (p.debug >> 8) ? (p.debug >> 8) : 4, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int bz = blockIdx.y / p.splitk, sk = blockIdx.y % p.splitk;
 
@@ -288,7 +416,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
         __syncthreads();
     }
 
-    gemm_epilogue<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane);
+    gemm_epilogue<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane, smem, wave);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -314,7 +442,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_pipe_kernel(const Gemm
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int swz = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (swz / tiles_n) * BM, n0 = (swz % tiles_n) * BN;
+    int tile_m, tile_n;
+    tile_coords(swz, tiles_m, tiles_n, (p.debug >> 8) ? (p.debug >> 8) : 4, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int bz = blockIdx.y;
     const bf16_t* __restrict__ A = p.A + (int64_t)bz * p.strideA;
     const bf16_t* __restrict__ W = p.W + (int64_t)bz * p.strideW;
@@ -392,7 +522,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_pipe_kernel(const Gemm
             for (int j = 0; j < FN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
-    gemm_epilogue<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane);
+    gemm_epilogue<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane, smem, wave);
 }
 
 template <int BM, int BN, int NS, int WM, int WN>
@@ -406,6 +536,144 @@ static int launch_pipe(const GemmParams& p, hipStream_t s) {
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, NS, WM, WN>), dim3(tiles, p.batch), dim3(WM * WN * 64), lds, s, p);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Ping-pong variant: 8 waves in two groups of four that run half a phase apart, so that while one group is in its
+// MFMA segment the other is in its LDS-read + DMA-issue segment (one wave of each group per SIMD: the matrix pipe
+// and the LDS/VMEM paths are busy at the same time instead of taking turns behind a common barrier).
+//   * BK = 32 tiles in a 4-slot LDS ring; the DMA for tile t+2 is issued in the load segment of tile t and waited
+//     for (counted s_waitcnt vmcnt) in the segment just before the barrier that precedes its first read, so a
+//     tile has two full compute segments to arrive and every LDS hazard (read-after-DMA, DMA-after-read) is
+//     separated by at least one workgroup barrier -- no placement or timing assumption.
+//   * segment structure per tile and wave:  [ds_read fragments of tile t, issue DMA of tile t+2] s_barrier
+//     [s_waitcnt lgkmcnt(0); MFMAs] s_barrier ; group 1 executes one extra barrier up front (stagger) and group 0
+//     one extra at the end, so both groups arrive at every barrier.
+template <int BM, int BN, int NS, int WM, int WN>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
+    constexpr int BK = 32, NW = 8;
+    static_assert(NS == 3 || NS == 4, "ring depth");
+    static_assert(WM * WN == NW, "eight waves");
+    constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INST = BM / 16 / NW, B_INST = BN / 16 / NW;
+    constexpr int LOADS = A_INST + B_INST;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                       // waves w and w+4 share a SIMD: one of each group per SIMD
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int swz = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tile_m, tile_n;
+    tile_coords(swz, tiles_m, tiles_n, (p.debug >> 8) ? (p.debug >> 8) : 4, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int bz = blockIdx.y;
+    const bf16_t* __restrict__ A = p.A + (int64_t)bz * p.strideA;
+    const bf16_t* __restrict__ W = p.W + (int64_t)bz * p.strideW;
+    const int lrow = lane >> 2;
+    const int schunk = (lane & 3) ^ ((0 - (lrow >> 2)) & 3);
+    const bf16_t* a_src[A_INST];
+    const bf16_t* b_src[B_INST];
+#pragma unroll
+    for (int it = 0; it < A_INST; ++it) {
+        int r = m0 + (wave + it * NW) * 16 + lrow;
+        r = r < p.M ? r : p.M - 1;
+        int64_t ar = r;
+        if (p.a_seg_rows > 0) {
+            const int bi = r / p.a_seg_rows;
+            ar = (int64_t)bi * p.a_seg_stride + p.a_seg_off + (r - bi * p.a_seg_rows);
+        }
+        a_src[it] = A + ar * p.lda + schunk * 8;
+    }
+#pragma unroll
+    for (int it = 0; it < B_INST; ++it) {
+        int r = n0 + (wave + it * NW) * 16 + lrow;
+        r = r < p.N ? r : p.N - 1;
+        b_src[it] = W + (int64_t)r * p.ldw + schunk * 8;
+    }
+    auto stage = [&](int slot, int kt) __attribute__((always_inline)) {
+        char* base = smem + slot * STAGE;
+#pragma unroll
+        for (int it = 0; it < A_INST; ++it)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[it] + kt * BK), (lds_ptr_t)(base + (wave + it * NW) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int it = 0; it < B_INST; ++it)
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[it] + kt * BK),
+                                             (lds_ptr_t)(base + A_BYTES + (wave + it * NW) * 1024), 16, 0, 0);
+    };
+    const int frow = lane & 15;
+    const int frag_off = frow * 64 + ((((lane >> 4)) ^ ((0 - (frow >> 2)) & 3)) << 4);
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.debug & 8) ? 2 : p.K / BK;
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                     // tile 0 is complete for everybody
+    if (grp == 1) __builtin_amdgcn_s_barrier();       // stagger: group 1 runs one segment behind
+    int slot = 0, slot2 = 2;                          // ring slots of tile kt and tile kt+2
+    for (int kt = 0; kt < nk; ++kt) {
+        // ---- load segment: fragments of tile kt, DMA of tile kt+2
+        const char* ta = smem + slot * STAGE + wm * TM * 64;
+        const char* tb = smem + slot * STAGE + A_BYTES + wn * TN * 64;
+        bf16x8_t af[FM], bf[FN];
+        if (!(p.debug & 2) || kt == 0) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(ta + i * 1024 + frag_off);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(tb + j * 1024 + frag_off);
+        }
+        if (kt + 2 < nk && !(p.debug & 1)) stage(slot2, kt + 2);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        slot2 = slot2 + 1 == NS ? 0 : slot2 + 1;
+        if (grp == 1) {   // tile kt+1 is first read right after the next barrier (by group 0)
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // with a 3-slot ring group 0 refills the slot of tile kt (= slot of tile kt+3) right after the next
+            // barrier: this group's fragment reads of it must have completed, not just been issued
+            if (NS == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- compute segment
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) {
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();       // matches group 1's stagger barrier
+    if (p.debug & 4) { if (acc[0][0][0] != 12345.678f) return; }
+    gemm_epilogue<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane, smem, wave);
+}
+
+template <int BM, int BN, int NS, int WM, int WN>
+static int launch_pp(const GemmParams& p, hipStream_t s) {
+    constexpr int lds = NS * (BM + BN) * 32 * 2;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<BM, BN, NS, WM, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, NS, WM, WN>), dim3(tiles, p.batch), dim3(512), lds, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
@@ -461,7 +729,13 @@ static int gemm_variant(int M, int N, int K, int batch, int conv, int plain) {  
     return plain ? 15 : 0;
 }
 
-int gemm_bf16(const GemmParams& p, hipStream_t s) {
+int gemm_bf16(const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    {
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("ADVGRPO_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
+        p.debug = dbg;
+    }
     ADVGRPO_CHECK(p.A && p.W && p.C, "gemm: null operand");
     ADVGRPO_CHECK(p.M > 0 && p.N > 0 && p.K > 0 && p.K % 64 == 0, "gemm: need M,N>0 and K %% 64 == 0 (M=%d N=%d K=%d)",
                   p.M, p.N, p.K);
@@ -496,6 +770,12 @@ int gemm_bf16(const GemmParams& p, hipStream_t s) {
         case 13: return launch_pipe<128, 128, 3, 2, 4>(p, s);
         case 14: return launch<128, 128, 2, 4, false>(p, s);
         case 18: return launch<128, 128, 4, 2, true>(p, s);
+        case 20: return launch_pp<256, 256, 4, 2, 4>(p, s);
+        case 21: return launch_pp<256, 128, 4, 4, 2>(p, s);
+        case 22: return launch_pp<128, 128, 4, 2, 4>(p, s);
+        case 23: return launch_pp<256, 128, 3, 4, 2>(p, s);
+        case 24: return launch_pp<128, 128, 3, 2, 4>(p, s);
+        case 25: return launch_pp<128, 128, 3, 4, 2>(p, s);
         case 15: return launch<128, 128, 4, 2, false>(p, s);
         case 16: return launch_pipe<128, 256, 3, 2, 4>(p, s);
         case 17: return launch_pipe<256, 128, 3, 4, 2>(p, s);

@@ -29,6 +29,7 @@ struct GemmParams {
     // training extras: aux_out[orow, n] = pre-activation (bf16, pitch ldc); aux_in[orow, n] feeds the d-activation
     // epilogues; splitk > 1: the K range is split over grid.y and partial tiles are atomically added into f32 C
     bf16_t* aux_out; const bf16_t* aux_in; int64_t ld_aux; int splitk;
+    int debug;   // experiments only (ADVGRPO_GEMM_DEBUG): bit0 = skip steady-state DMA, bit1 = skip LDS fragment reads
 };
 
 int gemm_bf16(const GemmParams& p, hipStream_t stream);

@@ -15,7 +15,10 @@ GEMM_VARIANTS = {0: "gemm_bf16_kernel<128,128,2,2,false>", 1: "gemm_bf16_kernel<
                  11: "gemm_bf16_pipe_kernel<128,128,3,4,2>", 12: "gemm_bf16_pipe_kernel<128,128,4,4,2>",
                  13: "gemm_bf16_pipe_kernel<128,128,3,2,4>", 14: "gemm_bf16_kernel<128,128,2,4,false>",
                  15: "gemm_bf16_kernel<128,128,4,2,false>", 16: "gemm_bf16_pipe_kernel<128,256,3,2,4>",
-                 17: "gemm_bf16_pipe_kernel<256,128,3,4,2>", 18: "gemm_bf16_kernel<128,128,4,2,true>"}
+                 17: "gemm_bf16_pipe_kernel<256,128,3,4,2>", 18: "gemm_bf16_kernel<128,128,4,2,true>",
+                 20: "gemm_bf16_pp_kernel<256,256,4,2,4>", 21: "gemm_bf16_pp_kernel<256,128,4,4,2>",
+                 22: "gemm_bf16_pp_kernel<128,128,4,2,4>", 23: "gemm_bf16_pp_kernel<256,128,3,4,2>",
+                 24: "gemm_bf16_pp_kernel<128,128,3,2,4>", 25: "gemm_bf16_pp_kernel<128,128,3,4,2>"}
 # bench.py sets this to a list to collect (kernel name, flops, start event, end event) per GEMM launch;
 # events are recorded on the stream the kernel is launched on (torch's current stream).
 PROFILE = None

@@ -155,11 +155,18 @@ def test_g_step_chain_log_prob_loss_backward_adamw():
     osample = {k: v for k, v in sample.items()}
     _, lp_ref, _, _ = o_roll.compute_log_prob(tr, osch, osample, 0, embeds.cuda(), pooled.cuda(), guidance_scale=4.5,
                                               noise_level=0.8)
-    old = (lp_ref.detach() + 2e-5 * torch.randn(G, generator=g).cuda())
-    loss_ref, _ = o_loss.grpo_loss(lp_ref, old, adv.cuda(), 5, 1e-4)
+    # The clip window (1e-4) is far narrower than the bf16-vs-fp32 difference of the two log-probs, so each side gets
+    # its "old" log-prob from its own forward plus the SAME perturbation: the ratios, and with them which samples
+    # are clipped, then agree and the gradients are comparable.
+    delta = 2e-5 * torch.randn(G, generator=g).cuda()
+    loss_ref, _ = o_loss.grpo_loss(lp_ref, lp_ref.detach() + delta, adv.cuda(), 5, 1e-4)
     loss_ref.backward()
-    info = g_step.micro_step(model, sch, sample, 0, embeds.cuda(), pooled.cuda(), old, adv.cuda(), guidance_scale=4.5,
-                             noise_level=0.8, adv_clip_max=5, clip_range=1e-4)
+    probe = g_step.micro_step(model, sch, sample, 0, embeds.cuda(), pooled.cuda(), lp_ref.detach(), adv.cuda(),
+                              guidance_scale=4.5, noise_level=0.8, adv_clip_max=5, clip_range=1e-4)
+    model.grads.zero_()
+    info = g_step.micro_step(model, sch, sample, 0, embeds.cuda(), pooled.cuda(), probe["log_prob"] + delta, adv.cuda(),
+                             guidance_scale=4.5, noise_level=0.8, adv_clip_max=5, clip_range=1e-4)
+    assert torch.equal(info["log_prob"], probe["log_prob"])                   # deterministic forward
     # log-prob is a mean of 4096 squared differences of O(1): bf16 transformer vs fp32 oracle
     assert torch.allclose(info["log_prob"], lp_ref.detach(), rtol=3e-2)
     grads = model.lora_grads()
