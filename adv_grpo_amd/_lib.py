@@ -17,6 +17,22 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libadvgrpo_hip.so")
 
 _P = c_void_p
+
+
+class GemmDesc(ctypes.Structure):
+    """advgrpo_gemm_desc (include/advgrpo.h), field for field."""
+    _fields_ = [("A", _P), ("W", _P), ("C", _P), ("lda", c_int64), ("ldw", c_int64), ("ldc", c_int64),
+                ("out_dtype", c_int32), ("M", c_int32), ("N", c_int32), ("K", c_int32),
+                ("bias", _P), ("act", c_int32), ("alpha", c_float),
+                ("gate", _P), ("gate_stride", c_int64), ("gate_rows", c_int32),
+                ("residual", _P), ("ldr", c_int64),
+                ("seg_rows", c_int32), ("seg_stride", c_int64), ("seg_off", c_int64),
+                ("a_seg_rows", c_int32), ("a_seg_stride", c_int64), ("a_seg_off", c_int64),
+                ("aux_out", _P), ("aux_in", _P), ("ld_aux", c_int64),
+                ("rms_weight", _P), ("rms_nheads", c_int32), ("rms_heads_per_weight", c_int32), ("rms_eps", c_float),
+                ("rms_rs_out", _P)]
+
+
 # name -> (restype, argtypes); must list every function include/advgrpo.h declares
 SIGNATURES = {
     "advgrpo_abi_version": (c_int, []),
@@ -33,6 +49,7 @@ SIGNATURES = {
                                   c_float, _P, c_int64, c_int, _P, c_int64, c_int, c_int64, c_int64, c_int, c_int64,
                                   c_int64, c_int, c_int64, c_int64, c_int64, _P]),
     "advgrpo_gemm_variant": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "advgrpo_gemm_grouped": (c_int, [POINTER(GemmDesc), c_int, _P]),
     "advgrpo_layernorm_mod": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int,
                                       c_int, c_float, _P]),
     "advgrpo_rmsnorm_heads": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int, c_float, c_int, c_int64, c_int64,

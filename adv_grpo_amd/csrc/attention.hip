@@ -260,6 +260,19 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
 //   K (ds_read_b128 fragments): 16-byte chunk c of row r sits at slot c ^ (r & 7)       (as in gemm.hip)
 //   V (ds_read_b64_tr_b16):     32-byte segment s of row r sits at slot s ^ ((r >> 1) & 3): the 8 rows a 32-lane
 //                               service group touches land on 8 disjoint 8-bank ranges.
+// xor-16 / xor-32 lane exchanges on the VALU (gfx950 v_permlane{16,32}_swap) instead of ds_bpermute: the softmax
+// row maximum no longer takes two LDS round trips per tile, nor shares lgkmcnt with the V fragment reads.
+// v_permlane32_swap d, s: d[32..63] <-> s[0..31]; with d = s = v the pair (d, s) afterwards holds, in every lane,
+// the lane's value and its xor-32 partner's (16: odd 16-lane rows of d <-> even rows of s).
+// (inline asm with two read-write operands: given the same value twice the builtin form is folded onto ONE
+// register and returns the swap of a register with itself -- checked with scripts/probes/permlane_probe.hip)
+#define ADVGRPO_SWAP16(a, b) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b))
+#define ADVGRPO_SWAP32(a, b) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b))
+__device__ __forceinline__ float xor16_max(float v) { float a = v, b = v; ADVGRPO_SWAP16(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xor32_max(float v) { float a = v, b = v; ADVGRPO_SWAP32(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xor16_add(float v) { float a = v, b = v; ADVGRPO_SWAP16(a, b); return a + b; }
+__device__ __forceinline__ float xor32_add(float v) { float a = v, b = v; ADVGRPO_SWAP32(a, b); return a + b; }
+
 typedef __attribute__((address_space(3))) void* att_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* att_gptr_t;
 
@@ -288,19 +301,39 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnPa
     // DMA: instruction j (0..7) of a tile covers rows 8j..8j+7; this wave issues j = wave and wave + 4
     const int lrow = lane >> 3, pch = lane & 7;
     const int k_src_chunk = pch ^ lrow;                                   // K: chunk ^ (row & 7)
-    auto stage = [&](int slot, int kv0) __attribute__((always_inline)) {
+    // per-lane source pointers of tile 0 (rows clamped to the sequence); interior tiles advance them by a uniform
+    // stride, only a ragged last tile recomputes the clamped rows (64-bit integer multiplies are quarter rate)
+    const bf16_t* k_src[2];
+    const bf16_t* v_src[2];
+    int v_chunk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rl = (wave + i * 4) * 8 + lrow;
+        v_chunk[i] = ((((pch >> 1) ^ ((rl >> 1) & 3)) << 1) | (pch & 1)) * 8;
+        const int r = rl < p.Skv ? rl : p.Skv - 1;
+        k_src[i] = kp + (int64_t)r * p.ldk + k_src_chunk * 8;
+        v_src[i] = vp + (int64_t)r * p.ldv + v_chunk[i];
+    }
+    const int64_t k_step = (int64_t)ATT_KB * p.ldk, v_step = (int64_t)ATT_KB * p.ldv;
+    auto stage = [&](int slot, int kv0) __attribute__((always_inline)) {   // called with kv0 = 0, KB, 2 KB, ... in order
         char* base = smem + slot * 2 * TILE_B;
+        const bool ragged = kv0 + ATT_KB > p.Skv;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int j = wave + i * 4;
-            const int rl = j * 8 + lrow;                                 // row inside the tile
-            int r = kv0 + rl;
-            r = r < p.Skv ? r : p.Skv - 1;
-            const int v_src_chunk = ((((pch >> 1) ^ ((rl >> 1) & 3)) << 1) | (pch & 1));
-            __builtin_amdgcn_global_load_lds((att_gptr_t)(kp + (int64_t)r * p.ldk + k_src_chunk * 8),
-                                             (att_lds_ptr_t)(base + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((att_gptr_t)(vp + (int64_t)r * p.ldv + v_src_chunk * 8),
-                                             (att_lds_ptr_t)(base + TILE_B + j * 1024), 16, 0, 0);
+            const bf16_t* ks = k_src[i];
+            const bf16_t* vs = v_src[i];
+            if (ragged) {
+                asm volatile("; ragged tile" ::: "memory");
+                int r = kv0 + j * 8 + lrow;
+                r = r < p.Skv ? r : p.Skv - 1;
+                ks = kp + (int64_t)r * p.ldk + k_src_chunk * 8;
+                vs = vp + (int64_t)r * p.ldv + v_chunk[i];
+            }
+            __builtin_amdgcn_global_load_lds((att_gptr_t)ks, (att_lds_ptr_t)(base + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((att_gptr_t)vs, (att_lds_ptr_t)(base + TILE_B + j * 1024), 16, 0, 0);
+            k_src[i] += k_step;
+            v_src[i] += v_step;
         }
     };
     f32x4 o[4][2];
@@ -352,7 +385,8 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnPa
                     s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb][ks], s[kb][qb], 0, 0, 0);
         }
         const bool edge = (kv0 + ATT_KB > p.Skv) || p.causal;
-        if (edge) {
+        if (edge) {   // ragged last tile / causal only: a real (wave-uniform) branch, interior tiles pay nothing
+            asm volatile("; masked tile" ::: "memory");
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -372,24 +406,33 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnPa
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xor32_max(xor16_max(mx));
             const float m_new = fmaxf(m_run[qb], mx * p.scale_log2e);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
             m_run[qb] = m_new;
-            float psum = 0.f;
+            // exp2(s * scale - m) two scores per v_pk_fma_f32; row sums on v_pk_add_f32
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {-m_use, -m_use};
+            f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(s[kb][qb][r] * p.scale_log2e - m_use);
-                    s[kb][qb][r] = e;
-                    psum += e;
+                for (int r = 0; r < 4; r += 2) {
+                    f32x2 a = {s[kb][qb][r], s[kb][qb][r + 1]};
+                    a = __builtin_elementwise_fma(a, sc2, nm2);
+                    a[0] = __builtin_amdgcn_exp2f(a[0]);
+                    a[1] = __builtin_amdgcn_exp2f(a[1]);
+                    s[kb][qb][r] = a[0];
+                    s[kb][qb][r + 1] = a[1];
+                    ps2 += a;
                 }
-            l_run[qb] = l_run[qb] * alpha + psum;
+            l_run[qb] = l_run[qb] * alpha + (ps2[0] + ps2[1]);
+            // the running maximum settles after the first few tiles: skip the rescale of O when no lane's moved
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-            for (int db = 0; db < 4; ++db) o[db][qb] *= alpha;
+                for (int db = 0; db < 4; ++db) o[db][qb] *= alpha;
+            }
 #pragma unroll
             for (int kpair = 0; kpair < 2; ++kpair) {
                 bf16x8_t f;
@@ -418,24 +461,34 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnPa
             }
         }
     }
+    // Output: in the accumulator layout a lane owns 4 dims of one row and a quarter-wave spans 16 rows, i.e. 64
+    // scattered 8-byte stores per instruction.  Each wave bounces its 32 x 64 bf16 tile through LDS (the ring slot
+    // of tile nt-2: every wave passed the last barrier, so nobody reads it and no DMA targets it any more) and
+    // stores whole 128-byte rows, 16 bytes per lane.
+    char* ob = smem + (slot == 0 ? NS - 2 : (slot == 1 ? NS - 1 : slot - 2)) * 2 * TILE_B + wave * 4096;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         float l = l_run[qb];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = xor32_add(xor16_add(l));
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         const int qi = q0 + qb * 16 + t;
-        if (qi >= p.Sq) continue;
-        if (p.lse && g == 0) p.lse[((int64_t)b * p.H + h) * p.Sq + qi] = m_run[qb] + __builtin_amdgcn_logf(l);
-        bf16_t* op = p.o + (int64_t)b * p.bso + (int64_t)qi * p.ldo + h * HD + g * 4;
+        if (p.lse && g == 0 && qi < p.Sq) p.lse[((int64_t)b * p.H + h) * p.Sq + qi] = m_run[qb] + __builtin_amdgcn_logf(l);
+        const int r = qb * 16 + t;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
             const f32x4 v = o[db][qb] * inv;
             uint2 pk;
             pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
             pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-            *reinterpret_cast<uint2*>(op + db * 16) = pk;
+            *reinterpret_cast<uint2*>(ob + r * 128 + (((db * 2 + (g >> 1)) ^ (r & 7)) << 4) + (g & 1) * 8) = pk;
         }
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int r = ps * 8 + (lane >> 3), c = lane & 7;
+        const uint4 q = *reinterpret_cast<const uint4*>(ob + r * 128 + ((c ^ (r & 7)) << 4));
+        const int qi = q0 + r;
+        if (qi < p.Sq) *reinterpret_cast<uint4*>(p.o + (int64_t)b * p.bso + (int64_t)qi * p.ldo + h * HD + c * 8) = q;
     }
 }
 
@@ -448,7 +501,8 @@ int attention_fwd(const AttnParams& p, int B, int head_dim, hipStream_t s) {
     dim3 grid((p.Sq + ATT_QB - 1) / ATT_QB, p.H, B);
     static int use_glds = -1;
     if (use_glds < 0) { const char* e = getenv("ADVGRPO_ATTN_REGSTAGE"); use_glds = (e && atoi(e)) ? 0 : 1; }
-    if (head_dim == 64 && use_glds) hipLaunchKernelGGL(attention_fwd_glds_kernel, grid, dim3(256), 0, s, p);
+    const bool o16 = p.ldo % 8 == 0 && p.bso % 8 == 0 && (reinterpret_cast<uintptr_t>(p.o) & 15) == 0;   // 16-byte row stores
+    if (head_dim == 64 && use_glds && o16) hipLaunchKernelGGL(attention_fwd_glds_kernel, grid, dim3(256), 0, s, p);
     else if (head_dim == 64) hipLaunchKernelGGL(attention_fwd_kernel<64>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attention_fwd_kernel<80>, grid, dim3(256), 0, s, p);
     ADVGRPO_LAUNCH_CHECK();

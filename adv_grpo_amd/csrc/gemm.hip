@@ -143,6 +143,28 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4 (&
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += bias8[e];
             }
+            if constexpr (TN == 64) {
+                if (p.rms_w) {   // QK-norm: the wave tile's 64 columns are one head, its row sits in 8 adjacent lanes
+                    const int hh = n >> 6;
+                    float sq = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v[e] = round_bf16(v[e]);          // the Linear's bf16 output is what gets normalised
+                        sq += v[e] * v[e];
+                    }
+                    sq += __shfl_xor(sq, 1, 64);
+                    sq += __shfl_xor(sq, 2, 64);
+                    sq += __shfl_xor(sq, 4, 64);
+                    if (hh < p.rms_nheads) {
+                        const float rs = rsqrtf(sq * (1.0f / 64.0f) + p.rms_eps);
+                        if (p.rms_rs_out && (lane & 7) == 0) p.rms_rs_out[orow * p.rms_nheads + hh] = rs;
+                        float w8[8];
+                        unpack8(*reinterpret_cast<const uint4*>(p.rms_w + (hh / p.rms_hpw) * 64 + c8), w8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = round_bf16(v[e] * rs) * w8[e];
+                    }
+                }
+            }
             if (p.aux_out)
                 *reinterpret_cast<uint4*>(p.aux_out + (int64_t)bz * p.strideC + orow * p.ld_aux + n) = pack8(v);
             if (p.act >= ACT_DGELU_TANH) {
@@ -285,8 +307,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
 }
 
+// two independent problems served by one launch (same tile variant): workgroups [0, tiles_a) run problem a, the rest
+// problem b.  Used to run the short text-stream Linear of a joint MMDiT block in the tail of its image-stream twin
+// instead of as a second, badly filled launch (M = 16 x 205 rows against 256 CUs x 2 workgroups).
+struct GemmPair { GemmParams a, b; int tiles_a; };
+
 template <int BM, int BN, int WM, int WN, bool CONV>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bid, const int by, char* smem) {
     constexpr int BK = 64;
     constexpr int NW = WM * WN;                 // waves per workgroup
     constexpr int TM = BM / WM, TN = BN / WN;   // wave tile
@@ -295,7 +322,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int A_INST = BM / 8 / NW, B_INST = BN / 8 / NW;  // DMA instructions per wave per tile
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -303,11 +329,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
 
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int nwg = tiles_m * tiles_n;
-    const int swz = xcd_remap(blockIdx.x, nwg);
+    const int swz = xcd_remap(bid, nwg);
     int tile_m, tile_n;
     tile_coords(swz, tiles_m, tiles_n, (p.debug >> 8) ? (p.debug >> 8) : 4, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int bz = blockIdx.y / p.splitk, sk = blockIdx.y % p.splitk;
+    const int bz = by / p.splitk, sk = by % p.splitk;
 
     const bf16_t* __restrict__ A = p.A + (int64_t)bz * p.strideA;
     const bf16_t* __restrict__ W = p.W + (int64_t)bz * p.strideW;
@@ -419,6 +445,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
     gemm_epilogue<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane, smem, wave);
 }
 
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_bf16_body<BM, BN, WM, WN, CONV>(p, blockIdx.x, blockIdx.y, smem);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_pair_kernel(const GemmPair pp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x;
+    if (bid < pp.tiles_a) gemm_bf16_body<BM, BN, WM, WN, false>(pp.a, bid, 0, smem);
+    else gemm_bf16_body<BM, BN, WM, WN, false>(pp.b, bid - pp.tiles_a, 0, smem);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Deep-pipelined variant for short-K problems (the MMDiT's K = 1536 Linears): BK = 32, a 4-slot LDS ring, LDS-DMA
 // for three tiles kept in flight ACROSS the workgroup barrier (counted s_waitcnt vmcnt + raw s_barrier, guide
@@ -428,7 +468,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
 //   LDS tile image: rows of 32 k = 64 B = 4 chunks; one DMA instruction (1 KiB) covers 16 rows; chunk c of row r
 //   sits at slot c ^ ((-(r >> 2)) & 3), which spreads each ds_read_b128 service group over all 16 bank slots.
 template <int BM, int BN, int NS, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_pipe_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_bf16_pipe_body(const GemmParams& p, const int bid, const int by, char* smem) {
     constexpr int BK = 32, AHEAD = NS - 2;   // tiles kept in flight beyond the one being consumed
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
@@ -436,16 +476,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_pipe_kernel(const Gemm
     constexpr int A_INST = BM / 16 / NW, B_INST = BN / 16 / NW;     // 16-row DMA instructions per wave
     static_assert(A_INST >= 1 && B_INST >= 1, "tile too small for the wave count");
     constexpr int LOADS = A_INST + B_INST;                        // per wave per tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int swz = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int swz = xcd_remap(bid, tiles_m * tiles_n);
     int tile_m, tile_n;
     tile_coords(swz, tiles_m, tiles_n, (p.debug >> 8) ? (p.debug >> 8) : 4, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int bz = blockIdx.y;
+    const int bz = by;
     const bf16_t* __restrict__ A = p.A + (int64_t)bz * p.strideA;
     const bf16_t* __restrict__ W = p.W + (int64_t)bz * p.strideW;
 
@@ -523,6 +562,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_pipe_kernel(const Gemm
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
     gemm_epilogue<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane, smem, wave);
+}
+
+template <int BM, int BN, int NS, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_pipe_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_bf16_pipe_body<BM, BN, NS, WM, WN>(p, blockIdx.x, blockIdx.y, smem);
+}
+
+template <int BM, int BN, int NS, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_pipe_pair_kernel(const GemmPair pp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x;
+    if (bid < pp.tiles_a) gemm_bf16_pipe_body<BM, BN, NS, WM, WN>(pp.a, bid, 0, smem);
+    else gemm_bf16_pipe_body<BM, BN, NS, WM, WN>(pp.b, bid - pp.tiles_a, 0, smem);
 }
 
 template <int BM, int BN, int NS, int WM, int WN>
@@ -693,6 +746,39 @@ static int launch(const GemmParams& p, hipStream_t s) {
     return 0;
 }
 
+template <int BM, int BN, int WM, int WN>
+static int launch_pair(const GemmParams& a, const GemmParams& b, hipStream_t s) {
+    constexpr int lds = 2 * (BM + BN) * 64 * 2;
+    GemmPair pp{a, b, ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN)};
+    const int tiles_b = ((b.M + BM - 1) / BM) * ((b.N + BN - 1) / BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pair_kernel<BM, BN, WM, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, WM, WN>), dim3(pp.tiles_a + tiles_b), dim3(WM * WN * 64), lds, s, pp);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int BM, int BN, int NS, int WM, int WN>
+static int launch_pipe_pair(const GemmParams& a, const GemmParams& b, hipStream_t s) {
+    constexpr int lds = NS * (BM + BN) * 32 * 2;
+    GemmPair pp{a, b, ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN)};
+    const int tiles_b = ((b.M + BM - 1) / BM) * ((b.N + BN - 1) / BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pipe_pair_kernel<BM, BN, NS, WM, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_pipe_pair_kernel<BM, BN, NS, WM, WN>), dim3(pp.tiles_a + tiles_b), dim3(WM * WN * 64), lds,
+                       s, pp);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- tile variants.  id: 0 = 128x128 (4 waves), 1 = 128x64, 2 = 64x128, 3 = 256x256 (8 waves, 128 KB LDS,
 // one workgroup per CU), 6 = 256x128 (8 waves); +conv: 4 = 128x128, 5 = 128x64, 7 = 256x256, 8 = 256x128.
 // The choice maximises (how full the last round of workgroups is) x (measured relative speed of the tile).
@@ -729,8 +815,8 @@ static int gemm_variant(int M, int N, int K, int batch, int conv, int plain) {  
     return plain ? 15 : 0;
 }
 
-int gemm_bf16(const GemmParams& p_in, hipStream_t s) {
-    GemmParams p = p_in;
+// validation shared by the single and the paired launch; returns the tile variant or -1
+static int gemm_prepare(GemmParams& p) {
     {
         static int dbg = -1;
         if (dbg < 0) { const char* e = getenv("ADVGRPO_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
@@ -753,6 +839,35 @@ int gemm_bf16(const GemmParams& p_in, hipStream_t s) {
                       "conv3x3: need Cin %% 64 == 0, K == 9*Cin, a zero page and batch 1 (Cin=%d K=%d)", p.Cin, p.K);
         ADVGRPO_CHECK((p.Hout % (1 << p.ups)) == 0 && (p.Wout % (1 << p.ups)) == 0, "conv3x3: bad upsample shape");
     }
+    if (p.rms_w) {   // the fused QK-norm lives in the row-coalesced epilogue of the 64-wide wave tiles only
+        auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        const bool narrow = variant == 1 || variant == 5 || variant == 13 || variant == 14 || variant == 22 || variant == 24;
+        ADVGRPO_CHECK(!narrow && !p.conv && p.splitk == 1 && p.batch == 1 && p.N % 64 == 0 && p.ldc % 8 == 0 &&
+                          p.out_dtype == ADVGRPO_BF16 && a16(p.C) && a16(p.bias) && a16(p.rms_w) && p.rms_nheads > 0 &&
+                          p.rms_hpw > 0 && !p.gate && !p.residual && !p.aux_out && !p.aux_in && p.act == ACT_NONE,
+                      "gemm: fused QK-norm needs a plain bf16 projection with N %% 64 == 0 and 16-byte aligned rows");
+    }
+    return variant;
+}
+
+int gemm_bf16_pair(const GemmParams& a_in, const GemmParams& b_in, hipStream_t s) {
+    GemmParams a = a_in, b = b_in;
+    const int va = gemm_prepare(a);
+    if (va < 0) return -1;
+    const int vb = gemm_prepare(b);
+    if (vb < 0) return -1;
+    const bool pairable = a.batch == 1 && b.batch == 1 && a.splitk == 1 && b.splitk == 1 && !a.conv && !b.conv &&
+                          !(a.debug & 32);
+    if (pairable && va == 15) return launch_pair<128, 128, 4, 2>(a, b, s);
+    if (pairable && va == 17) return launch_pipe_pair<256, 128, 3, 4, 2>(a, b, s);
+    const int rc = gemm_bf16(a_in, s);
+    return rc ? rc : gemm_bf16(b_in, s);
+}
+
+int gemm_bf16(const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    const int variant = gemm_prepare(p);
+    if (variant < 0) return -1;
     switch (variant) {
         case 0: return launch<128, 128, 2, 2, false>(p, s);
         case 1: return launch<128, 64, 2, 2, false>(p, s);
@@ -810,6 +925,29 @@ extern "C" int advgrpo_gemm_bf16(const void* A, int64_t lda, const void* W, int6
     p.batch = batch < 1 ? 1 : batch; p.strideA = strideA; p.strideW = strideW; p.strideC = strideC;
     p.splitk = 1;
     return gemm_bf16(p, as_stream(stream));
+}
+
+static GemmParams from_desc(const advgrpo_gemm_desc& d) {
+    GemmParams p{};
+    p.A = (const bf16_t*)d.A; p.W = (const bf16_t*)d.W; p.C = d.C;
+    p.lda = d.lda; p.ldw = d.ldw; p.ldc = d.ldc; p.out_dtype = d.out_dtype;
+    p.M = d.M; p.N = d.N; p.K = d.K;
+    p.bias = (const bf16_t*)d.bias; p.act = d.act; p.alpha = d.alpha;
+    p.gate = (const bf16_t*)d.gate; p.gate_stride = d.gate_stride; p.gate_rows = d.gate_rows;
+    p.residual = (const bf16_t*)d.residual; p.ldr = d.ldr;
+    p.seg_rows = d.seg_rows; p.seg_stride = d.seg_stride; p.seg_off = d.seg_off;
+    p.a_seg_rows = d.a_seg_rows; p.a_seg_stride = d.a_seg_stride; p.a_seg_off = d.a_seg_off;
+    p.batch = 1; p.splitk = 1;
+    p.aux_out = (bf16_t*)d.aux_out; p.aux_in = (const bf16_t*)d.aux_in; p.ld_aux = d.ld_aux;
+    p.rms_w = (const bf16_t*)d.rms_weight; p.rms_nheads = d.rms_nheads; p.rms_hpw = d.rms_heads_per_weight;
+    p.rms_eps = d.rms_eps; p.rms_rs_out = d.rms_rs_out;
+    return p;
+}
+
+extern "C" int advgrpo_gemm_grouped(const advgrpo_gemm_desc* descs, int count, void* stream) {
+    ADVGRPO_CHECK(descs && (count == 1 || count == 2), "gemm_grouped: need 1 or 2 descriptors");
+    if (count == 1) return gemm_bf16(from_desc(descs[0]), as_stream(stream));
+    return gemm_bf16_pair(from_desc(descs[0]), from_desc(descs[1]), as_stream(stream));
 }
 
 /* training variant: + aux pre-activation output / d-activation input, split-K atomic accumulation */

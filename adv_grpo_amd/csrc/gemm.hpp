@@ -29,9 +29,15 @@ struct GemmParams {
     // training extras: aux_out[orow, n] = pre-activation (bf16, pitch ldc); aux_in[orow, n] feeds the d-activation
     // epilogues; splitk > 1: the K range is split over grid.y and partial tiles are atomically added into f32 C
     bf16_t* aux_out; const bf16_t* aux_in; int64_t ld_aux; int splitk;
+    // fused per-head RMSNorm on the first rms_nheads 64-wide column groups of the output (QK-norm of a fused QKV
+    // projection: q heads then k heads, V untouched): y = bf16(bf16(x) * rsqrt(mean(x^2) + eps)) * w[(head / hpw), :];
+    // rms_rs_out[orow, head] (f32, optional) keeps 1/rms for the backward.  Needs a 64-wide wave tile.
+    const bf16_t* rms_w; int rms_nheads; int rms_hpw; float rms_eps; float* rms_rs_out;
     int debug;   // experiments only (ADVGRPO_GEMM_DEBUG): bit0 = skip steady-state DMA, bit1 = skip LDS fragment reads
 };
 
 int gemm_bf16(const GemmParams& p, hipStream_t stream);
+// both problems in one launch when a pair-capable tile variant fits, else two launches
+int gemm_bf16_pair(const GemmParams& a, const GemmParams& b, hipStream_t stream);
 
 }  // namespace advgrpo

@@ -142,34 +142,38 @@ class SD3Transformer2DModel:
                 nc = ops.layernorm_mod(c, scale=mod(kc, 0), shift=mod(kc, 1), rows_per_batch=Nt)
             else:
                 nc = ops.layernorm_mod(c, scale=mod(kc, 1), shift=mod(kc, 0), rows_per_batch=Nt)
-            # --- joint attention
-            ops.gemm(nx, b["qkv.w"], bias=b["qkv.b"], out=qkv, seg=(Ni, S, 0))
-            ops.gemm(nc, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni))
-            if cfg.qk_norm:
-                ops.rmsnorm_heads(qkv, 0, 2 * H, b["rms_x"], H, seg=(Ni, S, 0), M=B * Ni)
-                ops.rmsnorm_heads(qkv, 0, 2 * H, b["rms_c"], H, seg=(Nt, S, Ni), M=B * Nt)
+            # --- joint attention.  Each text-stream Linear rides in the launch of its image-stream twin
+            #     (ops.gemm_grouped) and the QK RMSNorm is the epilogue of the fused QKV projection.
+            rms_x = (b["rms_x"], 2 * H, H, 1e-6, None) if cfg.qk_norm else None
+            rms_c = (b["rms_c"], 2 * H, H, 1e-6, None) if cfg.qk_norm else None
+            ops.gemm_grouped([ops.gemm_desc(nx, b["qkv.w"], bias=b["qkv.b"], out=qkv, seg=(Ni, S, 0), rms=rms_x),
+                              ops.gemm_desc(nc, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni), rms=rms_c)])
             ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att)
-            ops.gemm(att2d, b["out.w"], bias=b["out.b"], gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x,
-                     a_seg=(Ni, S, 0), M=B * Ni)
+            outs = [ops.gemm_desc(att2d, b["out.w"], bias=b["out.b"], gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x,
+                                  a_seg=(Ni, S, 0), M=B * Ni)]
             if not b["last"]:
-                ops.gemm(att2d, b["cout.w"], bias=b["cout.b"], gate=mod(kc, 2), gate_rows=Nt, residual=c, out=c,
-                         a_seg=(Nt, S, Ni), M=B * Nt)
+                outs.append(ops.gemm_desc(att2d, b["cout.w"], bias=b["cout.b"], gate=mod(kc, 2), gate_rows=Nt, residual=c,
+                                          out=c, a_seg=(Nt, S, Ni), M=B * Nt))
+            ops.gemm_grouped(outs)
             if b["dual"]:
-                qkv2 = ops.gemm(nx2, b["qkv2.w"], bias=b["qkv2.b"])
-                if cfg.qk_norm:
-                    ops.rmsnorm_heads(qkv2, 0, 2 * H, b["rms_2"], H)
+                rms_2 = (b["rms_2"], 2 * H, H, 1e-6, None) if cfg.qk_norm else None
+                (qkv2,) = ops.gemm_grouped([ops.gemm_desc(nx2, b["qkv2.w"], bias=b["qkv2.b"], rms=rms_2)])
                 q3 = qkv2.view(B, Ni, 3 * D)
                 o2 = ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], H)
                 ops.gemm(o2.view(B * Ni, D), b["out2.w"], bias=b["out2.b"], gate=mod(kx, 8), gate_rows=Ni, residual=x,
                          out=x)
             # --- MLPs
             nx = ops.layernorm_mod(x, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
-            hmid = ops.gemm(nx, b["ff1.w"], bias=b["ff1.b"], act="gelu_tanh")
-            ops.gemm(hmid, b["ff2.w"], bias=b["ff2.b"], gate=mod(kx, 5), gate_rows=Ni, residual=x, out=x)
+            ff1 = [ops.gemm_desc(nx, b["ff1.w"], bias=b["ff1.b"], act="gelu_tanh")]
             if not b["last"]:
                 nc = ops.layernorm_mod(c, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
-                hmid = ops.gemm(nc, b["cff1.w"], bias=b["cff1.b"], act="gelu_tanh")
-                ops.gemm(hmid, b["cff2.w"], bias=b["cff2.b"], gate=mod(kc, 5), gate_rows=Nt, residual=c, out=c)
+                ff1.append(ops.gemm_desc(nc, b["cff1.w"], bias=b["cff1.b"], act="gelu_tanh"))
+            hm = ops.gemm_grouped(ff1)
+            ff2 = [ops.gemm_desc(hm[0], b["ff2.w"], bias=b["ff2.b"], gate=mod(kx, 5), gate_rows=Ni, residual=x, out=x)]
+            if not b["last"]:
+                ff2.append(ops.gemm_desc(hm[1], b["cff2.w"], bias=b["cff2.b"], gate=mod(kc, 5), gate_rows=Nt, residual=c,
+                                         out=c))
+            ops.gemm_grouped(ff2)
             if return_intermediates:
                 inter[f"x{i + 1}"] = x.view(B, Ni, D).clone()
         nx = ops.layernorm_mod(x, scale=mod(("out",), 0), shift=mod(("out",), 1), rows_per_batch=Ni)

@@ -192,24 +192,24 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             qkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
             qkv3 = qkv.view(B, S, 3 * D)
             rs = torch.empty(B * S, 2 * H, dtype=torch.float32, device=dev)
-            ops.gemm(nx, b["qkv.w"], bias=b["qkv.b"], out=qkv, seg=(Ni, S, 0))
-            ops.gemm(nc, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni))
-            ops.rmsnorm_heads(qkv, 0, 2 * H, b["rms_x"], H, seg=(Ni, S, 0), M=B * Ni, rs_out=rs)
-            ops.rmsnorm_heads(qkv, 0, 2 * H, b["rms_c"], H, seg=(Nt, S, Ni), M=B * Nt, rs_out=rs)
+            ops.gemm_grouped([
+                ops.gemm_desc(nx, b["qkv.w"], bias=b["qkv.b"], out=qkv, seg=(Ni, S, 0), rms=(b["rms_x"], 2 * H, H, 1e-6, rs)),
+                ops.gemm_desc(nc, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni), rms=(b["rms_c"], 2 * H, H, 1e-6, rs))])
             att = torch.empty(B, S, D, dtype=bf16, device=dev)
             lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
             ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att, lse=lse)
             att2d = att.view(B * S, D)
-            ops.gemm(att2d, b["out.w"], bias=b["out.b"], gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x,
-                     a_seg=(Ni, S, 0), M=B * Ni)
+            outs = [ops.gemm_desc(att2d, b["out.w"], bias=b["out.b"], gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x,
+                                  a_seg=(Ni, S, 0), M=B * Ni)]
             if not b["last"]:
-                ops.gemm(att2d, b["cout.w"], bias=b["cout.b"], gate=mod(kc, 2), gate_rows=Nt, residual=c, out=c,
-                         a_seg=(Nt, S, Ni), M=B * Nt)
+                outs.append(ops.gemm_desc(att2d, b["cout.w"], bias=b["cout.b"], gate=mod(kc, 2), gate_rows=Nt, residual=c,
+                                          out=c, a_seg=(Nt, S, Ni), M=B * Nt))
+            ops.gemm_grouped(outs)
             s.update(nx=nx, nc=nc, qkv=qkv, rs=rs, att=att, lse=lse)
             if b["dual"]:
-                qkv2 = ops.gemm(nx2, b["qkv2.w"], bias=b["qkv2.b"])
                 rs2 = torch.empty(B * Ni, 2 * H, dtype=torch.float32, device=dev)
-                ops.rmsnorm_heads(qkv2, 0, 2 * H, b["rms_2"], H, rs_out=rs2)
+                (qkv2,) = ops.gemm_grouped([ops.gemm_desc(nx2, b["qkv2.w"], bias=b["qkv2.b"],
+                                                          rms=(b["rms_2"], 2 * H, H, 1e-6, rs2))])
                 q3 = qkv2.view(B, Ni, 3 * D)
                 lse2 = torch.empty(B, H, Ni, dtype=torch.float32, device=dev)
                 o2 = ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], H, lse=lse2)
@@ -218,16 +218,20 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             s["x_mid"] = x.clone()
             nxm = ops.layernorm_mod(x, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
             pre = torch.empty(B * Ni, 4 * D, dtype=bf16, device=dev)
-            hmid = ops.gemm_train(nxm, b["ff1.w"], bias=b["ff1.b"], act="gelu_tanh", aux_out=pre)
-            ops.gemm(hmid, b["ff2.w"], bias=b["ff2.b"], gate=mod(kx, 5), gate_rows=Ni, residual=x, out=x)
+            ff1 = [ops.gemm_desc(nxm, b["ff1.w"], bias=b["ff1.b"], act="gelu_tanh", aux_out=pre)]
             s.update(pre=pre)
             if not b["last"]:
                 s["c_mid"] = c.clone()
                 ncm = ops.layernorm_mod(c, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
                 cpre = torch.empty(B * Nt, 4 * D, dtype=bf16, device=dev)
-                chid = ops.gemm_train(ncm, b["cff1.w"], bias=b["cff1.b"], act="gelu_tanh", aux_out=cpre)
-                ops.gemm(chid, b["cff2.w"], bias=b["cff2.b"], gate=mod(kc, 5), gate_rows=Nt, residual=c, out=c)
+                ff1.append(ops.gemm_desc(ncm, b["cff1.w"], bias=b["cff1.b"], act="gelu_tanh", aux_out=cpre))
                 s.update(cpre=cpre)
+            hm = ops.gemm_grouped(ff1)
+            ff2 = [ops.gemm_desc(hm[0], b["ff2.w"], bias=b["ff2.b"], gate=mod(kx, 5), gate_rows=Ni, residual=x, out=x)]
+            if not b["last"]:
+                ff2.append(ops.gemm_desc(hm[1], b["cff2.w"], bias=b["cff2.b"], gate=mod(kc, 5), gate_rows=Nt, residual=c,
+                                         out=c))
+            ops.gemm_grouped(ff2)
             ctx["blocks"].append(s)
         ctx["x_final"] = x
         nx = ops.layernorm_mod(x, scale=mod(("out",), 0), shift=mod(("out",), 1), rows_per_batch=Ni)

@@ -75,6 +75,61 @@ def gemm(a, w, bias=None, act=None, alpha=1.0, gate=None, gate_rows=0, residual=
     return out
 
 
+def gemm_desc(a, w, bias=None, act=None, alpha=1.0, gate=None, gate_rows=0, residual=None, out=None,
+              out_dtype=torch.bfloat16, seg=None, a_seg=None, M=None, aux_out=None, aux_in=None, rms=None):
+    """Descriptor of one Linear for gemm_grouped (arguments as in gemm / gemm_train).
+    rms = (weight [n_w, 64] bf16, nheads, heads_per_weight, eps, rs_out or None): fused per-head RMSNorm of the first
+    `nheads` 64-wide output column groups (QK-norm of a fused QKV projection).  Returns (descriptor, out)."""
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.shape[1] == w.shape[1]
+    assert a.stride(1) == 1 and w.stride(1) == 1
+    K = a.shape[1]
+    M = a.shape[0] if M is None else M
+    N = w.shape[0]
+    if out is None:
+        assert seg is None
+        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    assert out.stride(-1) == 1
+    d = _lib.GemmDesc()
+    d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.lda, d.ldw, d.ldc = a.stride(0), w.stride(0), out.stride(-2)
+    d.out_dtype, d.M, d.N, d.K = _lib.dtype_code(out.dtype), M, N, K
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.act = ACT_D[act] if act in ACT_D else ACT[act]
+    d.alpha = float(alpha)
+    if gate is not None:
+        d.gate, d.gate_stride, d.gate_rows = gate.data_ptr(), gate.stride(0), int(gate_rows)
+    if residual is not None:
+        d.residual, d.ldr = residual.data_ptr(), residual.stride(-2)
+    if seg is not None:
+        d.seg_rows, d.seg_stride, d.seg_off = (int(v) for v in seg)
+    if a_seg is not None:
+        d.a_seg_rows, d.a_seg_stride, d.a_seg_off = (int(v) for v in a_seg)
+    aux = aux_out if aux_out is not None else aux_in
+    if aux is not None:
+        d.aux_out = aux_out.data_ptr() if aux_out is not None else None
+        d.aux_in = aux_in.data_ptr() if aux_in is not None else None
+        d.ld_aux = aux.stride(0)
+    if rms is not None:
+        rw, nheads, hpw, eps, rs_out = rms
+        d.rms_weight, d.rms_nheads, d.rms_heads_per_weight, d.rms_eps = rw.data_ptr(), int(nheads), int(hpw), float(eps)
+        d.rms_rs_out = rs_out.data_ptr() if rs_out is not None else None
+    return d, out
+
+
+def gemm_grouped(descs):
+    """One launch for one or two Linears ((descriptor, out) pairs from gemm_desc); returns the outputs."""
+    lib = _lib.load()
+    arr = (_lib.GemmDesc * len(descs))(*[d for d, _ in descs])
+    d0 = descs[0][0]
+    flops_extra = sum(2.0 * d.M * d.N * d.K for d, _ in descs[1:])
+    prof = _Prof(d0.M, d0.N, d0.K, 1, 0)
+    if prof.on:
+        prof.flops += flops_extra
+    with prof:
+        _lib.check(lib.advgrpo_gemm_grouped(arr, len(descs), _lib.stream_ptr()))
+    return [o for _, o in descs]
+
+
 def bmm_nt(a, w, out=None, out_dtype=torch.bfloat16, alpha=1.0):
     """Batched out[b] = alpha * a[b] @ w[b]^T; a [B,M,K], w [B,N,K] bf16."""
     lib = _lib.load()

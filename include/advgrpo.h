@@ -224,6 +224,27 @@ int advgrpo_dino_head_combine(const void* hidden, const void* w2, const void* b2
 int advgrpo_pickscore_pairs(const void* image_embs, const void* text_embs, int B, int P, float logit_scale_exp,
                             float* scores, void* stream);
 
+/* Descriptor form of the Linear (same semantics as advgrpo_gemm_bf16 / _train; unused fields zero) plus
+ *   - a fused QK-norm: RMSNorm(64, eps, affine) applied per head to the first rms_nheads 64-wide column groups of
+ *     the output (attn.norm_q / norm_k of diffusers' JointAttnProcessor2_0 on a fused to_q|to_k|to_v projection,
+ *     called from the transformer at adv_grpo/diffusers_patch/sd3_pipeline_with_logprob_fast.py:168-186):
+ *     y = bf16(bf16(x) * rsqrt(mean(x^2) + eps)) * w[head / heads_per_weight]; rms_rs_out[orow, head] keeps 1/rms;
+ *   - a grouped launch: descs[0] and descs[1] (count = 2) are served by ONE kernel launch, the second problem's
+ *     tiles filling the tail of the first (the text-stream Linear of a joint block next to its image-stream twin). */
+typedef struct advgrpo_gemm_desc {
+    const void* A; const void* W; void* C;
+    int64_t lda, ldw, ldc;
+    int32_t out_dtype, M, N, K;
+    const void* bias; int32_t act; float alpha;
+    const void* gate; int64_t gate_stride; int32_t gate_rows;
+    const void* residual; int64_t ldr;
+    int32_t seg_rows; int64_t seg_stride, seg_off;
+    int32_t a_seg_rows; int64_t a_seg_stride, a_seg_off;
+    void* aux_out; const void* aux_in; int64_t ld_aux;
+    const void* rms_weight; int32_t rms_nheads, rms_heads_per_weight; float rms_eps; float* rms_rs_out;
+} advgrpo_gemm_desc;
+int advgrpo_gemm_grouped(const advgrpo_gemm_desc* descs, int count /* 1 or 2 */, void* stream);
+
 /* ------------------------------------------------------------------ G-step (training) kernels
  * The update half of the path: loss.backward() / clip_grad_norm_ / AdamW / EMA at
  * scripts/train_sd3_fast_pickscore.py:1165-1171,1186-1187 and adv_grpo/ema.py:39-52; the backward of the

@@ -87,3 +87,64 @@ def test_bmm_nt():
     w = torch.randn(5, 260, 512, device="cuda", generator=g).to(torch.bfloat16)
     out = ops.bmm_nt(a, w, alpha=0.25)
     _check(out, 0.25 * torch.einsum("bmk,bnk->bmn", a.float(), w.float()), 512)
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 21, 128, 384), (16, 1024, 205, 256, 4608)])
+def test_gemm_grouped_pair_with_fused_qk_norm(shape):
+    """One launch for the image- and text-stream QKV projections with the per-head RMSNorm in the epilogue ==
+    two launches + the standalone rmsnorm_heads kernel (bit for bit), and == an fp32 torch reference."""
+    from adv_grpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(6)
+    B, Ni, Nt, K, N = shape
+    S, H = Ni + Nt, N // 3 // 64
+    xi = torch.randn(B * Ni, K, device="cuda", generator=g).to(torch.bfloat16)
+    xt = torch.randn(B * Nt, K, device="cuda", generator=g).to(torch.bfloat16)
+    wi = (torch.randn(N, K, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    wt = (torch.randn(N, K, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    bi = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    bt = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    rw_i = (1 + 0.1 * torch.randn(2, 64, device="cuda", generator=g)).to(torch.bfloat16)
+    rw_t = (1 + 0.1 * torch.randn(2, 64, device="cuda", generator=g)).to(torch.bfloat16)
+    # unfused: two launches + two norm kernels
+    ref = torch.zeros(B * S, N, dtype=torch.bfloat16, device="cuda")
+    rs_ref = torch.zeros(B * S, 2 * H, dtype=torch.float32, device="cuda")
+    ops.gemm(xi, wi, bias=bi, out=ref, seg=(Ni, S, 0))
+    ops.gemm(xt, wt, bias=bt, out=ref, seg=(Nt, S, Ni))
+    plain = ref.clone()
+    ops.rmsnorm_heads(ref, 0, 2 * H, rw_i, H, seg=(Ni, S, 0), M=B * Ni, rs_out=rs_ref)
+    ops.rmsnorm_heads(ref, 0, 2 * H, rw_t, H, seg=(Nt, S, Ni), M=B * Nt, rs_out=rs_ref)
+    # fused + grouped
+    out = torch.zeros(B * S, N, dtype=torch.bfloat16, device="cuda")
+    rs = torch.zeros(B * S, 2 * H, dtype=torch.float32, device="cuda")
+    ops.gemm_grouped([ops.gemm_desc(xi, wi, bias=bi, out=out, seg=(Ni, S, 0), rms=(rw_i, 2 * H, H, 1e-6, rs)),
+                      ops.gemm_desc(xt, wt, bias=bt, out=out, seg=(Nt, S, Ni), rms=(rw_t, 2 * H, H, 1e-6, rs))])
+    assert torch.equal(out, ref)
+    assert torch.equal(rs, rs_ref)
+    # fp32 reference of the norm on the bf16 projection
+    q = plain.float().view(B, S, 3, H, 64)
+    wsel = torch.cat([rw_i.float().view(1, 1, 2, 1, 64).expand(B, Ni, 2, H, 64),
+                      rw_t.float().view(1, 1, 2, 1, 64).expand(B, Nt, 2, H, 64)], 1)
+    qk = q[:, :, :2]
+    normed = qk * torch.rsqrt(qk.pow(2).mean(-1, keepdim=True) + 1e-6)
+    want = torch.cat([normed.to(torch.bfloat16).float() * wsel, q[:, :, 2:]], 2).reshape(B * S, N)
+    assert (out.float() - want).abs().max().item() <= 2e-2 * want.abs().max().item()
+
+
+def test_gemm_grouped_pair_gate_residual_matches_two_launches():
+    from adv_grpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(7)
+    B, Ni, Nt, K, N = 16, 1024, 205, 512, 1536
+    xi = torch.randn(B * Ni, K, device="cuda", generator=g).to(torch.bfloat16)
+    xt = torch.randn(B * Nt, K, device="cuda", generator=g).to(torch.bfloat16)
+    wi = (torch.randn(N, K, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    wt = (torch.randn(N, K, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    bi = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    gi = torch.randn(B, N, device="cuda", generator=g).to(torch.bfloat16)
+    gt = torch.randn(B, N, device="cuda", generator=g).to(torch.bfloat16)
+    ri = torch.randn(B * Ni, N, device="cuda", generator=g).to(torch.bfloat16)
+    rt = torch.randn(B * Nt, N, device="cuda", generator=g).to(torch.bfloat16)
+    a = ops.gemm(xi, wi, bias=bi, gate=gi, gate_rows=Ni, residual=ri)
+    b = ops.gemm(xt, wt, act="gelu_tanh", gate=gt, gate_rows=Nt, residual=rt)
+    oa, ob = ops.gemm_grouped([ops.gemm_desc(xi, wi, bias=bi, gate=gi, gate_rows=Ni, residual=ri),
+                               ops.gemm_desc(xt, wt, act="gelu_tanh", gate=gt, gate_rows=Nt, residual=rt)])
+    assert torch.equal(oa, a) and torch.equal(ob, b)
