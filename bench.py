@@ -52,6 +52,23 @@ def build(device):
     return SD3Pipeline(tr, vae, device), clip
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs of this same command, scripts/pmc_traffic.py: (2*FETCH_SIZE + WRITE_SIZE)*1024, the factor 2 being
+    the gfx950 correction of MI355X_MICROARCH.md).  Single and grouped launches of the tile variant are pooled."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    want = {kernel, kernel.replace("_kernel<", "_pair_kernel<").replace(",false>", ">")}
+    tot, n = 0.0, 0
+    for name, v in json.load(open(path)).items():
+        short = name.replace(" ", "").split("advgrpo::")[-1]
+        if short in want:
+            tot += v["hbm_bytes_per_launch"] * v["launches"]
+            n += v["launches"]
+    return (round(tot / n) if n else None), "profiles/r1_pmc_traffic.json"
+
+
 def cpu_baseline():
     """BASELINE config 1 on the host cores through the CPU oracle (kind "port": the reference's wheels --
     diffusers / timm / peft -- are not installed, so its own Python cannot run): SD3.5-medium shapes, 256x256,
@@ -167,8 +184,10 @@ def main():
         dom = max(per, key=lambda k: per[k][2])
         n, fl, tsec = per[dom]
         achieved = fl / tsec / 1e12
+        traffic, traffic_src = pmc_traffic(dom)
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": BF16_DENSE_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
                     "launches": n, "avg_launch_us": round(tsec / n * 1e6, 2),
                     "algorithmic_flops_per_launch": fl / n, "share_of_step_time": round(tsec / dt, 3)}
         images = world * G * args.steps

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--layers", type=int, default=None, help="reduce the MMDiT depth (smoke runs)")
     ap.add_argument("--batches", type=int, default=None, help="override sample.num_batches_per_epoch")
+    ap.add_argument("--images-per-prompt", type=int, default=None,
+                    help="override sample.num_image_per_prompt (the 16/8 presets need >= 2 ranks: k = 2 must divide n*b)")
     ap.add_argument("--log", default="logs/train.jsonl")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -39,6 +41,8 @@ def main():
     from adv_grpo_amd.trainer import SyntheticData, Trainer
     from adv_grpo_amd.vae import AutoencoderKLDecoder
     cfg = parse_config_flag(args.config, gpu_number=world)
+    if args.images_per_prompt:
+        cfg.sample.num_image_per_prompt = args.images_per_prompt
     if args.batches:
         cfg.sample.num_batches_per_epoch = args.batches
         cfg.train.gradient_accumulation_steps = max(1, args.batches // 2)
