@@ -349,6 +349,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
     for (int it = 0; it < A_INST; ++it) {
         int r = m0 + (wave + it * NW) * 8 + lrow;
         r = r < p.M ? r : p.M - 1;
+        if (p.debug & 64) r = (wave + it * NW) * 8 + lrow;   // experiment: every tile streams the same rows (all L2 hits)
         if constexpr (CONV) {
             const int hw = p.Hout * p.Wout;
             const int bi = r / hw, rem = r - bi * hw;
@@ -369,6 +370,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
     for (int it = 0; it < B_INST; ++it) {
         int r = n0 + (wave + it * NW) * 8 + lrow;
         r = r < p.N ? r : p.N - 1;
+        if (p.debug & 64) r = (wave + it * NW) * 8 + lrow;
         b_src[it] = W + (int64_t)r * p.ldw + schunk * 8;
     }
     auto stage = [&](int buf, int kt) {
@@ -424,21 +426,29 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
         if (kt + 1 < nk) stage(cur ^ 1, kt0 + kt + 1);
         const char* ta = smem + cur * STAGE + wm * TM * 128;
         const char* tb = smem + cur * STAGE + A_BYTES + wn * TN * 128;
+        // both k-steps' fragments are requested up front into separate registers, so the LDS latency of the second
+        // set is covered by the first set's MFMAs (left alone the compiler reuses one register set and waits for
+        // LDS twice per tile); sched_barriers pin the order
+        bf16x8_t af[2][FM], bf[2][FN];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t af[FM], bf[FN];
 #pragma unroll
             for (int i = 0; i < FM; ++i)
-                af[i] = *reinterpret_cast<const bf16x8_t*>(ta + i * 2048 + frag_off[ks]);
+                af[ks][i] = *reinterpret_cast<const bf16x8_t*>(ta + i * 2048 + frag_off[ks]);
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-                bf[j] = *reinterpret_cast<const bf16x8_t*>(tb + j * 2048 + frag_off[ks]);
+                bf[ks][j] = *reinterpret_cast<const bf16x8_t*>(tb + j * 2048 + frag_off[ks]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     }
 

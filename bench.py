@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--no-epoch", action="store_true", help="skip the untimed-for-the-metric full-epoch leg (N=1 only)")
     return ap.parse_args()
 
 
@@ -67,6 +68,44 @@ def pmc_traffic(kernel):
             tot += v["hbm_bytes_per_launch"] * v["launches"]
             n += v["launches"]
     return (round(tot / n) if n else None), "profiles/r1_pmc_traffic.json"
+
+
+def full_epoch(device):
+    """the whole sample -> score -> gather -> advantage -> G-step loop and its phases, outside the timed
+    region of the headline metric: config 2 (pickscore_cotrain_sd3_fast preset, 8 images per prompt so that one rank
+    holds whole groups), 2 prompt groups per epoch = 16 images, 2 optimizer steps; the second epoch is reported."""
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.config.experiments import get_config
+    from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
+    from adv_grpo_amd.model_configs import ClipConfig, MMDiTConfig, VaeConfig
+    from adv_grpo_amd.pickscore_scorer import PickScoreScorer
+    from adv_grpo_amd.pipeline import SD3Pipeline
+    from adv_grpo_amd.trainer import SyntheticData, Trainer
+    from adv_grpo_amd.vae import AutoencoderKLDecoder
+    cfg = get_config("pickscore_cotrain_sd3_fast", gpu_number=1)
+    cfg.sample.num_image_per_prompt = 8
+    cfg.sample.num_batches_per_epoch = 2
+    cfg.train.gradient_accumulation_steps = 1
+    cfg.train_d = False                      # G epochs only (the D/G gate depends on random rewards here)
+    mcfg = MMDiTConfig()
+    with synthetic.on_device(device):
+        tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, device, seed=cfg.seed)
+        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321), VaeConfig(), device)
+        scorer = PickScoreScorer(device, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
+    trainer = Trainer(cfg, SD3Pipeline(tr, vae, device), SyntheticData(resolution=cfg.resolution, device=device), scorer,
+                      None, 0, 1, log_path=None)
+    trainer.run_epoch()                      # warm-up epoch
+    trainer.timers.clear()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    trainer.run_epoch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    images = cfg.sample.num_batches_per_epoch * cfg.sample.mini_num_image_per_prompt
+    return {"images": images, "seconds": round(dt, 3), "images_per_s_full_epoch": round(images / dt, 3),
+            "phases_s": {k: round(v, 4) for k, v in trainer.timers.items()},
+            "note": "sample = rollout + VAE decode; score = PickScore of generated AND reference images; g_step = "
+                    "2 groups x 2 SDE timesteps fwd+bwd at CFG batch 16 + 2 clip+AdamW steps + EMA"}
 
 
 def cpu_baseline():
@@ -206,6 +245,10 @@ def main():
             "frac_of_bf16_mfma_peak": round(per_image_tflop * images / dt / world / BF16_DENSE_PEAK_TFLOPS, 4),
             "roofline": roofline,
         }
+        if world == 1 and not args.no_epoch:
+            del pipe, clip
+            torch.cuda.empty_cache()
+            res["epoch"] = full_epoch(device)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
