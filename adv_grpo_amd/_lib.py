@@ -56,6 +56,9 @@ SIGNATURES = {
                                       _P, _P]),
     "advgrpo_gemm_bf16_train": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_int, _P, c_int,
                                         c_float, _P, c_int64, c_int, _P, c_int64, _P, _P, c_int64, c_int, _P]),
+    "advgrpo_gemm_tn_f32acc": (c_int, [_P, c_int64, c_int, c_int64, c_int64, _P, c_int64, c_int, c_int64, c_int64, _P, c_int64,
+                                       c_int, c_int, c_int, c_int, c_float, _P, _P]),
+    "advgrpo_gemm_tn_workspace_bytes": (c_int64, [c_int, c_int]),
     "advgrpo_transpose_bf16": (c_int, [_P, _P, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int64, c_int64, _P]),
     "advgrpo_layernorm_mod_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int, _P, _P, c_int64, c_int,
                                           c_int, c_float, _P]),

@@ -245,18 +245,15 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
         A_cat, Bts, ads = self._lora[key]
         D = self.cfg.dim
         M = x_rows
-        splitk = max(1, min(32, M // 512))
-        XT = ops.transpose(X, R=M, seg=x_seg)                                   # [K, Mpad]
-        dYT = ops.transpose(dY, R=M, seg=dy_seg)                                # [n*D, Mpad]
         t = ops.gemm(X, A_cat, a_seg=x_seg, M=M)                                # [M, n*64] = X A^T
-        tT = ops.transpose(t)                                                   # [n*64, Mpad]
         for j, ad in enumerate(ads):
             gA, gB = self.A_view(ad, self.grads), self.B_view(ad, self.grads)
-            # dB[N,64] += s * dY_j^T t_j
-            ops.gemm_train(dYT[j * D:(j + 1) * D], tT[j * RPAD:(j + 1) * RPAD], alpha=self.scale, out=gB, splitk=splitk)
+            dYj = dY[:, j * D:(j + 1) * D]
+            # dB[N,64] += s * dY_j^T t_j      (token-contracted GEMM: no transposed copies)
+            ops.gemm_tn(dYj, t[:, j * RPAD:(j + 1) * RPAD], gB, alpha=self.scale, M=M, p_seg=dy_seg)
             # u = dY_j B [M,64] ; dA[64,K] += s * u^T X
-            u = ops.gemm(dY[:, j * D:(j + 1) * D], Bts[j], a_seg=dy_seg, M=M)
-            ops.gemm_train(ops.transpose(u), XT, alpha=self.scale, out=gA, splitk=splitk)
+            u = ops.gemm(dYj, Bts[j], a_seg=dy_seg, M=M)
+            ops.gemm_tn(X, u, gA, alpha=self.scale, M=M, p_seg=x_seg, transpose_out=True)
 
     # ------------------------------------------------------------------ explicit backward
     @torch.no_grad()

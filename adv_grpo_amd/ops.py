@@ -337,6 +337,29 @@ def gemm_train(a, w, bias=None, act=None, alpha=1.0, gate=None, gate_rows=0, res
     return out
 
 
+def gemm_tn(P, Q, out, alpha=1.0, M=None, p_seg=None, q_seg=None, transpose_out=False):
+    """out[n1, n2] (or out[n2, n1] with transpose_out) += alpha * sum_m P[row_p(m), n1] * Q[row_q(m), n2]; P [.., N1] and
+    Q [.., 64] bf16 token-major views (last dim contiguous), out f32 holding the running sum."""
+    lib = _lib.load()
+    assert P.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16 and out.dtype == torch.float32
+    assert P.stride(1) == 1 and Q.stride(1) == 1 and out.stride(1) == 1
+    M = P.shape[0] if M is None else M
+    ps = p_seg if p_seg is not None else (0, 0, 0)
+    qs = q_seg if q_seg is not None else (0, 0, 0)
+    global _TN_WS
+    need = lib.advgrpo_gemm_tn_workspace_bytes(M, P.shape[1])
+    if _TN_WS is None or _TN_WS.numel() < need or _TN_WS.device != P.device:
+        _TN_WS = torch.empty(need, dtype=torch.uint8, device=P.device)      # stream-ordered reuse across calls
+    _lib.check(lib.advgrpo_gemm_tn_f32acc(P.data_ptr(), P.stride(0), int(ps[0]), int(ps[1]), int(ps[2]), Q.data_ptr(),
+                                          Q.stride(0), int(qs[0]), int(qs[1]), int(qs[2]), out.data_ptr(), out.stride(0),
+                                          int(transpose_out), M, P.shape[1], Q.shape[1], float(alpha), _TN_WS.data_ptr(),
+                                          _lib.stream_ptr()))
+    return out
+
+
+_TN_WS = None
+
+
 def transpose(x, R=None, seg=None, pad_to=64, out=None):
     """x [rows, C] bf16 (row pitch = stride(0)) -> [C, Rpad] with Rpad = R rounded up to `pad_to` (zero filled).
     R rows are taken through the row-segment map `seg` = (seg_rows, seg_stride, seg_off) when given."""

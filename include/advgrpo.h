@@ -257,6 +257,15 @@ int advgrpo_gemm_bf16_train(const void* A, int64_t lda, const void* W, int64_t l
                             const void* gate, int64_t gate_stride, int gate_rows, const void* residual,
                             int64_t ldr, void* aux_out, const void* aux_in, int64_t ld_aux, int splitk,
                             void* stream);
+/* Token-contracted GEMM for the LoRA weight gradients (PEFT LoRA layers set up at TP:490-511, differentiated by
+ * loss.backward() at TP:1165): C[n1,n2] += alpha * sum_m P[row_p(m), n1] * Q[row_q(m), n2], f32 atomic accumulation;
+ * P [M, N1] and Q [M, 64] bf16, token-major, rows through the (seg_rows, seg_stride, seg_off) map; transpose_out
+ * writes C[n2 * ldc + n1]; slices of the token range are summed through `workspace` (no atomics).  dB = s dY^T (X A^T): P = dY, Q = X A^T; dA = s (dY B)^T X: P = X, Q = dY B, transposed. */
+int advgrpo_gemm_tn_f32acc(const void* P, int64_t ldp, int p_seg_rows, int64_t p_seg_stride, int64_t p_seg_off,
+                           const void* Q, int64_t ldq, int q_seg_rows, int64_t q_seg_stride, int64_t q_seg_off,
+                           float* C, int64_t ldc, int transpose_out, int M, int N1, int N2, float alpha,
+                           void* workspace /* advgrpo_gemm_tn_workspace_bytes(M, N1), 16-byte aligned */, void* stream);
+int64_t advgrpo_gemm_tn_workspace_bytes(int M, int N1);
 /* out[c, r] = in[row(r), c] for r < R, zero for R <= r < Rpad (row(r) = the GEMM row-segment map when seg_rows > 0). */
 int advgrpo_transpose_bf16(const void* in, void* out, int R, int C, int64_t ldi, int64_t ldo, int Rpad,
                            int seg_rows, int64_t seg_stride, int64_t seg_off, void* stream);

@@ -283,3 +283,27 @@ def test_pickscore_d_step_vs_autograd():
     tr.adam_step(1e-3)
     assert not torch.equal(model.v_enc.layers[-1]["fc1.w"], before)        # the scorer's weights alias the flat vector
     assert (tr.grads == 0).all()
+
+
+@pytest.mark.parametrize("M,seg", [(16 * 64, None), (3 * 205, (205, 333, 128)), (100, None)])
+def test_gemm_tn_token_contraction(M, seg):
+    """C[n1,n2] += alpha * sum_m P[row(m),n1] Q[m,n2] (LoRA weight gradients), plain and transposed output, with a row
+    map on P and a token count that is not a multiple of the 64-token stage."""
+    from adv_grpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    N1 = 256
+    rows = M if seg is None else (M // seg[0]) * seg[1] + 8
+    P = torch.randn(rows, N1 + 64, device="cuda", generator=g).to(torch.bfloat16)[:, 64:]    # a column slice (pitch > N1)
+    Q = torch.randn(M, 64, device="cuda", generator=g).to(torch.bfloat16)
+    if seg is None:
+        Pm = P[:M].float()
+    else:
+        idx = torch.arange(M, device="cuda")
+        Pm = P[(idx // seg[0]) * seg[1] + seg[2] + idx % seg[0]].float()
+    ref = 0.5 * Pm.t() @ Q.float()
+    out = torch.ones(N1, 64, dtype=torch.float32, device="cuda")
+    ops.gemm_tn(P, Q, out, alpha=0.5, M=M, p_seg=seg)
+    assert torch.allclose(out - 1.0, ref, rtol=2e-3, atol=2e-2 * ref.abs().max().item() / 10)
+    outT = torch.zeros(64, N1, dtype=torch.float32, device="cuda")
+    ops.gemm_tn(P, Q, outT, alpha=0.5, M=M, p_seg=seg, transpose_out=True)
+    assert torch.allclose(outT.t(), ref, rtol=2e-3, atol=2e-2 * ref.abs().max().item() / 10)
