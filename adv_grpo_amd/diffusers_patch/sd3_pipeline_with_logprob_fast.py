@@ -49,6 +49,12 @@ def pipeline_with_logprob_random(self, prompt=None, prompt_2=None, prompt_3=None
         tem_pe, tem_ppe = pe, ppe
     dtype = prompt_embeds.dtype
     B = pe.shape[0]
+    if latents is None and generator is not None and seed is None:
+        # the eval loop's path (TP:298-299,319): initial latents from the caller's torch generator exactly as diffusers'
+        # prepare_latents / randn_tensor draws them (a CPU generator draws on the CPU in the embedding dtype, then moves)
+        gdev = generator.device if isinstance(generator, torch.Generator) else torch.device("cpu")
+        shape = (B, self.transformer.config.in_channels, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())
     if latents is None:                                                        # PF:559-568 prepare_latents

@@ -88,6 +88,32 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             out[key + ".lora_B.weight"] = self.B_view(ad)[:, :RANK].clone()
         return out
 
+    def load_lora_state(self, lora_state):
+        """PeftModel.from_pretrained (TP:506-509): overwrite the adapters and re-merge.  Optimizer moments are kept."""
+        for key, ad in self.adapters.items():
+            A, Bm = lora_state[key + ".lora_A.weight"], lora_state[key + ".lora_B.weight"]
+            if tuple(A.shape) != (RANK, ad.K) or tuple(Bm.shape) != (ad.N, RANK):
+                raise ValueError(f"{key}: adapter shapes {tuple(A.shape)} / {tuple(Bm.shape)} do not match r={RANK}")
+            self.A_view(ad).zero_(); self.B_view(ad).zero_()
+            self.A_view(ad)[:RANK] = A.to(self.device, torch.float32)
+            self.B_view(ad)[:, :RANK] = Bm.to(self.device, torch.float32)
+        self.params_bf16 = self.params.to(torch.bfloat16)
+        self.refresh()
+
+    def save_pretrained(self, path, use_ema=False):
+        """save_ckpt (TP:389-398): PEFT layout; with use_ema the EMA weights are what is written (copy_ema_to /
+        copy_temp_to around save_pretrained upstream: the live parameters are left untouched here)."""
+        from . import checkpoint
+        if use_ema and self.ema is not None:
+            live, self.params = self.params, self.ema
+            try:
+                state = self.lora_state_dict()
+            finally:
+                self.params = live
+        else:
+            state = self.lora_state_dict()
+        checkpoint.save_lora(path, state, r=RANK, lora_alpha=int(round(self.scale * RANK)))
+
     def lora_grads(self):
         out = {}
         for key, ad in self.adapters.items():

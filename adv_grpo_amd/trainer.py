@@ -133,6 +133,71 @@ class Trainer:
                         "clip_ids": prompts})
         return {k: torch.cat([s[k] for s in out], dim=0) for k in out[0]}
 
+    # ------------------------------------------------------------------ eval loop
+    @torch.no_grad()
+    def evaluate(self, n_prompts=None, eval_reward_fn=None):
+        """eval() (TP:269-382): EMA weights swapped in, `eval_num_steps` deterministic steps (noise_level = 0), one image
+        per prompt, initial latents from a CPU generator seeded with 0 for every batch (TP:298-299), rewards gathered
+        over ranks, means of the valid (!= -10) entries logged as eval_reward_<name> (TP:373-377)."""
+        c = self.cfg
+        model = self.pipe.transformer
+        swapped = c.train.ema and getattr(model, "ema", None) is not None
+        if swapped:                                                                         # ema.copy_ema_to(store_temp)
+            live, model.params = model.params, model.ema
+            model.params_bf16 = model.params.to(torch.bfloat16)
+            model.refresh()
+        spec = eval_reward_fn if eval_reward_fn is not None else c.eval_reward_fn
+        fn = rewards.multi_score(self.device, spec.to_dict() if hasattr(spec, "to_dict") else dict(spec))
+        bs = c.sample.test_batch_size
+        n = n_prompts if n_prompts is not None else bs * self.world
+        neg_pe, neg_ppe = self.data.neg
+        acc = {}
+        try:
+            for start in range(self.rank * bs, n, bs * self.world):                         # test set sharded over ranks
+                idxs = list(range(start, min(start + bs, n)))
+                pe = torch.cat([self.data.prompt(i)[0] for i in idxs])
+                ppe = torch.cat([self.data.prompt(i)[1] for i in idxs])
+                gen = torch.Generator().manual_seed(0)                                      # TP:298-299
+                images, _, _, _ = pipeline_with_logprob_random(
+                    self.pipe, prompt_embeds=pe, pooled_prompt_embeds=ppe,
+                    negative_prompt_embeds=neg_pe.repeat(len(idxs), 1, 1), negative_pooled_prompt_embeds=neg_ppe.repeat(len(idxs), 1),
+                    num_inference_steps=c.sample.eval_num_steps, guidance_scale=c.sample.guidance_scale, output_type="pt",
+                    height=c.resolution, width=c.resolution, noise_level=0, mini_num_image_per_prompt=1,
+                    process_index=self.rank, sample_num_steps=c.sample.num_steps, random_timestep=c.sample.random_timestep,
+                    generator=gen)                                                          # TP:303-320
+                prompts = torch.cat([self.data.clip_ids(i, 1) for i in idxs])
+                ref = torch.cat([self.data.reference_images(i, 1) for i in idxs])
+                r, _ = fn(images.to(torch.bfloat16), prompts, [{}] * len(idxs), scorer=self.scorer, head=self.head,
+                          ref_images=ref, only_strict=True)                                 # TP:322
+                for k, v in r.items():
+                    acc.setdefault(k, []).append(torch.as_tensor(v, dtype=torch.float32, device=self.device).flatten())
+        finally:
+            if swapped:                                                                     # ema.copy_temp_to
+                model.params = live
+                model.params_bf16 = model.params.to(torch.bfloat16)
+                model.refresh()
+        out = {}
+        for k, chunks in acc.items():
+            v = torch.cat(chunks)
+            if self.world > 1:
+                import torch.distributed as dist
+                parts = [torch.empty_like(v) for _ in range(self.world)]
+                dist.all_gather(parts, v)                                                   # accelerator.gather, TP:330
+                v = torch.cat(parts)
+            v = v[v != -10]
+            out[f"eval_reward_{k}"] = v.mean().item() if v.numel() else float("nan")
+        self.logger.log(out, self.global_step)
+        return out
+
+    def save_checkpoint(self):
+        """save_ckpt (TP:389-398): rank 0 writes the (EMA) LoRA in PEFT layout under save_dir/checkpoints/checkpoint-<step>/lora."""
+        from . import checkpoint
+        if self.rank != 0:
+            return None
+        path = checkpoint.checkpoint_dir(self.cfg.save_dir, self.global_step)
+        self.pipe.transformer.save_pretrained(path, use_ema=bool(self.cfg.train.ema))
+        return path
+
     # ------------------------------------------------------------------ one epoch
     def run_epoch(self):
         c = self.cfg

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--batches", type=int, default=None, help="override sample.num_batches_per_epoch")
     ap.add_argument("--images-per-prompt", type=int, default=None,
                     help="override sample.num_image_per_prompt (the 16/8 presets need >= 2 ranks: k = 2 must divide n*b)")
+    ap.add_argument("--eval", action="store_true", help="run the eval loop every eval_freq epochs (with the co-trained scorer: "
+                    "the stand-alone PickScore / image-similarity scorers need real checkpoints)")
     ap.add_argument("--log", default="logs/train.jsonl")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -59,8 +61,17 @@ def main():
             scorer = PickScoreScorer(device, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
     pipe = SD3Pipeline(tr, vae, device)
     data = SyntheticData(resolution=cfg.resolution, device=device)
+    if cfg.train.lora_path:                                                      # TP:506-509
+        from adv_grpo_amd import checkpoint
+        tr.load_lora_state(checkpoint.load_lora(cfg.train.lora_path)[0])
     trainer = Trainer(cfg, pipe, data, scorer, head, rank, world, log_path=args.log)
     for _ in range(args.epochs):
+        if args.eval and trainer.epoch % cfg.eval_freq == 0:                     # TP:712-713
+            ev = trainer.evaluate(eval_reward_fn={trainer.reward_key: 1})
+            if rank == 0:
+                print(json.dumps({"epoch": trainer.epoch, **ev}))
+        if trainer.epoch % cfg.save_freq == 0 and trainer.epoch > 0:             # TP:714-715
+            trainer.save_checkpoint()
         info = trainer.run_epoch()
         if rank == 0:
             print(json.dumps({"epoch": trainer.epoch, **{k: (v if not hasattr(v, "item") else v.item()) for k, v in info.items()},

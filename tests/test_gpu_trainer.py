@@ -70,3 +70,36 @@ def test_pickscore_variant_d_step_gate():
         assert not torch.equal(tr_.scorer.model.v_enc.layers[-1]["fc1.w"], w0)
     if "G" in phases:
         assert not torch.equal(model.params, p0)
+
+
+def test_eval_loop_is_deterministic_swaps_ema_and_checkpoint_round_trips(tmp_path):
+    """eval() (TP:269-382) + save_ckpt (TP:389-398) + lora_path reload (TP:506-509) on the reduced stack."""
+    from adv_grpo_amd import checkpoint
+    tr_, model, _ = _build("pickscore", train_d=False, save_dir=str(tmp_path))
+    tr_.cfg.sample.eval_num_steps = 6
+    tr_.cfg.sample.test_batch_size = 3
+    tr_.run_epoch()                                   # moves the LoRA parameters and creates / updates the EMA copy
+    model.ema_step(7)
+    live = model.params.clone()
+    a = tr_.evaluate(eval_reward_fn={"pickscore_cotrain": 1})
+    b = tr_.evaluate(eval_reward_fn={"pickscore_cotrain": 1})
+    assert set(a) == set(b) == {"eval_reward_pickscore_cotrain", "eval_reward_avg"}
+    # fixed seed-0 latents and noise 0: repeatable up to the order of the f64 atomic sums in the VAE's GroupNorm statistics
+    assert all(v == v and abs(v - b[k]) <= 5e-3 * abs(v) for k, v in a.items())
+    assert torch.equal(model.params, live)            # EMA swapped back (copy_temp_to)
+    # checkpoint: PEFT layout, EMA weights written; reloading them reproduces the EMA model's prediction
+    path = tr_.save_checkpoint()
+    state, cfg = checkpoint.load_lora(path)
+    assert cfg["r"] == 32 and cfg["lora_alpha"] == 64
+    ema_state = {k: v for k, v in state.items()}
+    key = "transformer_blocks.0.attn.to_q.lora_A.weight"
+    from adv_grpo_amd.mmdit_train import RANK
+    assert torch.equal(ema_state[key].cuda(), model.A_view(model.adapters[key[:-len(".lora_A.weight")]], model.ema)[:RANK])
+    x = torch.randn(2, 16, 32, 32, device="cuda").to(torch.bfloat16)
+    t = torch.tensor([500.0, 500.0], device="cuda")
+    ctx = torch.randn(2, 21, 256, device="cuda").to(torch.bfloat16)
+    pooled = torch.randn(2, 128, device="cuda").to(torch.bfloat16)
+    model.load_lora_state(ema_state)
+    y1 = model(x, t, ctx, pooled)[0].clone()
+    model.load_lora_state({k: v.clone() for k, v in state.items()})
+    assert torch.equal(model(x, t, ctx, pooled)[0], y1)
