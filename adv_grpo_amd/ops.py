@@ -123,8 +123,12 @@ def gemm_grouped(descs):
     d0 = descs[0][0]
     flops_extra = sum(2.0 * d.M * d.N * d.K for d, _ in descs[1:])
     prof = _Prof(d0.M, d0.N, d0.K, 1, 0)
-    if prof.on:
+    if prof.on and len(descs) == 2:
         prof.flops += flops_extra
+        # the grouped launch runs the *_pair_kernel instantiation of the first problem's tile variant (15 / 17);
+        # any other variant falls back to two launches and is recorded under the first one's name
+        prof.name = {GEMM_VARIANTS[15]: "gemm_bf16_pair_kernel<128,128,4,2>",
+                     GEMM_VARIANTS[17]: "gemm_bf16_pipe_pair_kernel<256,128,3,4,2>"}.get(prof.name, prof.name)
     with prof:
         _lib.check(lib.advgrpo_gemm_grouped(arr, len(descs), _lib.stream_ptr()))
     return [o for _, o in descs]

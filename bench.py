@@ -56,11 +56,11 @@ def build(device):
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate runs of this same command, scripts/pmc_traffic.py: (2*FETCH_SIZE + WRITE_SIZE)*1024, the factor 2 being
-    the gfx950 correction of MI355X_MICROARCH.md).  Single and grouped launches of the tile variant are pooled."""
+    the gfx950 correction of MI355X_MICROARCH.md)."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
     if not os.path.exists(path):
         return None, None
-    want = {kernel, kernel.replace("_kernel<", "_pair_kernel<").replace(",false>", ">")}
+    want = {kernel}
     tot, n = 0.0, 0
     for name, v in json.load(open(path)).items():
         short = name.replace(" ", "").split("advgrpo::")[-1]
