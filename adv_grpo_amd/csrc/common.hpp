@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../../include/advgrpo.h"
 
@@ -53,15 +54,30 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B fragment
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 
 // ---- wave / block reductions (64-lane wave)
+// All-reduce on the VALU: quad permutes and row mirrors (DPP) inside each 16-lane row, then the gfx950 row / half-wave
+// swaps -- no LDS round trips (the __shfl_xor butterfly is six ds_bpermute, each ~100 cycles of latency).
+template <class Op>
+__device__ __forceinline__ float wave_allreduce(float v, Op op) {
+    auto dpp = [](float x, auto ctrl) __attribute__((always_inline)) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
+                                                                     0xf, 0xf, true));
+    };
+    v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));    // quad_perm [1,0,3,2]: lane ^ 1
+    v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));    // quad_perm [2,3,0,1]: lane ^ 2
+    v = op(v, dpp(v, std::integral_constant<int, 0x141>{}));   // row_half_mirror: the other quad of the 8-lane half
+    v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));   // row_mirror: the other half of the 16-lane row
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // rows 0<->1, 2<->3
+    v = op(a, b);
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // halves of the wave
+    return op(a, b);
+}
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return wave_allreduce(v, [](float x, float y) { return x + y; });
 }
 __device__ inline float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    return wave_allreduce(v, [](float x, float y) { return fmaxf(x, y); });
 }
 // sum over a block of NW waves; result valid in every thread. smem: >= NW floats.
 template <int NW>
