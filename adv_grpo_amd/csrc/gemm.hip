@@ -98,9 +98,9 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4 (&
                                                    int wn, int bz, int lane, char* scratch) {
     constexpr int RS = TN * 4 + 16;            // scratch row stride in bytes
     constexpr int LPR = TN / 8;                // lanes per row on the way out
-    constexpr int RPP = 64 / LPR;              // rows per pass
-    constexpr int PASSES = 16 / RPP;
-    static_assert(PASSES >= 1 && LPR >= 1, "wave tile too wide for the row epilogue");
+    constexpr int RPP = 64 / LPR;              // rows per pass (a 48-wide wave tile uses 60 of the 64 lanes)
+    constexpr int PASSES = (16 + RPP - 1) / RPP;
+    static_assert(RPP >= 1 && LPR >= 1 && TN % 8 == 0, "wave tile too wide for the row epilogue");
     const int mrow = lane & 15, ncol = (lane >> 4) * 4;
     const int orow_l = lane / LPR, c8 = (lane % LPR) * 8;
     auto unpack8 = [](const uint4& q, float (&f)[8]) __attribute__((always_inline)) {
@@ -128,6 +128,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4 (&
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int row = ps * RPP + orow_l;
+            if ((64 % LPR != 0 && lane >= LPR * RPP) || (16 % RPP != 0 && row >= 16)) continue;
             const f32x4 lo = *reinterpret_cast<const f32x4*>(scratch + row * RS + c8 * 4);
             const f32x4 hi = *reinterpret_cast<const f32x4*>(scratch + row * RS + c8 * 4 + 16);
             const int m = m0 + wm * TM + i * 16 + row;
@@ -320,8 +321,11 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
     constexpr int FM = TM / 16, FN = TN / 16;   // fragments per wave
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INST = BM / 8 / NW, B_INST = BN / 8 / NW;  // DMA instructions per wave per tile
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
+    // DMA instructions (8 rows each) per tile and per wave; when the wave count does not divide them (6 waves on a
+    // 128 x 192 tile) the last round is issued by the first waves only (wave-uniform guard)
+    constexpr int A_TOTAL = BM / 8, B_TOTAL = BN / 8;
+    constexpr int A_INST = (A_TOTAL + NW - 1) / NW, B_INST = (B_TOTAL + NW - 1) / NW;
+    static_assert(BM % 16 == 0 && BN % 16 == 0 && TM % 16 == 0 && TN % 16 == 0, "tile / wave tile must be fragment multiples");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -388,18 +392,21 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
                 const bf16_t* src = ok ? A + a_img[it] + ((int64_t)(yy >> p.ups) * win + (xx >> p.ups)) * p.Cin + c0 +
                                              schunk * 8
                                        : p.zero_page + schunk * 8;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(base + (wave + it * NW) * 1024), 16, 0, 0);
+                if (A_TOTAL % NW == 0 || wave + it * NW < A_TOTAL)
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(base + (wave + it * NW) * 1024), 16, 0, 0);
             }
         } else {
 #pragma unroll
             for (int it = 0; it < A_INST; ++it)
-                __builtin_amdgcn_global_load_lds((gptr_t)(a_src[it] + kt * BK),
-                                                 (lds_ptr_t)(base + (wave + it * NW) * 1024), 16, 0, 0);
+                if (A_TOTAL % NW == 0 || wave + it * NW < A_TOTAL)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(a_src[it] + kt * BK),
+                                                     (lds_ptr_t)(base + (wave + it * NW) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < B_INST; ++it)
-            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[it] + kt * BK),
-                                             (lds_ptr_t)(base + A_BYTES + (wave + it * NW) * 1024), 16, 0, 0);
+            if (B_TOTAL % NW == 0 || wave + it * NW < B_TOTAL)
+                __builtin_amdgcn_global_load_lds((gptr_t)(b_src[it] + kt * BK),
+                                                 (lds_ptr_t)(base + A_BYTES + (wave + it * NW) * 1024), 16, 0, 0);
     };
 
     // ---- fragment read offsets (bytes) inside a tile: row (lane&15), swizzled chunk
@@ -819,9 +826,13 @@ static int gemm_variant(int M, int N, int K, int batch, int conv, int plain) {  
     if (M >= 4096 && N >= 8192 && rounds_eff(256, 256, 256) > 0.85) return 3;
     if (M <= 64) return 2;
     // measured (scripts/bench_gemm.py): 8 waves per workgroup (16 waves per CU) beat 4 on every MMDiT / ViT shape;
-    // wide outputs (QKV, FF1: N >= 4096 with M = 16384) prefer the deep-pipelined 256x128 ring kernel.
+    // wide outputs (QKV, FF1: N >= 4096 with M = 16384) prefer the 192x128 tile (80 KB of LDS: still two workgroups per
+    // CU, 17 % fewer L2->LDS bytes per flop than 128x128; in situ +2.4 % on the whole rollout step over the 256x128 ring
+    // kernel, variant 17, which it replaced here).
     (void)K;
-    if (plain && M >= 8192 && N >= 4096) return 17;
+    if (plain && M >= 8192 && N >= 4096) return 26;
+    // N = 1536 Linears of the image stream (out-proj, FF2): 128x192 tiles, 8 waves of 64x48 (+2.3 % in situ over 128x128)
+    if (plain && M >= 8192 && N % 192 == 0) return 27;
     return plain ? 15 : 0;
 }
 
@@ -843,7 +854,8 @@ static int gemm_prepare(GemmParams& p) {
                   "gemm: split-K accumulates atomically into f32 and takes no other epilogue");
     ADVGRPO_CHECK(p.act < ACT_DGELU_TANH || p.aux_in, "gemm: d-activation epilogue needs aux_in");
     ADVGRPO_CHECK(!(p.aux_out || p.aux_in) || ((p.ld_aux & 3) == 0 && (p.N & 3) == 0), "gemm: aux needs N, ld_aux %% 4 == 0");
-    const int variant = gemm_variant(p.M, p.N, p.K, p.batch * p.splitk, p.conv, p.splitk == 1 && !p.conv);
+    int variant = gemm_variant(p.M, p.N, p.K, p.batch * p.splitk, p.conv, p.splitk == 1 && !p.conv);
+    if (p.rms_w && variant == 27) variant = 15;   // the fused QK-norm needs 64-wide wave tiles (one head per wave row)
     if (p.conv) {
         ADVGRPO_CHECK(p.Cin % 64 == 0 && p.K == 9 * p.Cin && p.zero_page && p.batch == 1,
                       "conv3x3: need Cin %% 64 == 0, K == 9*Cin, a zero page and batch 1 (Cin=%d K=%d)", p.Cin, p.K);
@@ -851,7 +863,7 @@ static int gemm_prepare(GemmParams& p) {
     }
     if (p.rms_w) {   // the fused QK-norm lives in the row-coalesced epilogue of the 64-wide wave tiles only
         auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-        const bool narrow = variant == 1 || variant == 5 || variant == 13 || variant == 14 || variant == 22 || variant == 24;
+        const bool narrow = variant == 1 || variant == 5 || variant == 13 || variant == 14 || variant == 22 || variant == 24 || variant == 27;
         ADVGRPO_CHECK(!narrow && !p.conv && p.splitk == 1 && p.batch == 1 && p.N % 64 == 0 && p.ldc % 8 == 0 &&
                           p.out_dtype == ADVGRPO_BF16 && a16(p.C) && a16(p.bias) && a16(p.rms_w) && p.rms_nheads > 0 &&
                           p.rms_hpw > 0 && !p.gate && !p.residual && !p.aux_out && !p.aux_in && p.act == ACT_NONE,
@@ -870,6 +882,8 @@ int gemm_bf16_pair(const GemmParams& a_in, const GemmParams& b_in, hipStream_t s
                           !(a.debug & 32);
     if (pairable && va == 15) return launch_pair<128, 128, 4, 2>(a, b, s);
     if (pairable && va == 17) return launch_pipe_pair<256, 128, 3, 4, 2>(a, b, s);
+    if (pairable && va == 26) return launch_pair<192, 128, 4, 2>(a, b, s);
+    if (pairable && va == 27) return launch_pair<128, 192, 2, 4>(a, b, s);
     const int rc = gemm_bf16(a_in, s);
     return rc ? rc : gemm_bf16(b_in, s);
 }
@@ -902,6 +916,8 @@ int gemm_bf16(const GemmParams& p_in, hipStream_t s) {
         case 24: return launch_pp<128, 128, 3, 2, 4>(p, s);
         case 25: return launch_pp<128, 128, 3, 4, 2>(p, s);
         case 15: return launch<128, 128, 4, 2, false>(p, s);
+        case 26: return launch<192, 128, 4, 2, false>(p, s);
+        case 27: return launch<128, 192, 2, 4, false>(p, s);
         case 16: return launch_pipe<128, 256, 3, 2, 4>(p, s);
         case 17: return launch_pipe<256, 128, 3, 4, 2>(p, s);
     }

@@ -18,7 +18,8 @@ GEMM_VARIANTS = {0: "gemm_bf16_kernel<128,128,2,2,false>", 1: "gemm_bf16_kernel<
                  17: "gemm_bf16_pipe_kernel<256,128,3,4,2>", 18: "gemm_bf16_kernel<128,128,4,2,true>",
                  20: "gemm_bf16_pp_kernel<256,256,4,2,4>", 21: "gemm_bf16_pp_kernel<256,128,4,4,2>",
                  22: "gemm_bf16_pp_kernel<128,128,4,2,4>", 23: "gemm_bf16_pp_kernel<256,128,3,4,2>",
-                 24: "gemm_bf16_pp_kernel<128,128,3,2,4>", 25: "gemm_bf16_pp_kernel<128,128,3,4,2>"}
+                 24: "gemm_bf16_pp_kernel<128,128,3,2,4>", 25: "gemm_bf16_pp_kernel<128,128,3,4,2>",
+                 26: "gemm_bf16_kernel<192,128,4,2,false>", 27: "gemm_bf16_kernel<128,192,2,4,false>"}
 # bench.py sets this to a list to collect (kernel name, flops, start event, end event) per GEMM launch;
 # events are recorded on the stream the kernel is launched on (torch's current stream).
 PROFILE = None
@@ -125,10 +126,12 @@ def gemm_grouped(descs):
     prof = _Prof(d0.M, d0.N, d0.K, 1, 0)
     if prof.on and len(descs) == 2:
         prof.flops += flops_extra
-        # the grouped launch runs the *_pair_kernel instantiation of the first problem's tile variant (15 / 17);
+        # the grouped launch runs the *_pair_kernel instantiation of the first problem's tile variant (15 / 17 / 26);
         # any other variant falls back to two launches and is recorded under the first one's name
         prof.name = {GEMM_VARIANTS[15]: "gemm_bf16_pair_kernel<128,128,4,2>",
-                     GEMM_VARIANTS[17]: "gemm_bf16_pipe_pair_kernel<256,128,3,4,2>"}.get(prof.name, prof.name)
+                     GEMM_VARIANTS[17]: "gemm_bf16_pipe_pair_kernel<256,128,3,4,2>",
+                     GEMM_VARIANTS[26]: "gemm_bf16_pair_kernel<192,128,4,2>",
+                     GEMM_VARIANTS[27]: "gemm_bf16_pair_kernel<128,192,2,4>"}.get(prof.name, prof.name)
     with prof:
         _lib.check(lib.advgrpo_gemm_grouped(arr, len(descs), _lib.stream_ptr()))
     return [o for _, o in descs]
