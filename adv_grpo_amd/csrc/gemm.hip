@@ -826,13 +826,13 @@ static int gemm_variant(int M, int N, int K, int batch, int conv, int plain) {  
     if (M >= 4096 && N >= 8192 && rounds_eff(256, 256, 256) > 0.85) return 3;
     if (M <= 64) return 2;
     // measured (scripts/bench_gemm.py): 8 waves per workgroup (16 waves per CU) beat 4 on every MMDiT / ViT shape;
-    // wide outputs (QKV, FF1: N >= 4096 with M = 16384) prefer the 192x128 tile (80 KB of LDS: still two workgroups per
-    // CU, 17 % fewer L2->LDS bytes per flop than 128x128; in situ +2.4 % on the whole rollout step over the 256x128 ring
-    // kernel, variant 17, which it replaced here).
+    // image-stream Linears (M = 16384 rows): the 192x128 tile (80 KB of LDS: still two workgroups per CU, 17 % fewer
+    // L2->LDS bytes per flop than 128x128).  Chosen from in-situ runs of the whole rollout step with one shape forced to
+    // each candidate (ADVGRPO_GEMM_FORCE_NK): it beat 128x128, 128x192 and the 256x128 ring kernel on all four shapes
+    // (QKV 891 vs 784-798, FF1 850 vs 704-768, FF2 1004 vs 821-923, out-proj 741 vs 588-648 TFLOP/s on the same box),
+    // although 128x192 is the fastest in the isolated micro-benchmark.
     (void)K;
-    if (plain && M >= 8192 && N >= 4096) return 26;
-    // N = 1536 Linears of the image stream (out-proj, FF2): 128x192 tiles, 8 waves of 64x48 (+2.3 % in situ over 128x128)
-    if (plain && M >= 8192 && N % 192 == 0) return 27;
+    if (plain && M >= 8192 && N >= 1024) return 26;
     return plain ? 15 : 0;
 }
 
@@ -855,6 +855,15 @@ static int gemm_prepare(GemmParams& p) {
     ADVGRPO_CHECK(p.act < ACT_DGELU_TANH || p.aux_in, "gemm: d-activation epilogue needs aux_in");
     ADVGRPO_CHECK(!(p.aux_out || p.aux_in) || ((p.ld_aux & 3) == 0 && (p.N & 3) == 0), "gemm: aux needs N, ld_aux %% 4 == 0");
     int variant = gemm_variant(p.M, p.N, p.K, p.batch * p.splitk, p.conv, p.splitk == 1 && !p.conv);
+    {   // experiments: ADVGRPO_GEMM_FORCE_NK=N:K:variant overrides the tile variant of one Linear shape
+        static int fn = -2, fk = 0, fv = 0;
+        if (fn == -2) {
+            const char* e = getenv("ADVGRPO_GEMM_FORCE_NK");
+            fn = -1;
+            if (e) sscanf(e, "%d:%d:%d", &fn, &fk, &fv);
+        }
+        if (fn == p.N && fk == p.K && !p.conv && p.splitk == 1 && p.M >= 8192) variant = fv;
+    }
     if (p.rms_w && variant == 27) variant = 15;   // the fused QK-norm needs 64-wide wave tiles (one head per wave row)
     if (p.conv) {
         ADVGRPO_CHECK(p.Cin % 64 == 0 && p.K == 9 * p.Cin && p.zero_page && p.batch == 1,
