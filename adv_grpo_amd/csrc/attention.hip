@@ -34,6 +34,7 @@ struct AttnParams {
     float scale_log2e;            // softmax scale * log2(e)
     int causal;
     float* lse;                   // optional [B,H,Sq]: base-2 log-sum-exp of the scaled scores (for backward)
+    const float* bias;            // optional additive score bias [H,Sq,Skv] f32 (T5 relative position bias), head dim 64 only
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnPa
             v_src[i] += v_step;
         }
     };
+    const float sc = p.bias ? 1.0f : p.scale_log2e;
     f32x4 o[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -384,6 +386,21 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnPa
                 for (int qb = 0; qb < 2; ++qb)
                     s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb][ks], s[kb][qb], 0, 0, 0);
         }
+        if (p.bias) {   // scores <- scores * scale + bias, in base-2 units (the softmax below then uses scale 1)
+            asm volatile("; biased tile" ::: "memory");
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const int qi = min(q0 + qb * 16 + t, p.Sq - 1);
+                    const float* brow = p.bias + ((int64_t)h * p.Sq + qi) * p.Skv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = min(kv0 + kb * 16 + g * 4 + r, p.Skv - 1);
+                        s[kb][qb][r] = s[kb][qb][r] * p.scale_log2e + brow[key] * 1.4426950408889634f;
+                    }
+                }
+        }
         const bool edge = (kv0 + ATT_KB > p.Skv) || p.causal;
         if (edge) {   // ragged last tile / causal only: a real (wave-uniform) branch, interior tiles pay nothing
             asm volatile("; masked tile" ::: "memory");
@@ -407,13 +424,13 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnPa
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
             mx = xor32_max(xor16_max(mx));
-            const float m_new = fmaxf(m_run[qb], mx * p.scale_log2e);
+            const float m_new = fmaxf(m_run[qb], mx * sc);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
             m_run[qb] = m_new;
             // exp2(s * scale - m) two scores per v_pk_fma_f32; row sums on v_pk_add_f32
             typedef float f32x2 __attribute__((ext_vector_type(2)));
-            const f32x2 sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {-m_use, -m_use};
+            const f32x2 sc2 = {sc, sc}, nm2 = {-m_use, -m_use};
             f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
@@ -498,10 +515,12 @@ int attention_fwd(const AttnParams& p, int B, int head_dim, hipStream_t s) {
     ADVGRPO_CHECK(p.Sq > 0 && p.Skv > 0 && p.H > 0 && B > 0, "attention: bad shape");
     ADVGRPO_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0,
                   "attention: row pitches must keep 16-byte (q,k,v) / 8-byte (o) alignment");
+    ADVGRPO_CHECK(!p.bias || head_dim == 64, "attention: the score bias is implemented for head dim 64");
     dim3 grid((p.Sq + ATT_QB - 1) / ATT_QB, p.H, B);
     static int use_glds = -1;
     if (use_glds < 0) { const char* e = getenv("ADVGRPO_ATTN_REGSTAGE"); use_glds = (e && atoi(e)) ? 0 : 1; }
     const bool o16 = p.ldo % 8 == 0 && p.bso % 8 == 0 && (reinterpret_cast<uintptr_t>(p.o) & 15) == 0;   // 16-byte row stores
+    ADVGRPO_CHECK(!p.bias || (use_glds && o16), "attention: the score bias needs the LDS-DMA kernel (16-byte aligned output rows)");
     if (head_dim == 64 && use_glds && o16) hipLaunchKernelGGL(attention_fwd_glds_kernel, grid, dim3(256), 0, s, p);
     else if (head_dim == 64) hipLaunchKernelGGL(attention_fwd_kernel<64>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attention_fwd_kernel<80>, grid, dim3(256), 0, s, p);
@@ -525,5 +544,23 @@ extern "C" int advgrpo_attention_fwd(const void* q, const void* k, const void* v
     p.scale_log2e = scale * 1.4426950408889634f;
     p.causal = causal;
     p.lse = lse;
+    return attention_fwd(p, B, head_dim, as_stream(stream));
+}
+
+/* same + additive score bias [H,Sq,Skv] f32 shared by the batch: softmax(q k^T * scale + bias) v (T5's relative position
+ * bias; T5 itself uses scale = 1).  Text encoders of encode_prompt, train_dreambooth_lora_sd3.py:98-144. */
+extern "C" int advgrpo_attention_fwd_bias(const void* q, const void* k, const void* v, void* o, int64_t ldq, int64_t ldk,
+                                          int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso,
+                                          int B, int H, int Sq, int Skv, int head_dim, float scale, int causal,
+                                          const float* bias, void* stream) {
+    ADVGRPO_CHECK(bias, "attention_fwd_bias: null bias");
+    AttnParams p{};
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.bsq = bsq; p.bsk = bsk; p.bsv = bsv; p.bso = bso;
+    p.H = H; p.Sq = Sq; p.Skv = Skv;
+    p.scale_log2e = scale * 1.4426950408889634f;
+    p.causal = causal;
+    p.bias = bias;
     return attention_fwd(p, B, head_dim, as_stream(stream));
 }

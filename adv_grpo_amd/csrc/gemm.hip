@@ -42,11 +42,13 @@ __device__ inline float act_fn(float x, int act) {
         }
         case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
         case ACT_SILU: return x / (1.0f + __expf(-x));
+        case ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
         default: return x;
     }
 }
 // derivative of the activation at pre-activation u
 __device__ inline float dact_fn(float u, int act) {
+    if (act == ACT_MUL_AUX) return u;
     if (act == ACT_DGELU_TANH) {
         const float c = 0.7978845608028654f, a = 0.044715f;
         const float th = tanhf(c * (u + a * u * u * u));

@@ -6,8 +6,9 @@ namespace advgrpo {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
-enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3,
-       ACT_DGELU_TANH = 5 /* y *= gelu_tanh'(aux_in[m,n]) */, ACT_DGELU_ERF = 6 };
+enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_QUICK_GELU = 4 /* x sigmoid(1.702 x), CLIP-L */,
+       ACT_DGELU_TANH = 5 /* y *= gelu_tanh'(aux_in[m,n]) */, ACT_DGELU_ERF = 6,
+       ACT_MUL_AUX = 7 /* y *= aux_in[m,n]: the gate of T5's gated-GELU feed-forward */ };
 
 struct GemmParams {
     const bf16_t* A; const bf16_t* W; void* C;

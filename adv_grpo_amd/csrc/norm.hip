@@ -15,7 +15,7 @@
 
 namespace advgrpo {
 
-constexpr int LN_MAX_CHUNKS = 4;  // 8-element chunks per lane => D <= 2048
+constexpr int LN_MAX_CHUNKS = 8;  // 8-element chunks per lane => D <= 4096 (kernel instantiated for 4 and 8)
 
 __device__ inline void unpack8(const uint4& r, float o[8]) {
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
@@ -42,18 +42,20 @@ struct LnParams {
     const bf16_t* scale1; const bf16_t* shift1; // second modulation for out1
     int64_t mod_stride; int rows_per_batch;
     int M, D; float eps;
+    int rms;   // 1: RMSNorm (T5LayerNorm: no mean subtraction, no bias)
 };
 
+template <int MAXC>
 __global__ __launch_bounds__(256) void layernorm_mod_kernel(const LnParams p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.M) return;
     const int nch = p.D >> 3;
-    float v[LN_MAX_CHUNKS][8];
+    float v[MAXC][8];
     const bf16_t* xr = p.x + (int64_t)row * p.ldx;
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
             unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), v[i]);
@@ -61,10 +63,10 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const LnParams p) {
             for (int k = 0; k < 8; ++k) sum += v[i][k];
         }
     }
-    const float mean = wave_sum(sum) / (float)p.D;
+    const float mean = p.rms ? 0.f : wave_sum(sum) / (float)p.D;
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
 #pragma unroll
@@ -77,12 +79,16 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const LnParams p) {
     const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
     const int64_t mrow = p.rows_per_batch > 0 ? (int64_t)(row / p.rows_per_batch) * p.mod_stride : 0;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
         const int c = lane + i * 64;
         if (c >= nch) continue;
         float n[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) n[k] = (v[i][k] - mean) * rstd;
+        if (p.rms) {   // T5LayerNorm multiplies the weight into the value already cast to the weight dtype
+#pragma unroll
+            for (int k = 0; k < 8; ++k) n[k] = round_bf16(n[k]);
+        }
         if (p.w) {
             float w[8], bb[8];
             unpack8(*reinterpret_cast<const uint4*>(p.w + c * 8), w);
@@ -221,8 +227,25 @@ extern "C" int advgrpo_layernorm_mod(const void* x, int64_t ldx, void* out0, voi
     ADVGRPO_CHECK(!out1 || (scale1 && shift1), "layernorm_mod: out1 needs scale1/shift1");
     LnParams p{(const bf16_t*)x, ldx, (bf16_t*)out0, (bf16_t*)out1, ldo, (const bf16_t*)w, (const bf16_t*)b,
                (const bf16_t*)scale0, (const bf16_t*)shift0, (const bf16_t*)scale1, (const bf16_t*)shift1,
-               mod_stride, rows_per_batch, M, D, eps};
-    hipLaunchKernelGGL(layernorm_mod_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
+               mod_stride, rows_per_batch, M, D, eps, 0};
+    if (D <= 2048) hipLaunchKernelGGL(layernorm_mod_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(layernorm_mod_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+/* T5LayerNorm (transformers T5: x * rsqrt(mean(x^2) + eps) * w, statistics in f32): every norm of the T5-XXL text
+ * encoder behind encode_prompt (adv_grpo/diffusers_patch/train_dreambooth_lora_sd3.py:19-56). */
+extern "C" int advgrpo_rmsnorm_rows(const void* x, int64_t ldx, void* out, int64_t ldo, const void* w, int M, int D, float eps,
+                                    void* stream) {
+    ADVGRPO_CHECK(x && out && w, "rmsnorm_rows: null pointer");
+    ADVGRPO_CHECK(M > 0 && D > 0 && D % 8 == 0 && D <= LN_MAX_CHUNKS * 512, "rmsnorm_rows: need D %% 8 == 0, D <= %d (D=%d)",
+                  LN_MAX_CHUNKS * 512, D);
+    ADVGRPO_CHECK(ldx % 8 == 0 && ldo % 8 == 0, "rmsnorm_rows: pitches must be multiples of 8");
+    LnParams p{(const bf16_t*)x, ldx, (bf16_t*)out, nullptr, ldo, (const bf16_t*)w, nullptr, nullptr, nullptr, nullptr, nullptr,
+               0, 0, M, D, eps, 1};
+    if (D <= 2048) hipLaunchKernelGGL(layernorm_mod_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(layernorm_mod_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

@@ -5,7 +5,7 @@ import torch
 
 from . import _lib
 
-ACT = {None: 0, "none": 0, "gelu_tanh": 1, "gelu": 2, "gelu_erf": 2, "silu": 3}
+ACT = {None: 0, "none": 0, "gelu_tanh": 1, "gelu_new": 1, "gelu": 2, "gelu_erf": 2, "silu": 3, "quick_gelu": 4}
 
 GEMM_VARIANTS = {0: "gemm_bf16_kernel<128,128,2,2,false>", 1: "gemm_bf16_kernel<128,64,2,2,false>",
                  2: "gemm_bf16_kernel<64,128,2,2,false>", 3: "gemm_bf16_kernel<256,256,2,4,false>",
@@ -153,6 +153,21 @@ def bmm_nt(a, w, out=None, out_dtype=torch.bfloat16, alpha=1.0):
     return out
 
 
+def attention_bias(q, k, v, num_heads, bias, scale=1.0, causal=False, out=None):
+    """softmax(q k^T * scale + bias) v with bias [H,Sq,Skv] f32 shared over the batch (head dim 64)."""
+    lib = _lib.load()
+    B, Sq, HD = q.shape
+    Skv = k.shape[1]
+    assert bias.dtype == torch.float32 and bias.is_contiguous() and tuple(bias.shape) == (num_heads, Sq, Skv)
+    if out is None:
+        out = torch.empty(B, Sq, HD, dtype=torch.bfloat16, device=q.device)
+    _lib.check(lib.advgrpo_attention_fwd_bias(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+        q.stride(0), k.stride(0), v.stride(0), out.stride(0), B, num_heads, Sq, Skv, HD // num_heads, float(scale),
+        int(causal), bias.data_ptr(), _lib.stream_ptr()))
+    return out
+
+
 def attention(q, k, v, num_heads, scale=None, causal=False, out=None, lse=None):
     """q [B,Sq,H*D], k/v [B,Skv,H*D] bf16 views (last dim contiguous, any row/batch pitch) -> [B,Sq,H*D]."""
     lib = _lib.load()
@@ -207,6 +222,16 @@ def layernorm_mod(x, out=None, w=None, b=None, scale=None, shift=None, scale2=No
                                          dp(b), dp(scale), dp(shift), dp(scale2), dp(shift2), ms, int(rows_per_batch),
                                          M, D, float(eps), _lib.stream_ptr()))
     return (out, out2) if scale2 is not None else out
+
+
+def rmsnorm_rows(x, w, eps=1e-6, out=None):
+    """T5LayerNorm over the rows of x [M,D] bf16 (D <= 4096)."""
+    lib = _lib.load()
+    M, D = x.shape
+    out = torch.empty(M, D, dtype=torch.bfloat16, device=x.device) if out is None else out
+    _lib.check(lib.advgrpo_rmsnorm_rows(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), w.data_ptr(), M, D,
+                                        float(eps), _lib.stream_ptr()))
+    return out
 
 
 def rmsnorm_heads(buf, col0, nheads, weight, heads_per_weight, eps=1e-6, seg=None, M=None, rs_out=None):
@@ -316,7 +341,7 @@ def image_postprocess(y):
 
 
 # ------------------------------------------------------------------ G-step (training) ops
-ACT_D = {"dgelu_tanh": 5, "dgelu": 6}
+ACT_D = {"dgelu_tanh": 5, "dgelu": 6, "mul_aux": 7}   # "mul_aux": y *= aux_in (gated feed-forward)
 
 
 def gemm_train(a, w, bias=None, act=None, alpha=1.0, gate=None, gate_rows=0, residual=None, out=None,

@@ -40,6 +40,23 @@ class _Encoder:
         return x
 
 
+def pack_clip_layers(sd, pfx, n, dev):
+    """transformers CLIP encoder layers -> the packed per-layer dicts _Encoder consumes (q|k|v fused)."""
+    out = []
+    for i in range(n):
+        p = f"{pfx}.encoder.layers.{i}"
+        a = f"{p}.self_attn"
+        out.append({
+            "ln1.w": _bf(sd[f"{p}.layer_norm1.weight"], dev), "ln1.b": _bf(sd[f"{p}.layer_norm1.bias"], dev),
+            "ln2.w": _bf(sd[f"{p}.layer_norm2.weight"], dev), "ln2.b": _bf(sd[f"{p}.layer_norm2.bias"], dev),
+            "qkv.w": _bf(torch.cat([sd[f"{a}.q_proj.weight"], sd[f"{a}.k_proj.weight"], sd[f"{a}.v_proj.weight"]]), dev),
+            "qkv.b": _bf(torch.cat([sd[f"{a}.q_proj.bias"], sd[f"{a}.k_proj.bias"], sd[f"{a}.v_proj.bias"]]), dev),
+            "out.w": _bf(sd[f"{a}.out_proj.weight"], dev), "out.b": _bf(sd[f"{a}.out_proj.bias"], dev),
+            "fc1.w": _bf(sd[f"{p}.mlp.fc1.weight"], dev), "fc1.b": _bf(sd[f"{p}.mlp.fc1.bias"], dev),
+            "fc2.w": _bf(sd[f"{p}.mlp.fc2.weight"], dev), "fc2.b": _bf(sd[f"{p}.mlp.fc2.bias"], dev)})
+    return out
+
+
 def _pad_patch_weight(w, dev):
     """conv [D,3,14,14] -> [D, 640] bf16 (588 real columns + zero pad, matching the im2col rows)."""
     D = w.shape[0]
@@ -57,20 +74,7 @@ class CLIPModel:
         self.device = dev
         self.logit_scale = sd["logit_scale"].float()
 
-        def layers(pfx, n):
-            out = []
-            for i in range(n):
-                p = f"{pfx}.encoder.layers.{i}"
-                a = f"{p}.self_attn"
-                out.append({
-                    "ln1.w": _bf(sd[f"{p}.layer_norm1.weight"], dev), "ln1.b": _bf(sd[f"{p}.layer_norm1.bias"], dev),
-                    "ln2.w": _bf(sd[f"{p}.layer_norm2.weight"], dev), "ln2.b": _bf(sd[f"{p}.layer_norm2.bias"], dev),
-                    "qkv.w": _bf(torch.cat([sd[f"{a}.q_proj.weight"], sd[f"{a}.k_proj.weight"], sd[f"{a}.v_proj.weight"]]), dev),
-                    "qkv.b": _bf(torch.cat([sd[f"{a}.q_proj.bias"], sd[f"{a}.k_proj.bias"], sd[f"{a}.v_proj.bias"]]), dev),
-                    "out.w": _bf(sd[f"{a}.out_proj.weight"], dev), "out.b": _bf(sd[f"{a}.out_proj.bias"], dev),
-                    "fc1.w": _bf(sd[f"{p}.mlp.fc1.weight"], dev), "fc1.b": _bf(sd[f"{p}.mlp.fc1.bias"], dev),
-                    "fc2.w": _bf(sd[f"{p}.mlp.fc2.weight"], dev), "fc2.b": _bf(sd[f"{p}.mlp.fc2.bias"], dev)})
-            return out
+        layers = lambda pfx, n: pack_clip_layers(sd, pfx, n, dev)
         act = "gelu"
         v, t = "vision_model", "text_model"
         self.v_enc = _Encoder(layers(v, cfg.v_layers), cfg.v_heads, 1e-5, act)

@@ -132,6 +132,10 @@ int advgrpo_layernorm_mod(const void* x, int64_t ldx, void* out0, void* out1, in
                           const void* w, const void* b, const void* scale0, const void* shift0,
                           const void* scale1, const void* shift1, int64_t mod_stride, int rows_per_batch,
                           int M, int D, float eps, void* stream);
+/* T5LayerNorm (transformers' T5: bf16(x * rsqrt(mean(x^2) + eps)) * w, f32 statistics, no bias): the norms of the T5-XXL
+ * text encoder called by encode_prompt (adv_grpo/diffusers_patch/train_dreambooth_lora_sd3.py:19-56,125-133). */
+int advgrpo_rmsnorm_rows(const void* x, int64_t ldx, void* out, int64_t ldo, const void* w, int M, int D, float eps,
+                         void* stream);
 /* In-place RMSNorm over 64-wide heads (SD3.5 qk_norm): rows of buf[., ld], heads at columns
  * [col0, col0 + 64*nheads); head hh is scaled by weight[(hh / heads_per_weight)*64 ...].  Row m maps
  * through (seg_rows, seg_stride, seg_off) like the GEMM output map. */
@@ -161,6 +165,12 @@ int advgrpo_attention_fwd(const void* q, const void* k, const void* v, void* o,
                           int B, int H, int Sq, int Skv, int head_dim, float scale, int causal,
                           float* lse, void* stream);
 
+/* advgrpo_attention_fwd + an additive score bias [H,Sq,Skv] f32 shared over the batch: softmax(q k^T scale + bias) v.
+ * T5 self-attention (relative position bias, scale = 1) inside encode_prompt, train_dreambooth_lora_sd3.py:98-144. */
+int advgrpo_attention_fwd_bias(const void* q, const void* k, const void* v, void* o, int64_t ldq, int64_t ldk,
+                               int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso,
+                               int B, int H, int Sq, int Skv, int head_dim, float scale, int causal,
+                               const float* bias, void* stream);
 /* Backward of the fused attention (autograd of the transformer call inside compute_log_prob,
  * scripts/train_sd3_fast_pickscore.py:233-267, reached from loss.backward() at :1165).  head_dim 64.
  * d_o: gradient w.r.t. o (same view convention, pitch lddo / bsdo); lse from the forward; delta: f32 [B,H,Sq]
