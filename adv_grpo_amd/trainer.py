@@ -53,6 +53,41 @@ class SyntheticData:
         return torch.rand(n, 3, self.res, self.res, generator=g).to(self.device)
 
 
+class PromptFileData:
+    """The real data path with the interface of SyntheticData: prompts from ``<dataset>/<split>.txt`` (TextPromptDataset,
+    TP:50-66), reference images from the ``json_path`` map + ``reference_image_path`` directory (TP:705-707,773-801,
+    decoded ahead of time by reference_images.ReferenceImageStore), embeddings from a caller-supplied
+    ``embed_fn(list[str]) -> (prompt_embeds [B,205,4096], pooled [B,2048])`` (tokenizers + text_encoders.encode_prompt)
+    and ``clip_ids_fn(list[str]) -> ids [B,77]`` for the PickScore text tower.  Embeddings are cached per prompt."""
+
+    def __init__(self, dataset_dir, json_path, reference_image_path, embed_fn, clip_ids_fn, split="train", resolution=512,
+                 device="cuda", fallback_image=None):
+        from .reference_images import ReferenceImageStore
+        with open(os.path.join(dataset_dir, f"{split}.txt"), "r") as f:
+            self.prompts = [line.strip() for line in f.readlines()]
+        self.store = ReferenceImageStore(json_path, reference_image_path, resolution, device, fallback_image)
+        self.embed_fn, self.clip_ids_fn, self.device = embed_fn, clip_ids_fn, device
+        self._cache = {}
+        self.neg = embed_fn([""])                                                          # TP:669 / TP:272
+
+    def __len__(self):
+        return len(self.prompts)
+
+    def prompt(self, idx):
+        if idx not in self._cache:
+            self._cache[idx] = self.embed_fn([self.prompts[idx]])
+        return self._cache[idx]
+
+    def clip_ids(self, idx, n):
+        return self.clip_ids_fn([self.prompts[idx]]).repeat(n, 1).to(self.device)
+
+    def prefetch(self, idxs):
+        self.store.prefetch([self.prompts[i] for i in idxs])
+
+    def reference_images(self, idx, n):
+        return self.store.get(self.prompts[idx], n)
+
+
 class JsonlLogger:
     """wandb stand-in: one JSON object per log call (same metric names as TP:941-955,975-988,1132-1183)."""
 
@@ -106,6 +141,12 @@ class Trainer:
         for i in range(c.sample.num_batches_per_epoch):
             self.sampler.set_epoch(self.epoch * c.sample.num_batches_per_epoch + i)        # TP:729
             idx = next(iter(self.sampler))[0]
+            if hasattr(self.data, "prefetch"):      # decode this and the next group's reference images during sampling
+                nxt = []
+                if i + 1 < c.sample.num_batches_per_epoch:
+                    self.sampler.set_epoch(self.epoch * c.sample.num_batches_per_epoch + i + 1)
+                    nxt = [next(iter(self.sampler))[0]]
+                self.data.prefetch([idx] + nxt)
             pe, ppe = self.data.prompt(idx)
             t0 = time.perf_counter()
             images, lats, lps, tss = pipeline_with_logprob_random(
