@@ -432,13 +432,14 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
     __syncthreads();  // hipcc drains the LDS-DMA (vmcnt 0) before the barrier
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt0 + kt + 1);
+        if (kt + 1 < nk && !(p.debug & 1)) stage(cur ^ 1, kt0 + kt + 1);
         const char* ta = smem + cur * STAGE + wm * TM * 128;
         const char* tb = smem + cur * STAGE + A_BYTES + wn * TN * 128;
         // both k-steps' fragments are requested up front into separate registers, so the LDS latency of the second
         // set is covered by the first set's MFMAs (left alone the compiler reuses one register set and waits for
         // LDS twice per tile); sched_barriers pin the order
         bf16x8_t af[2][FM], bf[2][FN];
+        if (!(p.debug & 2) || kt == 0)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -461,6 +462,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
         __syncthreads();
     }
 
+    if (p.debug & 4) { if (acc[0][0][0] != 12345.678f) return; }
     gemm_epilogue<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane, smem, wave);
 }
 
