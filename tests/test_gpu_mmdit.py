@@ -58,3 +58,16 @@ def test_mmdit_sd35_medium_512():
     assert e_hip < max(2 * e_torch, 2e-2), (e_hip, e_torch)
     for k in ("x1", "x12", "x24"):
         assert _rel(inter[k], rinter[k]) < 5e-2, (k, _rel(inter[k], rinter[k]))
+
+
+@pytest.mark.parametrize("hw,B", [(32, 4), (128, 1), (40, 3)])
+def test_mmdit_other_resolutions(hw, B):
+    """256^2 (BASELINE config 1), 1024^2 (configs 4/5: 4096 image tokens, S = 4301) and a non-power-of-two 320^2 latent
+    grid (ragged tiles everywhere) on the SD3.5-medium width with a reduced depth."""
+    from oracle.mmdit import MMDiTConfig
+    cfg = MMDiTConfig(num_layers=3, dual_attention_layers=(0, 1))
+    out, ref, tb, inter, rinter = _run(cfg, B=B, hw=hw, Nt=205, seed=21 + hw)
+    assert out.shape == (B, 16, hw, hw)
+    e_hip, e_torch = _rel(out, ref), _rel(tb, ref)
+    assert e_hip < max(2 * e_torch, 2e-2), (hw, e_hip, e_torch)
+    assert _rel(inter["x3"], rinter["x3"]) < 3e-2
