@@ -466,14 +466,20 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
     gemm_epilogue<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane, smem, wave);
 }
 
+// waves per SIMD the register allocation must leave room for: two workgroups per CU whenever their LDS fits (<= 80 KB
+// each).  Without the bound the 192x128 kernel drifted to 136 VGPRs after an unrelated epilogue change, i.e. 3 waves per
+// SIMD = ONE 8-wave workgroup per CU, and lost 25 %.
+template <int BM, int BN, int NW>
+constexpr int gemm_min_waves_per_simd() { return (2 * (BM + BN) * 64 * 2 <= 81920 ? 2 : 1) * NW / 4; }
+
 template <int BM, int BN, int WM, int WN, bool CONV>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (gemm_min_waves_per_simd<BM, BN, WM * WN>())) void gemm_bf16_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm_bf16_body<BM, BN, WM, WN, CONV>(p, blockIdx.x, blockIdx.y, smem);
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_pair_kernel(const GemmPair pp) {
+__global__ __launch_bounds__(WM * WN * 64, (gemm_min_waves_per_simd<BM, BN, WM * WN>())) void gemm_bf16_pair_kernel(const GemmPair pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = blockIdx.x;
     if (bid < pp.tiles_a) gemm_bf16_body<BM, BN, WM, WN, false>(pp.a, bid, 0, smem);
