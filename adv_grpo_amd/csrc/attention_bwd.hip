@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const AttnBwdParams
 }
 
 // ---------------------------------------------------------------- dQ
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwdParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * BW_TILE];  // K0 K1 V0 V1
     bf16_t* Ks = smem;
     bf16_t* Vs = smem + 2 * BW_TILE;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
 }
 
 // ---------------------------------------------------------------- dK, dV
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdParams p) {
     // Q0 Q1 dO0 dO1 tiles + L / D vectors for the two buffers
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * BW_TILE];
     __shared__ float lds_L[2][64], lds_D[2][64];
