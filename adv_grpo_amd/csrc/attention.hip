@@ -277,6 +277,7 @@ __device__ __forceinline__ float xor32_add(float v) { float a = v, b = v; ADVGRP
 typedef __attribute__((address_space(3))) void* att_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* att_gptr_t;
 
+template <bool BIAS>
 __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnParams p) {
     constexpr int HD = 64, NS = 3, TILE_B = ATT_KB * 128;   // 8 KiB per K or V tile
     constexpr int LOADS = 4;                                 // DMA instructions per wave per tile (2 K + 2 V)
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnPa
             v_src[i] += v_step;
         }
     };
-    const float sc = p.bias ? 1.0f : p.scale_log2e;
+    const float sc = BIAS ? 1.0f : p.scale_log2e;
     f32x4 o[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnPa
                 for (int qb = 0; qb < 2; ++qb)
                     s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb][ks], s[kb][qb], 0, 0, 0);
         }
-        if (p.bias) {   // scores <- scores * scale + bias, in base-2 units (the softmax below then uses scale 1)
+        if constexpr (BIAS) {   // scores <- scores * scale + bias, in base-2 units (the softmax below then uses scale 1)
             asm volatile("; biased tile" ::: "memory");
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
@@ -521,7 +522,8 @@ int attention_fwd(const AttnParams& p, int B, int head_dim, hipStream_t s) {
     if (use_glds < 0) { const char* e = getenv("ADVGRPO_ATTN_REGSTAGE"); use_glds = (e && atoi(e)) ? 0 : 1; }
     const bool o16 = p.ldo % 8 == 0 && p.bso % 8 == 0 && (reinterpret_cast<uintptr_t>(p.o) & 15) == 0;   // 16-byte row stores
     ADVGRPO_CHECK(!p.bias || (use_glds && o16), "attention: the score bias needs the LDS-DMA kernel (16-byte aligned output rows)");
-    if (head_dim == 64 && use_glds && o16) hipLaunchKernelGGL(attention_fwd_glds_kernel, grid, dim3(256), 0, s, p);
+    if (head_dim == 64 && use_glds && o16 && p.bias) hipLaunchKernelGGL(attention_fwd_glds_kernel<true>, grid, dim3(256), 0, s, p);
+    else if (head_dim == 64 && use_glds && o16) hipLaunchKernelGGL(attention_fwd_glds_kernel<false>, grid, dim3(256), 0, s, p);
     else if (head_dim == 64) hipLaunchKernelGGL(attention_fwd_kernel<64>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attention_fwd_kernel<80>, grid, dim3(256), 0, s, p);
     ADVGRPO_LAUNCH_CHECK();
