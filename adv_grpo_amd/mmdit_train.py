@@ -305,16 +305,21 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             b, s = self.blocks[i], ctx["blocks"][i]
             kx, kc = ("x", i), ("c", i)
             # ---- image MLP
+            # (the text-stream data-gradient GEMMs ride in the launches of their image-stream twins, as in the forward)
             dyg = ops.gate_mul(dx, mod(kx, 5), Ni)
-            dpre = ops.gemm_train(dyg, b["ff2.wT"], act="dgelu_tanh", aux_in=s["pre"])
-            dnxm = ops.gemm(dpre, b["ff1.wT"])
-            dx1 = ops.layernorm_mod_bwd(s["x_mid"], dnxm, scale0=mod(kx, 4), dres=dx, rows_per_batch=Ni)
-            # ---- text MLP
+            d2 = [ops.gemm_desc(dyg, b["ff2.wT"], act="dgelu_tanh", aux_in=s["pre"])]
             if not b["last"]:
                 dcyg = ops.gate_mul(dc, mod(kc, 5), Nt)
-                dcpre = ops.gemm_train(dcyg, b["cff2.wT"], act="dgelu_tanh", aux_in=s["cpre"])
-                dncm = ops.gemm(dcpre, b["cff1.wT"])
-                dc1 = ops.layernorm_mod_bwd(s["c_mid"], dncm, scale0=mod(kc, 4), dres=dc, rows_per_batch=Nt)
+                d2.append(ops.gemm_desc(dcyg, b["cff2.wT"], act="dgelu_tanh", aux_in=s["cpre"]))
+            dpres = ops.gemm_grouped(d2)
+            d1 = [ops.gemm_desc(dpres[0], b["ff1.wT"])]
+            if not b["last"]:
+                d1.append(ops.gemm_desc(dpres[1], b["cff1.wT"]))
+            dmid = ops.gemm_grouped(d1)
+            dx1 = ops.layernorm_mod_bwd(s["x_mid"], dmid[0], scale0=mod(kx, 4), dres=dx, rows_per_batch=Ni)
+            # ---- text MLP
+            if not b["last"]:
+                dc1 = ops.layernorm_mod_bwd(s["c_mid"], dmid[1], scale0=mod(kc, 4), dres=dc, rows_per_batch=Nt)
             # ---- second (image-only) attention of the dual blocks
             dnx2 = None
             if b["dual"]:
@@ -330,12 +335,14 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             # ---- joint attention
             datt = torch.zeros(B * S, D, dtype=bf16, device=dev) if b["last"] else torch.empty(B * S, D, dtype=bf16, device=dev)
             dyo = ops.gate_mul(dx1, mod(kx, 2), Ni)                             # grad of to_out.0 output
-            ops.gemm(dyo, b["out.wT"], out=datt, seg=(Ni, S, 0))
+            douts = [ops.gemm_desc(dyo, b["out.wT"], out=datt, seg=(Ni, S, 0))]
             att2d = s["att"].view(B * S, D)
-            self._lora_wgrad((i, "out"), att2d, B * Ni, (Ni, S, 0), dyo, None)
             if not b["last"]:
                 dyc = ops.gate_mul(dc1, mod(kc, 2), Nt)
-                ops.gemm(dyc, b["cout.wT"], out=datt, seg=(Nt, S, Ni))
+                douts.append(ops.gemm_desc(dyc, b["cout.wT"], out=datt, seg=(Nt, S, Ni)))
+            ops.gemm_grouped(douts)
+            self._lora_wgrad((i, "out"), att2d, B * Ni, (Ni, S, 0), dyo, None)
+            if not b["last"]:
                 self._lora_wgrad((i, "cout"), att2d, B * Nt, (Nt, S, Ni), dyc, None)
             q3 = s["qkv"].view(B, S, 3 * D)
             dqkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
@@ -344,8 +351,8 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                               d3[:, :, :D], d3[:, :, D:2 * D], d3[:, :, 2 * D:])
             ops.rmsnorm_heads_bwd(dqkv, s["qkv"], s["rs"], 0, 2 * H, b["rms_x"], H, seg=(Ni, S, 0), M=B * Ni)
             ops.rmsnorm_heads_bwd(dqkv, s["qkv"], s["rs"], 0, 2 * H, b["rms_c"], H, seg=(Nt, S, Ni), M=B * Nt)
-            dnx = ops.gemm(dqkv, b["qkv.wT"], a_seg=(Ni, S, 0), M=B * Ni)
-            dnc = ops.gemm(dqkv, b["cqkv.wT"], a_seg=(Nt, S, Ni), M=B * Nt)
+            dnx, dnc = ops.gemm_grouped([ops.gemm_desc(dqkv, b["qkv.wT"], a_seg=(Ni, S, 0), M=B * Ni),
+                                         ops.gemm_desc(dqkv, b["cqkv.wT"], a_seg=(Nt, S, Ni), M=B * Nt)])
             self._lora_wgrad((i, "qkv"), s["nx"], B * Ni, None, dqkv, (Ni, S, 0))
             self._lora_wgrad((i, "cqkv"), s["nc"], B * Nt, None, dqkv, (Nt, S, Ni))
             # ---- first norms
