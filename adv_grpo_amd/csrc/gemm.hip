@@ -806,9 +806,11 @@ static int launch_pipe_pair(const GemmParams& a, const GemmParams& b, hipStream_
     return 0;
 }
 
-// ---- tile variants.  id: 0 = 128x128 (4 waves), 1 = 128x64, 2 = 64x128, 3 = 256x256 (8 waves, 128 KB LDS,
-// one workgroup per CU), 6 = 256x128 (8 waves); +conv: 4 = 128x128, 5 = 128x64, 7 = 256x256, 8 = 256x128.
-// The choice maximises (how full the last round of workgroups is) x (measured relative speed of the tile).
+// ---- tile variants (ids as accepted by ADVGRPO_GEMM_FORCE / advgrpo_gemm_variant):
+//   two-stage BK=64 kernel: 0 = 128x128 (4 waves), 1 = 128x64, 2 = 64x128, 14 = 128x128 (8 waves 2x4), 15 = 128x128 (8 waves
+//   4x2), 26 = 192x128, 27 = 128x192 (8 waves 2x4, 48-wide wave tiles); conv: 4 = 128x128 (4 waves), 5 = 128x64, 18 = 128x128
+//   (8 waves); BK=32 ring kernel: 11 = 128x128 (8 waves), 17 = 256x128; ping-pong kernel: 20 = 256x256, 21 / 23 = 256x128
+//   with a 4- / 3-slot ring.  Variants that lost every comparison (256x256 two-stage, 4-wave ring tiles, ...) were dropped.
 static int g_force_variant = -2;
 static int gemm_variant(int M, int N, int K, int batch, int conv, int plain) {   // batch includes the split-K factor
     if (g_force_variant == -2) {
@@ -825,15 +827,12 @@ static int gemm_variant(int M, int N, int K, int batch, int conv, int plain) {  
     if (N <= 64) return conv ? 5 : 1;
     if (g_force_variant >= 0) {
         const int f = g_force_variant;
-        if (conv) return f == 3 ? 7 : (f == 6 ? 8 : 4);
+        if (conv) return f == 18 ? 18 : 4;
         return f;
     }
     if (g_force_variant == -3) return conv ? 4 : 0;   // (experiments: ADVGRPO_GEMM_FORCE=-3 = always 128x128 2-stage)
-    // measured on MI355X (scripts/bench_gemm.py, random data): the 4-wave 128x128 tile wins on the MMDiT / ViT
-    // shapes (M = 16384 / 3280, N, K in {1536, 4608, 6144}); the 8-wave 256x256 tile only on large square problems.
     (void)rounds_eff;
     if (conv) return 18;
-    if (M >= 4096 && N >= 8192 && rounds_eff(256, 256, 256) > 0.85) return 3;
     if (M <= 64) return 2;
     // measured (scripts/bench_gemm.py): 8 waves per workgroup (16 waves per CU) beat 4 on every MMDiT / ViT shape;
     // image-stream Linears (M = 16384 rows): the 192x128 tile (80 KB of LDS: still two workgroups per CU, 17 % fewer
@@ -882,7 +881,7 @@ static int gemm_prepare(GemmParams& p) {
     }
     if (p.rms_w) {   // the fused QK-norm lives in the row-coalesced epilogue of the 64-wide wave tiles only
         auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-        const bool narrow = variant == 1 || variant == 5 || variant == 13 || variant == 14 || variant == 22 || variant == 24 || variant == 27;
+        const bool narrow = variant == 1 || variant == 5 || variant == 14 || variant == 27;
         ADVGRPO_CHECK(!narrow && !p.conv && p.splitk == 1 && p.batch == 1 && p.N % 64 == 0 && p.ldc % 8 == 0 &&
                           p.out_dtype == ADVGRPO_BF16 && a16(p.C) && a16(p.bias) && a16(p.rms_w) && p.rms_nheads > 0 &&
                           p.rms_hpw > 0 && !p.gate && !p.residual && !p.aux_out && !p.aux_in && p.act == ACT_NONE,
@@ -915,29 +914,17 @@ int gemm_bf16(const GemmParams& p_in, hipStream_t s) {
         case 0: return launch<128, 128, 2, 2, false>(p, s);
         case 1: return launch<128, 64, 2, 2, false>(p, s);
         case 2: return launch<64, 128, 2, 2, false>(p, s);
-        case 3: return launch<256, 256, 2, 4, false>(p, s);
-        case 6: return launch<256, 128, 4, 2, false>(p, s);
         case 4: return launch<128, 128, 2, 2, true>(p, s);
         case 5: return launch<128, 64, 2, 2, true>(p, s);
-        case 7: return launch<256, 256, 2, 4, true>(p, s);
-        case 8: return launch<256, 128, 4, 2, true>(p, s);
-        case 9: return launch_pipe<128, 128, 4, 2, 2>(p, s);
-        case 10: return launch_pipe<128, 128, 3, 2, 2>(p, s);
         case 11: return launch_pipe<128, 128, 3, 4, 2>(p, s);
-        case 12: return launch_pipe<128, 128, 4, 4, 2>(p, s);
-        case 13: return launch_pipe<128, 128, 3, 2, 4>(p, s);
         case 14: return launch<128, 128, 2, 4, false>(p, s);
         case 18: return launch<128, 128, 4, 2, true>(p, s);
         case 20: return launch_pp<256, 256, 4, 2, 4>(p, s);
         case 21: return launch_pp<256, 128, 4, 4, 2>(p, s);
-        case 22: return launch_pp<128, 128, 4, 2, 4>(p, s);
         case 23: return launch_pp<256, 128, 3, 4, 2>(p, s);
-        case 24: return launch_pp<128, 128, 3, 2, 4>(p, s);
-        case 25: return launch_pp<128, 128, 3, 4, 2>(p, s);
         case 15: return launch<128, 128, 4, 2, false>(p, s);
         case 26: return launch<192, 128, 4, 2, false>(p, s);
         case 27: return launch<128, 192, 2, 4, false>(p, s);
-        case 16: return launch_pipe<128, 256, 3, 2, 4>(p, s);
         case 17: return launch_pipe<256, 128, 3, 4, 2>(p, s);
     }
     set_error("gemm: bad variant %d", variant);

@@ -8,18 +8,13 @@ from . import _lib
 ACT = {None: 0, "none": 0, "gelu_tanh": 1, "gelu_new": 1, "gelu": 2, "gelu_erf": 2, "silu": 3, "quick_gelu": 4}
 
 GEMM_VARIANTS = {0: "gemm_bf16_kernel<128,128,2,2,false>", 1: "gemm_bf16_kernel<128,64,2,2,false>",
-                 2: "gemm_bf16_kernel<64,128,2,2,false>", 3: "gemm_bf16_kernel<256,256,2,4,false>",
-                 6: "gemm_bf16_kernel<256,128,4,2,false>", 4: "gemm_bf16_kernel<128,128,2,2,true>",
-                 5: "gemm_bf16_kernel<128,64,2,2,true>", 7: "gemm_bf16_kernel<256,256,2,4,true>",
-                 8: "gemm_bf16_kernel<256,128,4,2,true>", 9: "gemm_bf16_pipe_kernel<128,128,4,2,2>", 10: "gemm_bf16_pipe_kernel<128,128,3,2,2>",
-                 11: "gemm_bf16_pipe_kernel<128,128,3,4,2>", 12: "gemm_bf16_pipe_kernel<128,128,4,4,2>",
-                 13: "gemm_bf16_pipe_kernel<128,128,3,2,4>", 14: "gemm_bf16_kernel<128,128,2,4,false>",
-                 15: "gemm_bf16_kernel<128,128,4,2,false>", 16: "gemm_bf16_pipe_kernel<128,256,3,2,4>",
+                 2: "gemm_bf16_kernel<64,128,2,2,false>", 4: "gemm_bf16_kernel<128,128,2,2,true>",
+                 5: "gemm_bf16_kernel<128,64,2,2,true>", 11: "gemm_bf16_pipe_kernel<128,128,3,4,2>",
+                 14: "gemm_bf16_kernel<128,128,2,4,false>", 15: "gemm_bf16_kernel<128,128,4,2,false>",
                  17: "gemm_bf16_pipe_kernel<256,128,3,4,2>", 18: "gemm_bf16_kernel<128,128,4,2,true>",
                  20: "gemm_bf16_pp_kernel<256,256,4,2,4>", 21: "gemm_bf16_pp_kernel<256,128,4,4,2>",
-                 22: "gemm_bf16_pp_kernel<128,128,4,2,4>", 23: "gemm_bf16_pp_kernel<256,128,3,4,2>",
-                 24: "gemm_bf16_pp_kernel<128,128,3,2,4>", 25: "gemm_bf16_pp_kernel<128,128,3,4,2>",
-                 26: "gemm_bf16_kernel<192,128,4,2,false>", 27: "gemm_bf16_kernel<128,192,2,4,false>"}
+                 23: "gemm_bf16_pp_kernel<256,128,3,4,2>", 26: "gemm_bf16_kernel<192,128,4,2,false>",
+                 27: "gemm_bf16_kernel<128,192,2,4,false>"}
 # bench.py sets this to a list to collect (kernel name, flops, start event, end event) per GEMM launch;
 # events are recorded on the stream the kernel is launched on (torch's current stream).
 PROFILE = None
