@@ -5,21 +5,22 @@
 // This one kernel family carries every dense contraction of the hot path: the MMDiT
 // QKV / out-proj / MLP / adaLN linears (reference call sites
 // sd3_pipeline_with_logprob_fast.py:630-637 and train_sd3_fast_pickscore.py:235-255, which run
-// diffusers' SD3Transformer2DModel), the ViT reward towers, and (through the implicit-GEMM A
-// loader in conv.hip) the VAE decoder.
+// diffusers' SD3Transformer2DModel), the ViT reward towers, the text encoders, and (through the implicit-GEMM A
+// loader, CONV = true) the VAE decoder.
 //
-// CDNA4 mapping
-//   * 256 threads = 4 wave64 as 2x2; block tile BM x BN x 64, wave tile (BM/2)x(BN/2) built from
-//     v_mfma_f32_16x16x32_bf16 fragments.
-//   * HBM -> LDS by global_load_lds_dwordx4 (16 B/lane, no VGPR round trip), double-buffered;
-//     the next tile's DMA is issued before the current tile's MFMAs.
-//   * LDS image is lane-linear per wave instruction (8 rows x 128 B); bank conflicts of the
-//     column-slice ds_read_b128 are removed by an XOR swizzle applied to the per-lane SOURCE
-//     chunk (chunk ^= row & 7) and again on the read (guide rule 21).
-//   * MFMA is issued with operands swapped (W fragment as A, activation fragment as B) so each
-//     lane ends up with 4 CONSECUTIVE output columns of one row: 8-byte bf16x4 stores and
-//     vector loads of bias / gate / residual in the fused epilogue.
-//   * block ids are remapped so each XCD (private 4 MiB L2) walks a contiguous strip of tiles.
+// CDNA4 mapping (two-stage kernel, the one the dispatcher uses; the ring / ping-pong kernels below share its pieces)
+//   * 512 threads = 8 wave64; block tile BM x BN x 64 (192x128 for the image-stream Linears, 128x128 otherwise), wave
+//     tiles of v_mfma_f32_16x16x32_bf16 fragments; 80 / 64 KB of LDS and <= 128 VGPRs so that TWO workgroups share a CU
+//     (the register bound is explicit in __launch_bounds__: drifting past it once halved the occupancy).
+//   * HBM -> LDS by global_load_lds_dwordx4 (16 B/lane, no VGPR round trip) in whole 128-byte rows, double-buffered;
+//     the next tile's DMA is issued before the current tile's fragment reads and MFMAs.
+//   * LDS image is lane-linear per wave instruction (8 rows x 128 B); bank conflicts of the column-slice ds_read_b128
+//     are removed by an XOR swizzle applied to the per-lane SOURCE chunk (chunk ^= row & 7) and again on the read.
+//   * MFMA is issued with operands swapped (W fragment as A, activation fragment as B): a lane owns 4 consecutive output
+//     columns of one row; the epilogue then bounces 16-row slabs through LDS to get 8 consecutive columns per lane and
+//     whole 128-byte rows per 8 lanes (16-byte loads of bias / gate / residual, 16-byte stores).
+//   * block ids are remapped so each XCD (private 4 MiB L2) walks a contiguous range of tiles, in groups of 4 row-tiles.
+//   * a launch can carry two problems (GemmPair): the text-stream Linear rides in the tail of the image-stream one.
 //   * rows >= M / N are clamped on load and masked on store; K must be a multiple of 64.
 #include <stdlib.h>
 
