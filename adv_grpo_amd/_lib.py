@@ -14,7 +14,7 @@ F32, BF16, F64 = 0, 1, 2
 SDE_EPS, SDE_PHILOX, SDE_REPLAY = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadvgrpo_hip.so")
+LIB_PATH = os.environ.get("ADVGRPO_LIB") or os.path.join(_HERE, "libadvgrpo_hip.so")   # override: A/B runs of two builds
 
 _P = c_void_p
 

@@ -123,6 +123,26 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4 (&
     const int n = n0 + wn * TN + c8;
     float bias8[8];
     if (p.bias && n < p.N) unpack8(*reinterpret_cast<const uint4*>(p.bias + n), bias8);
+    // The residual rows of the whole wave tile are requested before the first slab is bounced: left inside the slab loop
+    // each of these (L2 / HBM latency) loads was waited for on the spot, a dozen vmcnt(0) per tile.  (The gate vectors
+    // stay in the loop: a few KB per launch, L1-resident; prefetching them too would spill at the 128-VGPR bound.)
+    uint4 res_q[FM][PASSES];
+    static_for<FM>([&](auto idx) {
+        constexpr int i = decltype(idx)::value;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int row = ps * RPP + orow_l;
+            const int m = m0 + wm * TM + i * 16 + row;
+            res_q[i][ps] = uint4{0u, 0u, 0u, 0u};
+            if (!p.residual || (64 % LPR != 0 && lane >= LPR * RPP) || (16 % RPP != 0 && row >= 16) || m >= p.M || n >= p.N) continue;
+            int64_t orow = m;
+            if (p.seg_rows > 0) {
+                const int bidx = m / p.seg_rows;
+                orow = (int64_t)bidx * p.seg_stride + p.seg_off + (m - bidx * p.seg_rows);
+            }
+            res_q[i][ps] = *reinterpret_cast<const uint4*>(p.residual + (int64_t)bz * p.strideR + orow * p.ldr + n);
+        }
+    });
     static_for<FM>([&](auto idx) {
         constexpr int i = decltype(idx)::value;
 #pragma unroll
@@ -190,7 +210,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4 (&
             }
             if (p.residual) {
                 float r[8];
-                unpack8(*reinterpret_cast<const uint4*>(p.residual + (int64_t)bz * p.strideR + orow * p.ldr + n), r);
+                unpack8(res_q[i][ps], r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += r[e];
             }
