@@ -71,3 +71,15 @@ def test_mmdit_other_resolutions(hw, B):
     e_hip, e_torch = _rel(out, ref), _rel(tb, ref)
     assert e_hip < max(2 * e_torch, 2e-2), (hw, e_hip, e_torch)
     assert _rel(inter["x3"], rinter["x3"]) < 3e-2
+
+
+def test_mmdit_sd35_large_width():
+    """The SD3.5-large family (BASELINE config 4: D = 2432 = 38 heads x 64, no dual-attention blocks, 192^2 position
+    table) on the same kernels, reduced depth: a width that is not a multiple of 128."""
+    from oracle.mmdit import MMDiTConfig
+    cfg = MMDiTConfig(num_layers=2, num_heads=38, pos_embed_max_size=192, dual_attention_layers=())
+    out, ref, tb, inter, rinter = _run(cfg, B=2, hw=64, Nt=205, seed=77)
+    assert out.shape == (2, 16, 64, 64)
+    e_hip, e_torch = _rel(out, ref), _rel(tb, ref)
+    assert e_hip < max(2 * e_torch, 2e-2), (e_hip, e_torch)
+    assert _rel(inter["x2"], rinter["x2"]) < 3e-2
