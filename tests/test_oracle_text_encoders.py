@@ -68,3 +68,19 @@ def test_oracle_matches_reference_encode_prompt():
         pe, pooled = te.encode_prompt(L, G, T, ids, ids, ids_t5)
     assert pe.shape == pe_ref.shape == (2, 77 + 40, 256) and pooled.shape == pooled_ref.shape == (2, 48 + 80)
     assert torch.allclose(pe, pe_ref, atol=2e-5, rtol=1e-4) and torch.allclose(pooled, pooled_ref, atol=2e-5, rtol=1e-4)
+
+
+def test_clip_legacy_eos_rule_matches_transformers():
+    """The released CLIP-L / CLIP-G configs of SD3 carry eos_token_id = 2, for which transformers pools at argmax(ids)
+    (the highest id = the real EOS token 49407) instead of the first occurrence of eos_token_id."""
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+    from oracle import text_encoders as te
+    torch.manual_seed(7)
+    m = CLIPTextModelWithProjection(CLIPTextConfig(vocab_size=99, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                                                   num_attention_heads=2, max_position_embeddings=77, projection_dim=32,
+                                                   hidden_act="quick_gelu", eos_token_id=2, bos_token_id=0, pad_token_id=1)).eval()
+    ids = torch.randint(3, 97, (2, 77)); ids[0, 9] = 98; ids[0, 10:] = 98; ids[1, 40:] = 98     # 98 plays the role of 49407
+    with torch.no_grad():
+        out = m(ids, output_hidden_states=True)
+        pen, pooled = te.clip_text_hidden_and_pooled({k: v.float() for k, v in m.state_dict().items()}, 2, 2, "quick_gelu", 2, ids)
+    assert torch.allclose(pen, out.hidden_states[-2], atol=2e-5, rtol=1e-4) and torch.allclose(pooled, out[0], atol=2e-5, rtol=1e-4)
