@@ -88,3 +88,22 @@ def test_attention_bias_and_rmsnorm_rows_vs_torch():
     xr = x.float()
     want = w * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16)
     assert torch.equal(y, want)
+
+
+def test_encode_prompt_matches_reference_golden():
+    """HIP path vs the committed outputs of the reference's encode_prompt (tests/golden/text_encoders.npz)."""
+    import os
+    import numpy as np
+    from adv_grpo_amd import text_encoders as te
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "text_encoders.npz"))
+    sd = {"l": {}, "g": {}, "t": {}}
+    for k in g.files:
+        if "/" in k:
+            tag, name = k.split("/", 1)
+            sd[tag][name] = torch.from_numpy(g[k]).view(torch.bfloat16).float()
+    ids, ids_t5 = torch.from_numpy(g["ids"]), torch.from_numpy(g["ids_t5"])
+    pe, pooled = te.encode_prompt(te.CLIPTextEncoder(sd["l"], 2, 1, "quick_gelu", 98), te.CLIPTextEncoder(sd["g"], 2, 2, "gelu", 98),
+                                  te.T5Encoder(sd["t"], 2, 1), ids, ids, ids_t5)
+    want_pe, want_pooled = torch.from_numpy(g["prompt_embeds"]), torch.from_numpy(g["pooled"])
+    assert pe.shape == want_pe.shape and pooled.shape == want_pooled.shape
+    assert _rel(pe[:, :77], want_pe[:, :77]) < 2e-2 and _rel(pe[:, 77:], want_pe[:, 77:]) < 2e-2 and _rel(pooled, want_pooled) < 2e-2

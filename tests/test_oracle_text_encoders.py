@@ -84,3 +84,24 @@ def test_clip_legacy_eos_rule_matches_transformers():
         out = m(ids, output_hidden_states=True)
         pen, pooled = te.clip_text_hidden_and_pooled({k: v.float() for k, v in m.state_dict().items()}, 2, 2, "quick_gelu", 2, ids)
     assert torch.allclose(pen, out.hidden_states[-2], atol=2e-5, rtol=1e-4) and torch.allclose(pooled, out[0], atol=2e-5, rtol=1e-4)
+
+
+def _load_text_golden():
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "text_encoders.npz"))
+    sd = {"l": {}, "g": {}, "t": {}}
+    for k in g.files:
+        if "/" in k:
+            tag, name = k.split("/", 1)
+            sd[tag][name] = torch.from_numpy(g[k]).view(torch.bfloat16).float()
+    return g, sd
+
+
+def test_oracle_matches_committed_reference_golden():
+    """tests/golden/text_encoders.npz = outputs of the reference's encode_prompt (made by make_golden_text.py)."""
+    from oracle import text_encoders as te
+    g, sd = _load_text_golden()
+    ids, ids_t5 = torch.from_numpy(g["ids"]), torch.from_numpy(g["ids_t5"])
+    pe, pooled = te.encode_prompt((sd["l"], 2, 1, "quick_gelu", 98), (sd["g"], 2, 2, "gelu", 98), (sd["t"], 2, 1, 64), ids, ids, ids_t5)
+    assert torch.allclose(pe, torch.from_numpy(g["prompt_embeds"]), atol=2e-5, rtol=1e-4)
+    assert torch.allclose(pooled, torch.from_numpy(g["pooled"]), atol=2e-5, rtol=1e-4)
