@@ -6,6 +6,8 @@ transformer into ``<save_dir>/checkpoints/checkpoint-<step>/lora``; ``config.tra
   adapter_model.safetensors : "base_model.model.<module path>.lora_A.weight" [r, in], "...lora_B.weight" [out, r]
                               (the adapter name "default" is stripped on save)
   adapter_config.json       : LoraConfig fields (peft_type, r, lora_alpha, target_modules, init_lora_weights, ...).
+PEFT cannot be imported here, so the layout is restated from its documented on-disk format and is NOT pinned against a
+file written by PEFT itself ("format unpinned"; the round trip and the key / config contents are tested).
 These functions are host-side format code: tensors in, files out (and back); they never touch the GPU."""
 import json
 import os
