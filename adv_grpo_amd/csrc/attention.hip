@@ -35,6 +35,7 @@ struct AttnParams {
     int causal;
     float* lse;                   // optional [B,H,Sq]: base-2 log-sum-exp of the scaled scores (for backward)
     const float* bias;            // optional additive score bias [H,Sq,Skv] f32 (T5 relative position bias), head dim 64 only
+    int nqb, nwg, xcd_local;      // query blocks per (b,h); workgroups in the 1-D grid; XCD-local block order (common.hpp)
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -59,8 +60,9 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, t = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * ATT_QB + wave * 32;
+    int qblk, h, b;
+    xcd_local_bh(p.nqb, p.H, p.nwg, p.xcd_local, qblk, h, b);
+    const int q0 = qblk * ATT_QB + wave * 32;
 
     const bf16_t* qp = p.q + (int64_t)b * p.bsq + h * HD;
     const bf16_t* kp = p.k + (int64_t)b * p.bsk + h * HD;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
 
     int kv_end = p.Skv;
     if (p.causal) {  // keys <= last query of the workgroup
-        const int last_q = min(blockIdx.x * ATT_QB + ATT_QB, p.Sq) - 1;
+        const int last_q = min(qblk * ATT_QB + ATT_QB, p.Sq) - 1;
         kv_end = min(kv_end, last_q + 1);
     }
     const int nt = (kv_end + ATT_KB - 1) / ATT_KB;
@@ -285,8 +287,9 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnPa
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, t = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * ATT_QB + wave * 32;
+    int qblk, h, b;
+    xcd_local_bh(p.nqb, p.H, p.nwg, p.xcd_local, qblk, h, b);
+    const int q0 = qblk * ATT_QB + wave * 32;
     const bf16_t* qp = p.q + (int64_t)b * p.bsq + h * HD;
     const bf16_t* kp = p.k + (int64_t)b * p.bsk + h * HD;
     const bf16_t* vp = p.v + (int64_t)b * p.bsv + h * HD;
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnPa
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
 
     int kv_end = p.Skv;
-    if (p.causal) kv_end = min(kv_end, min(blockIdx.x * ATT_QB + ATT_QB, p.Sq));
+    if (p.causal) kv_end = min(kv_end, min(qblk * ATT_QB + ATT_QB, p.Sq));
     const int nt = (kv_end + ATT_KB - 1) / ATT_KB;
     // fragment read offsets (bytes)
     int k_off[2];
@@ -510,16 +513,23 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnPa
     }
 }
 
-int attention_fwd(const AttnParams& p, int B, int head_dim, hipStream_t s) {
+int attention_fwd(const AttnParams& p_in, int B, int head_dim, hipStream_t s) {
+    AttnParams p = p_in;
     ADVGRPO_CHECK(head_dim == 64 || head_dim == 80, "attention: head_dim %d not supported (64, 80)", head_dim);
     ADVGRPO_CHECK(p.q && p.k && p.v && p.o, "attention: null pointer");
     ADVGRPO_CHECK(p.Sq > 0 && p.Skv > 0 && p.H > 0 && B > 0, "attention: bad shape");
     ADVGRPO_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0,
                   "attention: row pitches must keep 16-byte (q,k,v) / 8-byte (o) alignment");
     ADVGRPO_CHECK(!p.bias || head_dim == 64, "attention: the score bias is implemented for head dim 64");
-    dim3 grid((p.Sq + ATT_QB - 1) / ATT_QB, p.H, B);
-    static int use_glds = -1;
+    static int use_glds = -1, xcd_local = -1;
     if (use_glds < 0) { const char* e = getenv("ADVGRPO_ATTN_REGSTAGE"); use_glds = (e && atoi(e)) ? 0 : 1; }
+    if (xcd_local < 0) { const char* e = getenv("ADVGRPO_ATTN_NO_XCD"); xcd_local = (e && atoi(e)) ? 0 : 1; }   // A/B knob
+    p.nqb = (p.Sq + ATT_QB - 1) / ATT_QB;
+    const int64_t nwg = (int64_t)p.nqb * p.H * B;
+    ADVGRPO_CHECK(nwg < (1ll << 31), "attention: grid too large");
+    p.nwg = (int)nwg;
+    p.xcd_local = xcd_local;
+    dim3 grid((unsigned)nwg);
     const bool o16 = p.ldo % 8 == 0 && p.bso % 8 == 0 && (reinterpret_cast<uintptr_t>(p.o) & 15) == 0;   // 16-byte row stores
     ADVGRPO_CHECK(!p.bias || (use_glds && o16), "attention: the score bias needs the LDS-DMA kernel (16-byte aligned output rows)");
     if (head_dim == 64 && use_glds && o16 && p.bias) hipLaunchKernelGGL(attention_fwd_glds_kernel<true>, grid, dim3(256), 0, s, p);

@@ -15,6 +15,8 @@
 // (with the same consistent permutation of the contraction index as the forward kernel), the "transposed"
 // operands (K^T, dO^T, Q^T) come from row-major LDS tiles through ds_read_b64_tr_b16, and the accumulators are
 // kept transposed so each lane ends with 4 consecutive d of one row: 8-byte stores.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "gemm.hpp"
 
@@ -28,6 +30,7 @@ struct AttnBwdParams {
     int64_t bsq, bsk, bsv, bso, bsdo, bsdq;
     int H, Sq, Skv;
     float scale, scale_log2e;
+    int xcd_local;                // XCD-local block order (common.hpp xcd_local_bh)
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -89,8 +92,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwdParams
     bf16_t* Vs = smem + 2 * BW_TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, t = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    int qblk, h, b;
+    xcd_local_bh((p.Sq + 127) / 128, p.H, (int)gridDim.x, p.xcd_local, qblk, h, b);
+    const int q0 = qblk * 128 + wave * 32;
     const bf16_t* qp = p.q + (int64_t)b * p.bsq + h * 64;
     const bf16_t* kp = p.k + (int64_t)b * p.bsk + h * 64;
     const bf16_t* vp = p.v + (int64_t)b * p.bsv + h * 64;
@@ -215,8 +219,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
     bf16_t* Os = smem + 2 * BW_TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, t = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int k0 = blockIdx.x * 128 + wave * 32;           // this wave's 32 keys
+    int kblk, h, b;
+    xcd_local_bh((p.Skv + 127) / 128, p.H, (int)gridDim.x, p.xcd_local, kblk, h, b);
+    const int k0 = kblk * 128 + wave * 32;                 // this wave's 32 keys
     const bf16_t* qp = p.q + (int64_t)b * p.bsq + h * 64;
     const bf16_t* kp = p.k + (int64_t)b * p.bsk + h * 64;
     const bf16_t* vp = p.v + (int64_t)b * p.bsv + h * 64;
@@ -374,9 +379,14 @@ extern "C" int advgrpo_attention_bwd(const void* q, const void* k, const void* v
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)(((int64_t)B * Sq + 3) / 4)), dim3(256), 0, s, p, B);
     ADVGRPO_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Sq + 127) / 128, H, B), dim3(256), 0, s, p);
+    static int xcd_local = -1;
+    if (xcd_local < 0) { const char* e = getenv("ADVGRPO_ATTN_NO_XCD"); xcd_local = (e && atoi(e)) ? 0 : 1; }
+    p.xcd_local = xcd_local;
+    ADVGRPO_CHECK((int64_t)((Sq + 127) / 128) * H * B < (1ll << 31) && (int64_t)((Skv + 127) / 128) * H * B < (1ll << 31),
+                  "attention_bwd: grid too large");
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)((Sq + 127) / 128) * H * B), dim3(256), 0, s, p);
     ADVGRPO_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((Skv + 127) / 128, H, B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)((Skv + 127) / 128) * H * B), dim3(256), 0, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

@@ -93,6 +93,22 @@ __device__ inline float block_sum(float v, float* smem) {
     return r;
 }
 
+// bijective XCD remap: consecutive remapped ids live on one XCD (observed placement b % 8)
+__device__ inline int xcd_remap(int bid, int nwg) {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+// 1-D grid of nx * H * B workgroups -> (x, h, b) with x fastest in the REMAPPED id: all nx blocks of one (b, h), and runs
+// of consecutive heads, execute on one XCD and share that head's K / V (or Q / dO) in the XCD's private 4 MB L2.
+// With a plain 3-D grid the hardware deals consecutive x round-robin over the 8 XCDs and every L2 fetches the head itself.
+__device__ __forceinline__ void xcd_local_bh(int nx, int H, int nwg, bool local, int& x, int& h, int& b) {
+    const int id = local ? xcd_remap(blockIdx.x, nwg) : (int)blockIdx.x;
+    x = id % nx;
+    const int bh = id / nx;
+    h = bh % H;
+    b = bh / H;
+}
+
 inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 inline int dtype_size(int dt) { return dt == ADVGRPO_BF16 ? 2 : (dt == ADVGRPO_F64 ? 8 : 4); }
 
