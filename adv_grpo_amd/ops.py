@@ -14,7 +14,7 @@ GEMM_VARIANTS = {0: "gemm_bf16_kernel<128,128,2,2,false>", 1: "gemm_bf16_kernel<
                  17: "gemm_bf16_pipe_kernel<256,128,3,4,2>", 18: "gemm_bf16_kernel<128,128,4,2,true>",
                  20: "gemm_bf16_pp_kernel<256,256,4,2,4>", 21: "gemm_bf16_pp_kernel<256,128,4,4,2>",
                  23: "gemm_bf16_pp_kernel<256,128,3,4,2>", 26: "gemm_bf16_kernel<192,128,4,2,false>",
-                 27: "gemm_bf16_kernel<128,192,2,4,false>", 30: "gemm8p_kernel<false>"}
+                 27: "gemm_bf16_kernel<128,192,2,4,false>", 30: "gemm8p_kernel"}
 # bench.py sets this to a list to collect (kernel name, flops, start event, end event) per GEMM launch;
 # events are recorded on the stream the kernel is launched on (torch's current stream).
 PROFILE = None
@@ -127,7 +127,7 @@ def gemm_grouped(descs):
                      GEMM_VARIANTS[17]: "gemm_bf16_pipe_pair_kernel<256,128,3,4,2>",
                      GEMM_VARIANTS[26]: "gemm_bf16_pair_kernel<192,128,4,2>",
                      GEMM_VARIANTS[27]: "gemm_bf16_pair_kernel<128,192,2,4>",
-                     GEMM_VARIANTS[30]: "gemm8p_kernel<true>"}.get(prof.name, prof.name)
+                     GEMM_VARIANTS[30]: "gemm8p_kernel"}.get(prof.name, prof.name)
     with prof:
         _lib.check(lib.advgrpo_gemm_grouped(arr, len(descs), _lib.stream_ptr()))
     return [o for _, o in descs]
