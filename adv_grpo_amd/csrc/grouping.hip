@@ -12,37 +12,39 @@
 
 namespace advgrpo {
 
-// numpy's pairwise sum (loops_utils.h.src, PW_BLOCKSIZE = 128) over a contiguous f64 array
-__device__ double np_pairwise_leaf(const double* a, int n) {  // n <= 128
+// numpy's pairwise sum (loops_utils.h.src, PW_BLOCKSIZE = 128) over a contiguous f64 / f32 array
+template <class F>
+__device__ F np_pairwise_leaf(const F* a, int n) {  // n <= 128
     if (n < 8) {
-        double r = 0.;
+        F r = 0;
         for (int i = 0; i < n; ++i) r += a[i];
         return r;
     }
-    double r[8];
+    F r[8];
     for (int j = 0; j < 8; ++j) r[j] = a[j];
     int i;
     for (i = 8; i < n - (n % 8); i += 8)
         for (int j = 0; j < 8; ++j) r[j] += a[i + j];
-    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    F res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
     for (; i < n; ++i) res += a[i];
     return res;
 }
-__device__ double np_pairwise_sum(const double* a, int n) {
+template <class F>
+__device__ F np_pairwise_sum(const F* a, int n) {
     if (n <= 128) return np_pairwise_leaf(a, n);
     // iterative form of the recursion: explicit stack of (ptr, n) halves, summed left to right
     // in the same association order as the recursive definition  f(a,n) = f(a,n2) + f(a+n2,n-n2)
-    struct Fr { const double* a; int n; int state; double left; };
+    struct Fr { const F* a; int n; int state; F left; };
     Fr st[32];
     int sp = 0;
-    st[0] = {a, n, 0, 0.};
-    double ret = 0.;
+    st[0] = {a, n, 0, 0};
+    F ret = 0;
     while (sp >= 0) {
         Fr& f = st[sp];
         if (f.n <= 128) { ret = np_pairwise_leaf(f.a, f.n); --sp; continue; }
         int n2 = f.n / 2; n2 -= n2 % 8;
-        if (f.state == 0) { f.state = 1; st[++sp] = {f.a, n2, 0, 0.}; }
-        else if (f.state == 1) { f.left = ret; f.state = 2; st[++sp] = {f.a + n2, f.n - n2, 0, 0.}; }
+        if (f.state == 0) { f.state = 1; st[++sp] = {f.a, n2, 0, 0}; }
+        else if (f.state == 1) { f.left = ret; f.state = 2; st[++sp] = {f.a + n2, f.n - n2, 0, 0}; }
         else { ret = f.left + ret; --sp; }
     }
     return ret;
@@ -58,6 +60,38 @@ __device__ double np_colsum(const double* vals, int T, int j, int r0, int cnt) {
 
 constexpr int GA_THREADS = 256;
 
+// per-group np.std of column 0 in arithmetic type F, then (zero_std_ratio, mean std); all threads of the workgroup
+template <class F>
+__device__ void group_std_stats(const double* vals, double* s_col, double* s_sq, double* s_std, const int32_t* gid, const int* pos,
+                                const int* gstart, const int* gcount, const int* leader, int N, int T, double* out_stats) {
+    F* col = reinterpret_cast<F*>(s_col);     // column 0, rows permuted so that groups are contiguous
+    F* sq = reinterpret_cast<F*>(s_sq);
+    F* stds = reinterpret_cast<F*>(s_std);    // indexed by the group's rank in ascending key order
+    for (int i = threadIdx.x; i < N; i += blockDim.x) col[pos[i]] = (F)vals[(size_t)pos[i] * T];
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        if (pos[i] != gstart[i]) continue;                 // one thread per group
+        const int s = gstart[i], cnt = gcount[i];
+        const F mean = np_pairwise_sum<F>(col + s, cnt) / (F)cnt;
+        for (int k = 0; k < cnt; ++k) {
+            const F x = col[s + k] - mean;
+            sq[s + k] = x * x;
+        }
+        const F var = np_pairwise_sum<F>(sq + s, cnt) / (F)cnt;
+        int rank = 0;
+        for (int k = 0; k < N; ++k) rank += (leader[k] == k && gid[k] < gid[i]) ? 1 : 0;
+        stds[rank] = sqrt(var);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ng = 0, zero = 0;
+        for (int k = 0; k < N; ++k) ng += leader[k] == k ? 1 : 0;
+        for (int g = 0; g < ng; ++g) zero += stds[g] == (F)0 ? 1 : 0;
+        out_stats[0] = (double)zero / (double)ng;
+        out_stats[1] = (double)(np_pairwise_sum<F>(stds, ng) / (F)ng);
+    }
+}
+
 // dynamic LDS (all f64 arrays are [N*T]):
 //   vals  rewards permuted so each group's rows are contiguous (stable in row order)
 //   dev   scratch: original-order copy, then squared deviations
@@ -65,7 +99,7 @@ constexpr int GA_THREADS = 256;
 //   gstd[T] global std;  pos / gstart / gcount / tmp : int[N]
 __global__ __launch_bounds__(GA_THREADS) void group_advantage_kernel(
     const void* __restrict__ rewards, int r_dt, const int32_t* __restrict__ gid, int N, int T,
-    int global_std, double* __restrict__ out) {
+    int global_std, double* __restrict__ out, double* __restrict__ out_stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const size_t nt = (size_t)N * T;
     double* vals = reinterpret_cast<double*>(smem);
@@ -156,6 +190,16 @@ __global__ __launch_bounds__(GA_THREADS) void group_advantage_kernel(
         const double sd = global_std ? gstd[j] : gsd[(size_t)gstart[i] * T + j];
         out[w] = (vals[(size_t)pos[i] * T + j] - m) / sd;
     }
+    // calculate_zero_std_ratio (train_sd3_fast_pickscore.py:195-229) on column 0 (the reference's 'ori_avg' is the
+    // pre-repeat [N] reward): np.std of every group IN THE INPUT DTYPE (f32 as gathered: numpy keeps float32 through
+    // mean / multiply / sum / sqrt), groups in ascending key order like np.unique, then the fraction of exact zeros and the
+    // mean of the group stds (pairwise sums).  Rows inside a group keep their input order (np.argsort of the inverse
+    // indices is stable for the sizes np.std's pairwise order is sensitive to; checked against the goldens).
+    if (out_stats) {
+        __syncthreads();
+        if (r_dt == ADVGRPO_F64) group_std_stats<double>(vals, dev, gsd, gmean, gid, pos, gstart, gcount, tmp, N, T, out_stats);
+        else group_std_stats<float>(vals, dev, gsd, gmean, gid, pos, gstart, gcount, tmp, N, T, out_stats);
+    }
 }
 
 // ---- GRPO clipped surrogate, train_sd3_fast_pickscore.py:1111-1162
@@ -212,8 +256,8 @@ __global__ void grpo_loss_kernel(const float* __restrict__ lp, const float* __re
 
 using namespace advgrpo;
 
-extern "C" int advgrpo_group_advantage(const void* rewards, int rewards_dtype, const int32_t* group_id, int N, int T,
-                                       int global_std, double* out_adv, void* stream) {
+static int group_advantage_launch(const void* rewards, int rewards_dtype, const int32_t* group_id, int N, int T,
+                                  int global_std, double* out_adv, double* out_stats, void* stream) {
     ADVGRPO_CHECK(rewards && group_id && out_adv, "group_advantage: null argument");
     ADVGRPO_CHECK(rewards_dtype == ADVGRPO_F32 || rewards_dtype == ADVGRPO_F64, "group_advantage: bad dtype %d",
                   rewards_dtype);
@@ -225,9 +269,20 @@ extern "C" int advgrpo_group_advantage(const void* rewards, int rewards_dtype, c
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(group_advantage_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     hipLaunchKernelGGL(group_advantage_kernel, dim3(1), dim3(GA_THREADS), bytes, as_stream(stream), rewards,
-                       rewards_dtype, group_id, N, T, global_std, out_adv);
+                       rewards_dtype, group_id, N, T, global_std, out_adv, out_stats);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int advgrpo_group_advantage(const void* rewards, int rewards_dtype, const int32_t* group_id, int N, int T,
+                                       int global_std, double* out_adv, void* stream) {
+    return group_advantage_launch(rewards, rewards_dtype, group_id, N, T, global_std, out_adv, nullptr, stream);
+}
+
+extern "C" int advgrpo_group_advantage_stats(const void* rewards, int rewards_dtype, const int32_t* group_id, int N, int T,
+                                             int global_std, double* out_adv, double* out_stats, void* stream) {
+    ADVGRPO_CHECK(out_stats, "group_advantage_stats: null out_stats");
+    return group_advantage_launch(rewards, rewards_dtype, group_id, N, T, global_std, out_adv, out_stats, stream);
 }
 
 extern "C" int advgrpo_grpo_loss(const float* log_prob, const float* old_log_prob, const float* advantages, int B,

@@ -222,8 +222,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p32, bf1
 // ---- EMA: e += (1 - decay) * (p - e)   (adv_grpo/ema.py:45-46)
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ e, const float* __restrict__ p, int64_t n,
                                                   float one_minus_decay) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        e[i] += one_minus_decay * (p[i] - e[i]);
+    // the reference rounds three times (sub, mul, add_): no fma, or the 40-step golden sequence drifts by an ulp
+#pragma clang fp contract(off)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = p[i] - e[i];
+        const float s = one_minus_decay * d;
+        e[i] = e[i] + s;
+    }
 }
 
 static int grid_for(int64_t n, int per) {

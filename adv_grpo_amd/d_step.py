@@ -23,11 +23,17 @@ class DinoHeadTrainable:
         n = hidden_dim * in_dim + hidden_dim + hidden_dim + 1
         self.n_params = n
         self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
-        if state_dict is None:                      # nn.Linear default init (kaiming-uniform a=sqrt(5)) on the host
+        if state_dict is None:
+            # nn.Linear's default init -- kaiming_uniform_(a = sqrt(5)) = U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and
+            # bias alike -- drawn from a generator seeded with `seed`, so that every rank that passes the same seed starts
+            # from the same head (the reference gets that from DDP's broadcast of rank 0's parameters, TD:749)
             g = torch.Generator().manual_seed(seed)
-            lin1, lin2 = torch.nn.Linear(in_dim, hidden_dim), torch.nn.Linear(hidden_dim, 1)
-            state_dict = {"layers.0.weight": lin1.weight.detach(), "layers.0.bias": lin1.bias.detach(),
-                          "layers.2.weight": lin2.weight.detach(), "layers.2.bias": lin2.bias.detach()}
+
+            def uniform(shape, fan_in):
+                bound = 1.0 / fan_in ** 0.5
+                return (torch.rand(shape, generator=g) * 2 - 1) * bound
+            state_dict = {"layers.0.weight": uniform((hidden_dim, in_dim), in_dim), "layers.0.bias": uniform((hidden_dim,), in_dim),
+                          "layers.2.weight": uniform((1, hidden_dim), hidden_dim), "layers.2.bias": uniform((1,), hidden_dim)}
         o = self._offsets()
         self.params[o[0]:o[1]] = state_dict["layers.0.weight"].float().reshape(-1).to(self.device)
         self.params[o[1]:o[2]] = state_dict["layers.0.bias"].float().to(self.device)

@@ -64,8 +64,13 @@ def pipeline_with_logprob_random(self, prompt=None, prompt_2=None, prompt_3=None
     random.seed(process_index)                                                 # PF:585
     if random_timestep is None:
         random_timestep = random.randint(0, sample_num_steps // 2)
+    self.last_random_timestep = random_timestep    # host int: scheduler index of the first recorded step (for the G-step)
     all_latents, all_log_probs, all_timesteps = [], [], []
     n_per = latents[0].numel()
+    # One Philox key per rollout call, disjoint counter ranges per draw: the initial latents use counters [0, ctr), the
+    # epsilon of denoise step i the range [(1 + i) * ctr, (2 + i) * ctr).  (Separate keys seed + 1 + i per step made rank
+    # r + 1's latents equal rank r's step-0 noise whenever callers numbered their ranks' seeds consecutively.)
+    ctr = (B * n_per + 3) // 4 + 1
     for i in range(len(timesteps)):
         t = timesteps[i]
         if i == random_timestep:                                               # PF:606-623
@@ -83,7 +88,7 @@ def pipeline_with_logprob_random(self, prompt=None, prompt_2=None, prompt_3=None
         want_f32 = dtype == torch.float32
         nxt, cast, log_prob, _, _ = sde_step_cfg(                              # PF:640-655 fused
             self.scheduler, vu, vt, guidance_scale, None, latents, cur,
-            noise=None if noises is None else noises[i], seed=seed + 1 + i, offset=0,
+            noise=None if noises is None else noises[i], seed=seed, offset=(1 + i) * ctr,
             out_dtype=None if want_f32 else dtype, want_mean=False, step_index=i)
         latents = nxt if want_f32 else cast
         if random_timestep <= i < random_timestep + train_num_steps:           # PF:657-660

@@ -14,9 +14,12 @@ from .diffusers_patch.sd3_sde_with_logprob import sde_step_cfg
 
 @torch.no_grad()
 def micro_step(model, scheduler, sample, j, embeds, pooled_embeds, old_log_prob, advantages, *, guidance_scale,
-               noise_level, adv_clip_max, clip_range, loss_scale=1.0):
+               noise_level, adv_clip_max, clip_range, loss_scale=1.0, step_index=None):
     """sample: dict with latents / next_latents [G,T,16,h,w], timesteps [G,T].  embeds / pooled: CFG-concatenated
-    (negative first, TP:1084-1091).  Accumulates into model.grads; returns the diagnostics of TP:1132-1162."""
+    (negative first, TP:1084-1091).  Accumulates into model.grads; returns the diagnostics of TP:1132-1162.
+    step_index: scheduler index of timestep j, carried on the host by the caller (the rollout knows it); without it the
+    index is looked up from the timestep value as the reference does (scheduler.index_for_timestep, SDE:106-110), which
+    costs a device -> host copy per micro-step."""
     lib = _lib.load()
     x = sample["latents"][:, j].contiguous()
     nxt = sample["next_latents"][:, j].contiguous()
@@ -24,7 +27,8 @@ def micro_step(model, scheduler, sample, j, embeds, pooled_embeds, old_log_prob,
     G = x.shape[0]
     v, ctx = model.forward_train(torch.cat([x, x]), torch.cat([ts, ts]).float(), embeds, pooled_embeds)
     vu, vt = v[:G].contiguous(), v[G:].contiguous()
-    step_index = scheduler.index_for_timestep(float(ts[0]))
+    if step_index is None:
+        step_index = scheduler.index_for_timestep(float(ts[0]))
     _, _, log_prob, _, _ = sde_step_cfg(scheduler, vu, vt, guidance_scale, None, x, noise_level, prev_sample=nxt,
                                         want_mean=False, step_index=step_index)
     scal, dlp = losses.grpo_loss(log_prob, old_log_prob, advantages, adv_clip_max, clip_range)

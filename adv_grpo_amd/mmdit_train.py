@@ -22,7 +22,9 @@ import math
 
 import torch
 
-from . import _lib, ops
+from . import _lib
+from . import ops
+from .ema import EMAModuleWrapper
 from .mmdit import SD3Transformer2DModel
 
 RANK, RPAD = 32, 64
@@ -68,7 +70,10 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
         self.exp_avg_sq = torch.zeros_like(self.params)
         self.params_bf16 = self.params.to(torch.bfloat16)
         self.opt_step = 0
-        self.ema = None
+        # EMA of the trainable parameters from their INITIAL values (EMAModuleWrapper built at construction, TP:528);
+        # self.ema aliases its one flat tensor (eval swap, EMA checkpoints)
+        self.ema_wrapper = EMAModuleWrapper([self.params], decay=0.9, update_step_interval=8, device=dev)
+        self.ema = self.ema_wrapper.ema_parameters[0]
         self._base_T = {}
         self._prepare_transposes()
         self.refresh()
@@ -98,6 +103,7 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             self.A_view(ad)[:RANK] = A.to(self.device, torch.float32)
             self.B_view(ad)[:, :RANK] = Bm.to(self.device, torch.float32)
         self.params_bf16 = self.params.to(torch.bfloat16)
+        self.ema.copy_(self.params)          # the reference rebuilds the EMA after PeftModel.from_pretrained (TP:506-528)
         self.refresh()
 
     def save_pretrained(self, path, use_ema=False):
@@ -388,11 +394,5 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
     @torch.no_grad()
     def ema_step(self, optimization_step, decay=0.9, update_step_interval=8):
         """EMAModuleWrapper.step (adv_grpo/ema.py:39-52)."""
-        if self.ema is None:
-            self.ema = self.params.clone()
-        if (optimization_step + 1) % update_step_interval != 0:
-            return
-        d = min((1 + optimization_step) / (10 + optimization_step), decay)
-        lib = _lib.load()
-        _lib.check(lib.advgrpo_ema_step(self.ema.data_ptr(), self.params.data_ptr(), self.n_params, 1.0 - d,
-                                        _lib.stream_ptr()))
+        self.ema_wrapper.decay, self.ema_wrapper.update_step_interval = decay, update_step_interval
+        self.ema_wrapper.step([self.params], optimization_step)

@@ -7,7 +7,11 @@ Differences that come with the platform, none of which change the number compute
     still accepted (converted once);
   * prompts are either strings (needs a ``tokenizer`` callable; no tokenizer files exist on the GPU box) or
     ready ``input_ids`` [N,77];
-  * weights come from a state dict (``model_sd``) because no checkpoint can be downloaded here.
+  * weights come from a state dict (``model_sd``) because no checkpoint can be downloaded here;
+  * ``dtype`` is accepted for signature parity and recorded, but the towers always compute in bf16 on the MFMA units
+    with f32 accumulation: gfx950 has no fast fp32 matrix path (1/16 of the bf16 rate), so the fp32 scorer the
+    reference builds for ``pickscore`` (rewards.py:564) differs from this one by bf16 tower rounding (bounded against
+    the fp32 oracle in tests/test_gpu_vit.py); ``compute_dtype`` says what actually runs.
 """
 import numpy as np
 import torch
@@ -22,6 +26,7 @@ class PickScoreScorer(torch.nn.Module):
             raise RuntimeError("PickScoreScorer needs model_sd + clip_cfg (no checkpoint download on this platform)")
         self.device = device
         self.dtype = dtype
+        self.compute_dtype = torch.bfloat16
         self.tokenizer = tokenizer
         self.model = vit.CLIPModel(model_sd, clip_cfg, device)
 
@@ -34,6 +39,8 @@ class PickScoreScorer(torch.nn.Module):
     def _ids(self, prompt):
         if isinstance(prompt, torch.Tensor):
             return prompt
+        if getattr(prompt, "clip_ids", None) is not None:       # rewards.PromptBatch: strings that carry their token ids
+            return prompt.clip_ids
         if self.tokenizer is None:
             raise RuntimeError("string prompts need a tokenizer; pass input_ids [N,77] instead")
         return self.tokenizer(prompt, padding="max_length", truncation=True, max_length=77, return_tensors="pt").input_ids

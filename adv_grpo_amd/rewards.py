@@ -17,6 +17,16 @@ _OUT_OF_SCOPE = ("deqa", "video_ocr", "imagereward", "qwenvl", "aesthetic", "jpe
                  "geneval", "clipscore", "image_similarity_eval", "constractive_external", "discriminator",
                  "pickscore_patch", "dino_multi_cotrain", "siglip_cotrain", "siglip_image_similarity")
 
+class PromptBatch(list):
+    """The ``prompts`` argument of the scorer plugins when both faces of a prompt are needed: a list of the prompt STRINGS
+    (what text-matching host scorers such as ``ocr`` read) that also carries the CLIP ``input_ids`` [N,77] of the same
+    prompts for the scorers whose tokenizer cannot run on this platform (PickScore)."""
+
+    def __init__(self, texts, clip_ids=None):
+        super().__init__(texts)
+        self.clip_ids = clip_ids
+
+
 _PICKSCORE_FACTORY_ARGS = {}
 
 
@@ -74,17 +84,32 @@ def dino_cotrain_score(device):
 
 
 def image_similarity_score(device):
-    """rewards.py:147-203 (eval): max cosine similarity of DINOv2 CLS embeddings against reference images.
+    """rewards.py:147-203 (eval): max over the reference images of the cosine similarity of DINOv2 CLS embeddings.
+    On the kernels of the path: fused preprocess + DINOv2 tower, CLS rows L2-normalised by ``gather_l2norm_rows``, the
+    [N, M] similarity matrix by the MFMA GEMM (f32 out); only the row maximum is index plumbing.  (The reference runs
+    this tower in fp32; the towers here are bf16-MFMA / f32-accumulate -- DESIGN.md, deviations.)
     Needs a backbone: configure with rewards.configure_dino(model)."""
+    def _cls_rows(model, images):
+        from . import _lib
+        lib = _lib.load()
+        images = images if isinstance(images, torch.Tensor) else torch.as_tensor(images)
+        if images.shape[-1] == 3:                                               # NHWC -> NCHW (RW:165-166)
+            images = images.permute(0, 3, 1, 2)
+        if images.dtype == torch.uint8 or images.max() > 1.0:                   # RW:163-164
+            images = images.float() / 255.0
+        feats = model.forward_features(images=images.to(device).to(torch.bfloat16)).contiguous()   # [N, 1+P, D], final norm applied
+        N, T, Dm = feats.shape
+        rows = torch.empty(N, Dm, dtype=torch.bfloat16, device=feats.device)    # n = 0: the CLS row of every image only
+        _lib.check(lib.advgrpo_gather_l2norm_rows(_lib.ptr(feats), None, rows.data_ptr(), N, T, Dm, 0, 0.0, _lib.stream_ptr()))
+        return rows
+
     def _fn(images, ref_images):
+        from . import ops
         model = _DINO.get("model")
         if model is None:
             raise RuntimeError("call rewards.configure_dino(model) first (no checkpoint download)")
-        a = model.forward_features(images=images.to(device).float())[:, 0].float()
-        b = model.forward_features(images=ref_images.to(device).float())[:, 0].float()
-        a = a / a.norm(dim=-1, keepdim=True)
-        b = b / b.norm(dim=-1, keepdim=True)
-        scores = a @ b.T
+        a, b = _cls_rows(model, images), _cls_rows(model, ref_images)
+        scores = ops.gemm(a, b, out_dtype=torch.float32)                        # [N, M] cosine similarities (RW:191)
         return scores.max(dim=1).values, {"pairwise": scores}
     return _fn
 
@@ -96,10 +121,24 @@ def configure_dino(model):
     _DINO["model"] = model
 
 
+_OCR = {}
+
+
+def configure_ocr(recognizer):
+    """Text recogniser for the ``ocr`` scorer: ``uint8 [H,W,3] ndarray -> str`` (PaddleOCR is used when importable)."""
+    _OCR["recognizer"] = recognizer
+
+
 def ocr_score(device):
-    """rewards.py:675-689: PaddleOCR + Levenshtein on the host; stays a host plugin (no kernel)."""
+    """rewards.py:675-689: quantise to uint8 NHWC (on the device), recognise + Levenshtein on the host (ocr.OcrScorer).
+    ``prompts`` must be the prompt STRINGS (the target is the quoted part, ocr.py:32)."""
+    from .ocr import OcrScorer
+    scorer = OcrScorer(recognizer=_OCR.get("recognizer"))
+
     def _fn(images, prompts, metadata):
-        raise RuntimeError("ocr scorer needs paddleocr, which is not installed on this platform")
+        if isinstance(images, torch.Tensor):
+            images = (images.float() * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().cpu().numpy()
+        return scorer(images, prompts), {}
     return _fn
 
 

@@ -25,6 +25,20 @@ from .diffusers_patch.sd3_pipeline_with_logprob_fast import pipeline_with_logpro
 from .sampler import DistributedKRepeatSampler
 
 
+def rollout_seed(config_seed, iteration, rank):
+    """Philox key of one rollout call: a 64-bit mix (splitmix64 finaliser) of (config.seed, sampler iteration, rank), so
+    that no two (iteration, rank) pairs share or neighbour a key whatever the world size -- the reference gets the same
+    independence from set_seed(config.seed, device_specific=True) and each rank's own generator state (TP:444)."""
+    m = (1 << 64) - 1
+    x = ((int(config_seed) & 0xFFFFFFFF) << 32) ^ ((int(rank) & 0xFFFF) << 16) ^ ((int(iteration) * 0x9E3779B97F4A7C15) & m)
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & m
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & m
+    x ^= x >> 31
+    return x >> 1            # 63 bits: stays a positive int64 through ctypes / torch
+
+
 class SyntheticData:
     """Seeded stand-in for the prompt dataset + text encoders + reference-image store."""
 
@@ -47,6 +61,10 @@ class SyntheticData:
     def clip_ids(self, idx, n):
         from .synthetic import clip_input_ids
         return clip_input_ids(1, seed=idx).repeat(n, 1).to(self.device)
+
+    def prompt_text(self, idx):
+        """A stand-in prompt string in the shape of dataset/ocr (a quoted target text, adv_grpo/ocr.py:32)."""
+        return f'a sign that says "prompt {idx}" on a wall'
 
     def reference_images(self, idx, n):
         g = torch.Generator().manual_seed(2_000_003 * idx + 11)
@@ -80,6 +98,9 @@ class PromptFileData:
 
     def clip_ids(self, idx, n):
         return self.clip_ids_fn([self.prompts[idx]]).repeat(n, 1).to(self.device)
+
+    def prompt_text(self, idx):
+        return self.prompts[idx]
 
     def prefetch(self, idxs):
         self.store.prefetch([self.prompts[i] for i in idxs])
@@ -124,12 +145,87 @@ class Trainer:
             if c.tune_layer != -1:
                 raise NotImplementedError("PickScore D-step is built for tune_layer = -1 (the shipped config)")
             self.clip_trainable = ClipLastLayerTrainable(scorer.model)                    # TP:1016-1020
+        if world > 1:
+            # every trainable state starts identical on all ranks: rank 0's values are broadcast, as DDP / DeepSpeed do
+            # at construction (TD:749, TP:554-561); afterwards only all-reduced gradients change them
+            import torch.distributed as dist
+            for state in self._trainable_state():
+                dist.broadcast(state, src=0)
+            if hasattr(pipeline.transformer, "refresh"):
+                pipeline.transformer.ema.copy_(pipeline.transformer.params)
+                pipeline.transformer.refresh()
+            if head is not None and hasattr(head, "p16"):
+                head.p16.copy_(head.params)
+        # reference rewards only feed the PickScore D/G gate and the D-steps (TP:1008-1037, TD:1091-1097)
+        self.needs_reference = bool(c.get("train_d", False)) or self.variant == "dino"
+        self.async_reward = bool(c.get("async_reward", True))
+        self.profile_phases = True
+        if self.async_reward:
+            from concurrent.futures import ThreadPoolExecutor
+            self._score_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="advgrpo-score")   # TP:668
+            d = torch.device(self.device)
+            self._dev_index = d.index if d.index is not None else torch.cuda.current_device()
+            self._score_stream = torch.cuda.Stream(device=self._dev_index)
         self.epoch, self.global_step = 0, 0
         self.logger = JsonlLogger(log_path, enabled=(rank == 0))
         self.timers = {}
 
+    def _trainable_state(self):
+        """Flat f32 parameter vectors that training changes (LoRA, discriminator head / last CLIP layer)."""
+        out = []
+        tr = self.pipe.transformer
+        if hasattr(tr, "params"):
+            out.append(tr.params)
+        if self.head is not None and hasattr(self.head, "params"):
+            out.append(self.head.params)
+        if self.clip_trainable is not None and hasattr(self.clip_trainable, "params"):
+            out.append(self.clip_trainable.params)
+        return out
+
+    # ------------------------------------------------------------------ reward futures (SURVEY 8a11, TP:668,816-817,839-856)
+    def _submit_score(self, images, ref, prompts, G):
+        """Score generated (and reference) images on the worker thread, on its own stream, behind an event recorded on the
+        caller's stream.  Returns a future of (rewards dict, reference rewards dict | None, completion event | None).
+        One worker (the reference uses 8 for its PIL / HTTP scorers): the towers keep per-model workspaces, so calls are
+        serialised; what overlaps is the scoring of group i with the rollout of group i + 1."""
+        def score(stream_ctx):
+            with stream_ctx:
+                imgs = images.to(torch.bfloat16)
+                r, _ = self.reward_fn(imgs, prompts, [{}] * G, scorer=self.scorer, head=self.head, only_strict=True)
+                rr = None
+                if ref is not None:
+                    rr, _ = self.reward_fn(ref.to(torch.bfloat16), prompts, [{}] * G, scorer=self.scorer, head=self.head,
+                                           only_strict=True)
+            return r, rr
+        if not self.async_reward:
+            import contextlib
+            from concurrent.futures import Future
+            f = Future()
+            try:
+                f.set_result((*score(contextlib.nullcontext()), None))
+            except Exception as e:      # surfaces at .result(), like the executor path
+                f.set_exception(e)
+            return f
+        ready = torch.cuda.Event()
+        ready.record()                                     # everything the scorer reads has been enqueued before this point
+
+        def work():
+            torch.cuda.set_device(self._dev_index)
+            self._score_stream.wait_event(ready)
+            r, rr = score(torch.cuda.stream(self._score_stream))
+            done = torch.cuda.Event()
+            done.record(self._score_stream)
+            for t in (images, ref, getattr(prompts, "clip_ids", prompts)):   # consumed on the side stream: no early recycling
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(self._score_stream)
+            return r, rr, done
+        return self._score_pool.submit(work)
+
     def _tick(self, name, t0):
-        torch.cuda.synchronize()
+        """Phase timers.  Only the calling thread's stream is drained (the scoring stream keeps running), and only when
+        phase profiling is on: a device-wide synchronize here would serialise the reward futures against the rollouts."""
+        if self.profile_phases:
+            torch.cuda.current_stream().synchronize()
         self.timers[name] = self.timers.get(name, 0.0) + time.perf_counter() - t0
 
     # ------------------------------------------------------------------ hot loop 1: sampling + scoring
@@ -137,7 +233,7 @@ class Trainer:
         c = self.cfg
         G, T = c.sample.mini_num_image_per_prompt, c.sample.train_num_steps
         neg_pe, neg_ppe = self.data.neg
-        out = []
+        out, first_step = [], []
         for i in range(c.sample.num_batches_per_epoch):
             self.sampler.set_epoch(self.epoch * c.sample.num_batches_per_epoch + i)        # TP:729
             idx = next(iter(self.sampler))[0]
@@ -155,24 +251,36 @@ class Trainer:
                 guidance_scale=c.sample.guidance_scale, output_type="pt", height=c.resolution, width=c.resolution,
                 noise_level=c.sample.noise_level, mini_num_image_per_prompt=G, train_num_steps=T,
                 process_index=self.rank, sample_num_steps=c.sample.num_steps, random_timestep=c.sample.random_timestep,
-                seed=(self.epoch * 1000 + i) * 64 + self.rank)                             # TP:755-772
+                seed=rollout_seed(c.seed, self.epoch * c.sample.num_batches_per_epoch + i, self.rank))   # TP:755-772
             self._tick("sample", t0)
-            ref = self.data.reference_images(idx, G)                                       # TP:773-801
-            t0 = time.perf_counter()
+            first_step.append(int(self.pipe.last_random_timestep))
+            ref = self.data.reference_images(idx, G) if self.needs_reference else None     # TP:773-801
             prompts = self.data.clip_ids(idx, G)
-            r, _ = self.reward_fn(images.to(torch.bfloat16), prompts, [{}] * G, scorer=self.scorer, head=self.head,
-                                  only_strict=True)                                        # TP:816
-            rr, _ = self.reward_fn(ref.to(torch.bfloat16), prompts, [{}] * G, scorer=self.scorer, head=self.head,
-                                   only_strict=True)                                       # TP:817
-            self._tick("score", t0)
+            score_prompts = prompts
+            if hasattr(self.data, "prompt_text"):          # host scorers (ocr) read the strings, PickScore the ids
+                score_prompts = rewards.PromptBatch([self.data.prompt_text(idx)] * G, clip_ids=prompts)
+            # TP:816-817: rewards of the generated and of the reference images are submitted to the executor and the loop
+            # goes on with the next group's rollout; they are waited for after the loop (TP:839-856)
+            fut = self._submit_score(images, ref, score_prompts, G)
             lat = torch.stack(lats, dim=1)
             out.append({"group": torch.full((G,), idx, dtype=torch.int32, device=self.device),
                         "prompt_embeds": pe.repeat(G, 1, 1), "pooled_prompt_embeds": ppe.repeat(G, 1),
                         "timesteps": torch.stack(tss, dim=1), "latents": lat[:, :-1], "next_latents": lat[:, 1:],
-                        "log_probs": torch.stack(lps, dim=1), "rewards": torch.as_tensor(r["avg"]).float(),
-                        "reference_rewards": torch.as_tensor(rr["avg"]).float(), "images": images, "ref_images": ref,
-                        "clip_ids": prompts})
-        return {k: torch.cat([s[k] for s in out], dim=0) for k in out[0]}
+                        "log_probs": torch.stack(lps, dim=1), "images": images, "clip_ids": prompts, "_future": fut})
+            if ref is not None:
+                out[-1]["ref_images"] = ref
+        t0 = time.perf_counter()
+        for s in out:                                                                      # TP:839-856
+            r, rr, done = s.pop("_future").result()          # re-raises what the scorer raised
+            if done is not None:
+                torch.cuda.current_stream().wait_event(done)
+            s["rewards"] = torch.as_tensor(r["avg"], device=self.device).float()
+            if rr is not None:
+                s["reference_rewards"] = torch.as_tensor(rr["avg"], device=self.device).float()
+        self._tick("score", t0)
+        samples = {k: torch.cat([s[k] for s in out], dim=0) for k in out[0]}
+        samples["first_step_index"] = first_step        # host ints, one per prompt group: no device -> host copy in the G-step
+        return samples
 
     # ------------------------------------------------------------------ eval loop
     @torch.no_grad()
@@ -248,21 +356,32 @@ class Trainer:
         t0 = time.perf_counter()
         rew = samples["rewards"].unsqueeze(1).repeat(1, T)                                  # TP:926-928
         all_rew, all_gid = D.gather_rewards(rew, samples["group"])
-        adv = self.stat_tracker.update(all_gid, all_rew) if c.per_prompt_stat_tracking else \
-            ((all_rew - all_rew.mean()) / (all_rew.std() + 1e-4)).double()
-        group_size, n_hist = self.stat_tracker.get_stats()
-        self.stat_tracker.clear()
+        if c.per_prompt_stat_tracking:
+            adv = self.stat_tracker.update(all_gid, all_rew)                                # TP:970
+            group_stats = self.stat_tracker.last_group_stats                               # TP:975 (same launch)
+            group_size, n_hist = self.stat_tracker.get_stats()
+            self.stat_tracker.clear()                                                       # TP:989
+        else:   # TP:991: numpy arrays upstream, i.e. float32 mean and POPULATION std (ddof = 0)
+            adv = ((all_rew - all_rew.mean()) / (all_rew.std(unbiased=False) + 1e-4)).double()
+            group_stats, group_size, n_hist = None, 0, 0
         samples["advantages"] = D.ungather(adv, self.world, self.rank).float()              # TP:995-999
         mean_gen = D.all_mean(samples["rewards"])                                           # TP:1008
-        mean_ref = D.all_mean(samples["reference_rewards"])                                 # TP:1011
+        mean_ref = D.all_mean(samples["reference_rewards"]) if "reference_rewards" in samples else None   # TP:1011
         self._tick("gather+advantage", t0)
-        self.logger.log({"epoch": self.epoch, "reward_avg": all_rew[:, 0].mean(), "reference_reward_avg": mean_ref,
-                         "group_size": group_size, "trained_prompt_num": n_hist}, self.global_step)
+        metrics = {"epoch": self.epoch, "reward_avg": all_rew[:, 0].mean(), "group_size": group_size, "trained_prompt_num": n_hist}
+        if mean_ref is not None:
+            metrics["reference_reward_avg"] = mean_ref
+        if group_stats is not None:                                                         # TP:977-988
+            metrics["zero_std_ratio"], metrics["reward_std_mean"] = group_stats[0], group_stats[1]
+        self.last_metrics = metrics
+        self.logger.log(metrics, self.global_step)
         # ---- D or G (identical on every rank: derived from gathered data / the epoch counter)
+        # (a config without a discriminator -- pickscore_sd3_fast, the multi-reward preset -- keeps the gate at G: SURVEY 8f)
+        train_d = bool(c.get("train_d", False))
         if self.variant == "dino":
-            do_d = c.train_d and (self.epoch + 1) % c.d_times != 0                          # TD:1097
+            do_d = train_d and (self.epoch + 1) % c.d_times != 0                            # TD:1097
         else:
-            do_d = c.train_d and bool(mean_ref < mean_gen)                                  # TP:1025
+            do_d = train_d and bool(mean_ref < mean_gen)                                    # TP:1025
         if do_d:
             t0 = time.perf_counter()
             info = self.d_step(samples)
@@ -312,7 +431,8 @@ class Trainer:
                     info = g_step.micro_step(model, self.pipe.scheduler, s, j, embeds, pooled, s["log_probs"][:, j],
                                              s["advantages"][:, j], guidance_scale=c.sample.guidance_scale,
                                              noise_level=c.sample.noise_level, adv_clip_max=c.train.adv_clip_max,
-                                             clip_range=c.train.clip_range, loss_scale=1.0 / (GA * T))
+                                             clip_range=c.train.clip_range, loss_scale=1.0 / (GA * T),
+                                             step_index=samples["first_step_index"][i] + j)
                     for k in ("loss", "approx_kl", "clipfrac", "clipfrac_gt_one", "clipfrac_lt_one", "policy_loss"):
                         agg[k] = agg.get(k, 0) + info[k]
                     n_acc += 1

@@ -169,6 +169,7 @@ def main():
     from adv_grpo_amd import ops, stat_tracking, synthetic, vit
     from adv_grpo_amd.diffusers_patch.sd3_pipeline_with_logprob_fast import pipeline_with_logprob_random
     from adv_grpo_amd.sampler import DistributedKRepeatSampler
+    from adv_grpo_amd.trainer import rollout_seed
 
     pipe, clip = build(device)
     G, STEPS, T, RES = 8, 10, 2, 512
@@ -184,7 +185,7 @@ def main():
             pipe, prompt_embeds=pe, pooled_prompt_embeds=ppe, negative_prompt_embeds=npe,
             negative_pooled_prompt_embeds=nppe, num_inference_steps=STEPS, guidance_scale=4.5, output_type="pt",
             height=RES, width=RES, noise_level=0.8, mini_num_image_per_prompt=G, train_num_steps=T,
-            process_index=rank, sample_num_steps=STEPS, random_timestep=0, seed=1000 * it + rank)
+            process_index=rank, sample_num_steps=STEPS, random_timestep=0, seed=rollout_seed(42, it, rank))
         scores = vit.pickscore_scores(clip.get_image_features(images=image.to(torch.bfloat16)),
                                       clip.get_text_features(ids), clip.logit_scale)
         rewards = scores.unsqueeze(1).repeat(1, T)                          # TP:926-928

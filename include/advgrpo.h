@@ -89,6 +89,12 @@ int advgrpo_sde_step_bwd(const void* v_uncond, const void* v_text, int v_dtype, 
  * Sums run in row order like numpy's axis-0 reduction, so results are bit-exact with it. */
 int advgrpo_group_advantage(const void* rewards, int rewards_dtype, const int32_t* group_id,
                             int N, int T, int global_std, double* out_adv, void* stream);
+/* same launch + the logging statistics of calculate_zero_std_ratio, scripts/train_sd3_fast_pickscore.py:195-229
+ * (logged at :975-988): out_stats[0] = zero_std_ratio (share of groups whose reward std is exactly 0),
+ * out_stats[1] = reward_std_mean (mean of the per-group np.std), both from column 0 of `rewards` in ITS dtype's
+ * arithmetic (float32 as gathered upstream), groups in ascending key order, numpy summation orders: bit-exact. */
+int advgrpo_group_advantage_stats(const void* rewards, int rewards_dtype, const int32_t* group_id,
+                                  int N, int T, int global_std, double* out_adv, double* out_stats, void* stream);
 
 /* ------------------------------------------------------------------ GRPO loss
  * Clipped surrogate forward + backward + diagnostics, train_sd3_fast_pickscore.py:1111-1162

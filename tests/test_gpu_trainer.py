@@ -103,3 +103,165 @@ def test_eval_loop_is_deterministic_swaps_ema_and_checkpoint_round_trips(tmp_pat
     y1 = model(x, t, ctx, pooled)[0].clone()
     model.load_lora_state({k: v.clone() for k, v in state.items()})
     assert torch.equal(model(x, t, ctx, pooled)[0], y1)
+
+
+def test_eval_matches_oracle_eval_on_reduced_stack():
+    """f1: Trainer.evaluate (TP:269-382) against the same loop through the fp32 oracle: `eval_num_steps` deterministic steps
+    (noise_level = 0), latents of every test batch from a CPU generator seeded with 0 (TP:298-299), PickScore of the
+    decoded images, mean over the prompts.  bf16 transformer / VAE / towers vs fp32: a few per cent on the score scale."""
+    from adv_grpo_amd import synthetic
+    from oracle import lora as o_lora
+    from oracle import mmdit as o_m
+    from oracle import rewards as o_rw
+    from oracle import rollout as o_r
+    from oracle import vae as o_v
+    from oracle import vit as o_t
+    from oracle.scheduler import FlowMatchEulerScheduler
+    from tests.test_gpu_vit import _pil_clip_preprocess
+    tr_, model, _ = _build("pickscore", train_d=False)
+    c = tr_.cfg
+    c.sample.eval_num_steps, c.sample.test_batch_size, c.train.ema = 6, 3, False
+    got = tr_.evaluate(n_prompts=3, eval_reward_fn={"pickscore_cotrain": 1})
+    # ---- the oracle's eval on identical weights / prompts
+    mcfg = o_m.MMDiTConfig(num_layers=2, num_heads=4, joint_attention_dim=256, pooled_projection_dim=128,
+                           pos_embed_max_size=96, dual_attention_layers=(0,))
+    vcfg, ccfg = o_v.VaeConfig(), o_t.ClipConfig(v_layers=2, t_layers=2)
+    W = {k: v.to(torch.bfloat16).float().cuda() for k, v in synthetic.mmdit_weights(mcfg, 1).items()}
+    lora = {k: v.float().cuda() for k, v in model.lora_state_dict().items()}
+    Weff = o_lora.effective_weights(W, lora)
+    V32 = {k: v.to(torch.bfloat16).float().cuda() for k, v in synthetic.vae_decoder_weights(vcfg, 2).items()}
+    C32 = {k: v.float().cuda() for k, v in synthetic.clip_weights(ccfg, 4).items()}
+    sch = FlowMatchEulerScheduler(); sch.device = "cuda"
+    data = tr_.data
+    idxs = [0, 1, 2]
+    pe = torch.cat([data.prompt(i)[0] for i in idxs]); ppe = torch.cat([data.prompt(i)[1] for i in idxs])
+    npe, nppe = data.neg[0].repeat(3, 1, 1), data.neg[1].repeat(3, 1)
+    lat0 = torch.randn(3, 16, c.resolution // 8, c.resolution // 8, generator=torch.Generator().manual_seed(0), dtype=pe.dtype)
+    fn = lambda x, t, cc, p: o_m.mmdit_forward(Weff, mcfg, x.float(), t, cc.float(), p.float()).to(x.dtype)
+    with torch.no_grad():
+        img, _, _, _ = o_r.rollout(fn, lambda z: o_v.vae_decode(V32, vcfg, z), sch, prompt_embeds=pe, pooled_prompt_embeds=ppe,
+                                   negative_prompt_embeds=npe, negative_pooled_prompt_embeds=nppe, num_inference_steps=6,
+                                   guidance_scale=c.sample.guidance_scale, height=c.resolution, width=c.resolution, noise_level=0,
+                                   mini_num_image_per_prompt=1, train_num_steps=c.sample.train_num_steps, process_index=0,
+                                   sample_num_steps=c.sample.num_steps, random_timestep=c.sample.random_timestep,
+                                   latents=lat0.cuda(), noises=[torch.zeros_like(lat0).cuda() for _ in range(6)])
+        px = _pil_clip_preprocess(o_rw.to_uint8(img.to(torch.bfloat16).cpu()).permute(0, 2, 3, 1).numpy()).to(torch.bfloat16).float().cuda()
+        ids = torch.cat([data.clip_ids(i, 1) for i in idxs])
+        ref = o_rw.pickscore_from_embeddings(o_t.clip_image_features(C32, ccfg, px), o_t.clip_text_features(C32, ccfg, ids),
+                                             C32["logit_scale"]).mean().item()
+    assert abs(got["eval_reward_pickscore_cotrain"] - ref) < 5e-2 * max(1.0, abs(ref)), (got, ref)
+    assert got["eval_reward_avg"] == got["eval_reward_pickscore_cotrain"]
+
+
+def test_reward_futures_from_worker_threads_match_serial_scoring():
+    """a11 / include/advgrpo.h "callable from worker threads, one stream each": two scorer calls issued from two worker
+    threads on their own streams WHILE the main thread runs a rollout must return exactly what serial calls return."""
+    import threading
+    from adv_grpo_amd import rewards
+    from adv_grpo_amd.diffusers_patch.sd3_pipeline_with_logprob_fast import pipeline_with_logprob_random
+    tr_, model, _ = _build("pickscore", train_d=False)
+    g = torch.Generator().manual_seed(3)
+    imgs = [torch.rand(2, 3, 256, 256, generator=g).cuda().to(torch.bfloat16) for _ in range(2)]
+    ids = [tr_.data.clip_ids(i, 2) for i in range(2)]
+    fn = rewards.multi_score("cuda", {"pickscore_cotrain": 1})
+    serial = [fn(imgs[k], ids[k], [{}] * 2, scorer=tr_.scorer)[0]["avg"].clone() for k in range(2)]
+    torch.cuda.synchronize()
+    out, errs = [None, None], []
+    lock = threading.Lock()          # the scorer's towers keep per-model workspaces: calls on ONE model are serialised
+
+    def work(k):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    with lock:
+                        r = fn(imgs[k], ids[k], [{}] * 2, scorer=tr_.scorer)[0]["avg"]
+                        st.synchronize()
+                out[k] = r.clone()
+            st.synchronize()
+        except Exception as e:       # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    pe, ppe = tr_.data.prompt(5)
+    c = tr_.cfg
+    img, _, lps, _ = pipeline_with_logprob_random(                 # concurrently, on the main thread's stream
+        tr_.pipe, prompt_embeds=pe, pooled_prompt_embeds=ppe, negative_prompt_embeds=tr_.data.neg[0],
+        negative_pooled_prompt_embeds=tr_.data.neg[1], num_inference_steps=4, guidance_scale=4.5, output_type="pt", height=256,
+        width=256, noise_level=0.8, mini_num_image_per_prompt=2, train_num_steps=2, process_index=0, sample_num_steps=4,
+        random_timestep=0, seed=11)
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for k in range(2):
+        assert torch.equal(out[k], serial[k]), (out[k], serial[k])
+    img2, _, lps2, _ = pipeline_with_logprob_random(               # and the rollout was not disturbed either
+        tr_.pipe, prompt_embeds=pe, pooled_prompt_embeds=ppe, negative_prompt_embeds=tr_.data.neg[0],
+        negative_pooled_prompt_embeds=tr_.data.neg[1], num_inference_steps=4, guidance_scale=4.5, output_type="pt", height=256,
+        width=256, noise_level=0.8, mini_num_image_per_prompt=2, train_num_steps=2, process_index=0, sample_num_steps=4,
+        random_timestep=0, seed=11)
+    assert torch.equal(torch.stack(lps), torch.stack(lps2))
+    # the trainer's own futures: async and inline scoring give the same rewards for the same epoch
+    a = tr_.sample_epoch()
+    tr_.async_reward = False
+    b = tr_.sample_epoch()
+    assert torch.equal(a["log_probs"], b["log_probs"])
+    # (the decoded images repeat only up to the order of the f64 atomic sums in the VAE's GroupNorm statistics)
+    assert torch.allclose(a["rewards"], b["rewards"], rtol=1e-2, atol=2e-3), (a["rewards"], b["rewards"])
+
+
+def test_no_discriminator_multi_reward_config_runs():
+    """BASELINE config 4's preset (`pickscore_sd3_fast`: reward_fn = {pickscore: 0.5, ocr: 0.5}, no discriminator keys,
+    config/grpo.py:379-427): the loop keeps the D/G gate at G, scores no reference images, and the ocr scorer runs as a
+    host plugin on the prompt strings with a stand-in recogniser (PaddleOCR is not installed)."""
+    from adv_grpo_amd import rewards, synthetic
+    from adv_grpo_amd.config.experiments import get_config
+    from adv_grpo_amd.model_configs import ClipConfig
+    tr0, model, _ = _build("pickscore", train_d=False)
+    cfg = get_config("pickscore_sd3_fast", gpu_number=1)
+    assert cfg.get("train_d") is None and dict(cfg.reward_fn.items()) == {"pickscore": 0.5, "ocr": 0.5}
+    cfg.resolution = 256
+    cfg.sample.num_steps = 4
+    cfg.sample.num_image_per_prompt = cfg.sample.mini_num_image_per_prompt = 2
+    cfg.sample.num_batches_per_epoch = 2
+    cfg.train.gradient_accumulation_steps = 1
+    cc = ClipConfig(v_layers=2, t_layers=2)
+    rewards.configure_pickscore(synthetic.clip_weights(cc, 4), cc)
+    seen = []
+
+    def recognizer(img):
+        assert img.dtype.name == "uint8" and img.shape == (256, 256, 3)
+        seen.append(1)
+        return "prompt 1" if len(seen) % 2 else ""
+    rewards.configure_ocr(recognizer)
+    from adv_grpo_amd.trainer import Trainer
+    tr_ = Trainer(cfg, tr0.pipe, tr0.data, None, None)
+    assert not tr_.needs_reference
+    p0 = model.params.clone()
+    s = tr_.sample_epoch()
+    assert "reference_rewards" not in s and s["rewards"].shape == (4,) and len(seen) == 4
+    info = tr_.run_epoch()
+    assert info["phase"] == "G" and not torch.equal(model.params, p0)
+    assert "zero_std_ratio" in tr_.last_metrics and "reward_std_mean" in tr_.last_metrics
+
+
+def test_image_similarity_scorer_on_the_kernels():
+    """rewards.py:147-203 (eval reward): max cosine similarity of DINOv2 CLS embeddings, kernels vs the fp32 oracle tower."""
+    from adv_grpo_amd import rewards, synthetic, vit
+    from adv_grpo_amd.model_configs import DinoConfig
+    from oracle import rewards as o_rw
+    from oracle import vit as o
+    dc = DinoConfig(layers=2)
+    W = {k: v.to(torch.bfloat16) for k, v in synthetic.dino_weights(dc, 3).items()}
+    rewards.configure_dino(vit.DinoV2(W, dc, "cuda"))
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.rand(3, 3, 128, 128, generator=g).to(torch.bfloat16), torch.rand(4, 3, 128, 128, generator=g).to(torch.bfloat16)
+    s, info = rewards.multi_score("cuda", {"image_similarity": 1.0})(a.cuda(), None, None, ref_images=b.cuda())[0]["image_similarity"], None
+    W32 = {k: v.float().cuda() for k, v in W.items()}
+    ea = o.dino_forward_features(W32, dc, o_rw.dino_preprocess(a, cuda_semantics=True).float().cuda())[:, 0]
+    eb = o.dino_forward_features(W32, dc, o_rw.dino_preprocess(b, cuda_semantics=True).float().cuda())[:, 0]
+    ea, eb = ea / ea.norm(dim=-1, keepdim=True), eb / eb.norm(dim=-1, keepdim=True)
+    ref = (ea @ eb.T).max(dim=1).values
+    assert s.shape == (3,) and (s - ref).abs().max().item() < 2e-2, (s, ref)
