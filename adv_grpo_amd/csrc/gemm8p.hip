@@ -207,7 +207,8 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, f32x4 (&acc)[8]
                 f.r[ps] = ld16(p.residual, __umul24(out_row(c, row), (uint32_t)p.ldr) + n);
         }
         f.g = uint4{0u, 0u, 0u, 0u};
-        if (has_gate && i < 8 && n_ok) f.g = ld16(p.gate, __umul24((uint32_t)c.gate_b, (uint32_t)p.gate_stride) + n);
+        if (has_gate && i < 8 && mw0 + i * 16 < p.M && n_ok)     // (a slab past the last row has no gate vector: out of bounds)
+            f.g = ld16(p.gate, __umul24((uint32_t)c.gate_b, (uint32_t)p.gate_stride) + n);
     };
     Cur c0 = start(__builtin_amdgcn_readfirstlane(mw0)), c1 = c0, c2;
     advance(c1);
