@@ -55,3 +55,31 @@ def load_lora(path):
     if cfg.get("peft_type", "LORA") != "LORA":
         raise ValueError(f"{path}: not a LoRA adapter ({cfg.get('peft_type')})")
     return out, cfg
+
+
+# ---------------------------------------------------------------- resume state (what the reference does not save)
+# save_ckpt upstream writes the LoRA only (TP:389-398): the DINO head (TD:592-603) is never written and optimizer / EMA /
+# step state cannot be restored.  SURVEY 8(f2) asks for it: one extra safetensors file next to the PEFT ones,
+# `trainer_state.safetensors` (+ `trainer_state.json` for the scalars), which PEFT ignores when it loads the adapter.
+RESUME_FILE, RESUME_META = "trainer_state.safetensors", "trainer_state.json"
+
+
+def save_resume_state(path, tensors, scalars):
+    """tensors: {name: tensor} (flat f32 vectors: LoRA master weights, Adam moments, EMA, discriminator parameters and
+    moments ...); scalars: JSON-serialisable dict (global_step, epoch, opt_step ...)."""
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    save_file({k: v.detach().to("cpu").contiguous() for k, v in tensors.items()}, os.path.join(path, RESUME_FILE),
+              metadata={"format": "pt"})
+    with open(os.path.join(path, RESUME_META), "w") as f:
+        json.dump(scalars, f, indent=2, sort_keys=True)
+
+
+def load_resume_state(path):
+    """-> (tensors, scalars) or (None, None) when the checkpoint holds the adapter only (e.g. one written upstream)."""
+    from safetensors.torch import load_file
+    if not os.path.exists(os.path.join(path, RESUME_FILE)):
+        return None, None
+    with open(os.path.join(path, RESUME_META)) as f:
+        scalars = json.load(f)
+    return load_file(os.path.join(path, RESUME_FILE)), scalars

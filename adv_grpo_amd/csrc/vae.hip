@@ -204,8 +204,44 @@ extern "C" int advgrpo_groupnorm_nhwc(const void* x, void* y, double* stats, con
     return 0;
 }
 
+// long rows (n > 8192: the 16384 keys of the mid-block attention at 1024^2): one workgroup per row, three passes over a
+// row that stays in L2 (32 KiB at n = 16384) instead of registers; same arithmetic
+__global__ __launch_bounds__(256) void softmax_rows_long_kernel(bf16_t* __restrict__ s, int n) {
+    __shared__ float red[4];
+    bf16_t* r = s + (int64_t)blockIdx.x * n;
+    const int n8 = n >> 3;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < n8; c += 256) {
+        float v[8];
+        unpack8v(*reinterpret_cast<const uint4*>(r + c * 8), v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mx = fmaxf(mx, v[k]);
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < n8; c += 256) {
+        float v[8];
+        unpack8v(*reinterpret_cast<const uint4*>(r + c * 8), v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += __expf(v[k] - mx);
+    }
+    const float inv = 1.0f / block_sum<4>(sum, red);
+    for (int c = threadIdx.x; c < n8; c += 256) {
+        float v[8];
+        unpack8v(*reinterpret_cast<const uint4*>(r + c * 8), v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __expf(v[k] - mx) * inv;
+        *reinterpret_cast<uint4*>(r + c * 8) = pack8v(v);
+    }
+}
+
 extern "C" int advgrpo_softmax_rows(void* s, int64_t rows, int n, void* stream) {
-    ADVGRPO_CHECK(s && rows > 0 && n > 0 && n % 8 == 0 && n <= 8192, "softmax_rows: need n %% 8 == 0, n <= 8192 (n=%d)", n);
+    ADVGRPO_CHECK(s && rows > 0 && n > 0 && n % 8 == 0 && rows < (1ll << 31), "softmax_rows: need n %% 8 == 0 (n=%d)", n);
+    if (n > 8192) hipLaunchKernelGGL(softmax_rows_long_kernel, dim3((unsigned)rows), dim3(256), 0, as_stream(stream), (bf16_t*)s, n);
+    else
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), (bf16_t*)s,
                        rows, n);
     ADVGRPO_LAUNCH_CHECK();

@@ -44,3 +44,21 @@ def all_mean(t):
     s = torch.stack([t.float().sum(), torch.tensor(float(t.numel()), device=t.device)])
     dist.all_reduce(s)
     return s[0] / s[1]
+
+
+def average_gradients(flat):
+    """The update half's exchange: all-reduce (sum) of a flat gradient vector, then / world -- what DeepSpeed / DDP do to
+    the LoRA gradients inside ``accelerator.backward`` (TP:1165) and DDP to the DINO head (TD:749).  In place; every rank
+    ends with the same vector, so the optimizer steps that follow stay identical without a parameter broadcast."""
+    n = world()
+    if n > 1:
+        dist.all_reduce(flat)
+        flat /= n
+    return flat
+
+
+def broadcast_state(tensors, src=0):
+    """Rank `src`'s trainable state on every rank (DDP / DeepSpeed broadcast at construction, TD:749, TP:554-561)."""
+    if world() > 1:
+        for t in tensors:
+            dist.broadcast(t, src=src)

@@ -148,9 +148,7 @@ class Trainer:
         if world > 1:
             # every trainable state starts identical on all ranks: rank 0's values are broadcast, as DDP / DeepSpeed do
             # at construction (TD:749, TP:554-561); afterwards only all-reduced gradients change them
-            import torch.distributed as dist
-            for state in self._trainable_state():
-                dist.broadcast(state, src=0)
+            D.broadcast_state(self._trainable_state())
             if hasattr(pipeline.transformer, "refresh"):
                 pipeline.transformer.ema.copy_(pipeline.transformer.params)
                 pipeline.transformer.refresh()
@@ -345,7 +343,53 @@ class Trainer:
             return None
         path = checkpoint.checkpoint_dir(self.cfg.save_dir, self.global_step)
         self.pipe.transformer.save_pretrained(path, use_ema=bool(self.cfg.train.ema))
+        tensors, scalars = self.resume_state()
+        checkpoint.save_resume_state(path, tensors, scalars)
         return path
+
+    # ------------------------------------------------------------------ resume (what upstream cannot restore)
+    def _stateful(self):
+        """(name, object with .params / .exp_avg / .exp_avg_sq / .opt_step) of everything an optimizer updates."""
+        out = [("lora", self.pipe.transformer)]
+        if self.head is not None and hasattr(self.head, "exp_avg"):
+            out.append(("head", self.head))                                                 # DINOHead, TD:592-603
+        if self.clip_trainable is not None:
+            out.append(("clip_last_layer", self.clip_trainable))                           # TP:1016-1020
+        return out
+
+    def resume_state(self):
+        tensors, scalars = {}, {"global_step": self.global_step, "epoch": self.epoch}
+        for name, obj in self._stateful():
+            tensors[f"{name}.params"], tensors[f"{name}.exp_avg"] = obj.params, obj.exp_avg
+            tensors[f"{name}.exp_avg_sq"] = obj.exp_avg_sq
+            scalars[f"{name}.opt_step"] = int(obj.opt_step)
+        tensors["lora.ema"] = self.pipe.transformer.ema
+        return tensors, scalars
+
+    def load_checkpoint(self, path):
+        """Restore a checkpoint written by save_checkpoint.  With the resume file: bit-exact continuation (live LoRA master
+        weights, Adam moments and step counts, EMA, discriminator state, epoch / global_step -- the sampler and the noise
+        streams are functions of those).  Without it (an adapter written upstream): PeftModel.from_pretrained semantics,
+        TP:506-509."""
+        from . import checkpoint
+        tensors, scalars = checkpoint.load_resume_state(path)
+        if tensors is None:
+            state, _ = checkpoint.load_lora(path)
+            self.pipe.transformer.load_lora_state(state)
+            return False
+        for name, obj in self._stateful():
+            for field in ("params", "exp_avg", "exp_avg_sq"):
+                getattr(obj, field).copy_(tensors[f"{name}.{field}"].to(obj.params.device))
+            obj.opt_step = int(scalars[f"{name}.opt_step"])
+            if hasattr(obj, "p16"):
+                obj.p16.copy_(obj.params)
+            if hasattr(obj, "sync_model"):
+                obj.sync_model()
+        tr = self.pipe.transformer
+        tr.ema.copy_(tensors["lora.ema"].to(tr.params.device))
+        tr.refresh()
+        self.global_step, self.epoch = int(scalars["global_step"]), int(scalars["epoch"])
+        return True
 
     # ------------------------------------------------------------------ one epoch
     def run_epoch(self):
@@ -397,13 +441,7 @@ class Trainer:
         return {"phase": "G", **info}
 
     def d_step(self, samples):
-        reduce = None
-        if self.world > 1:
-            import torch.distributed as dist
-
-            def reduce(g):
-                dist.all_reduce(g)
-                g /= self.world
+        reduce = D.average_gradients if self.world > 1 else None
         if self.variant != "dino":
             d_loss = train_pickscore(self.clip_trainable, samples["clip_ids"], samples["ref_images"], samples["images"],
                                      lr=self.cfg.d_lr, all_reduce=reduce)                   # TP:1025-1037
@@ -437,10 +475,7 @@ class Trainer:
                         agg[k] = agg.get(k, 0) + info[k]
                     n_acc += 1
                 if (i + 1) % GA == 0:                                                       # sync_gradients, TP:1166-1185
-                    if self.world > 1:
-                        import torch.distributed as dist
-                        dist.all_reduce(model.grads)
-                        model.grads /= self.world
+                    D.average_gradients(model.grads)                                       # TP:1165 (DeepSpeed / DDP)
                     model.optimizer_step(lr=c.train.learning_rate, betas=(c.train.adam_beta1, c.train.adam_beta2),
                                          eps=c.train.adam_epsilon, weight_decay=c.train.adam_weight_decay,
                                          max_grad_norm=c.train.max_grad_norm)

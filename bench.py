@@ -35,17 +35,23 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
-    ap.add_argument("--no-epoch", action="store_true", help="skip the untimed-for-the-metric full-epoch leg (N=1 only)")
+    ap.add_argument("--no-epoch", action="store_true", help="skip the untimed-for-the-metric full-epoch leg")
+    ap.add_argument("--epoch", action="store_true", help="run the full-epoch leg for N > 1 too (adds the LoRA-gradient all-reduce "
+                                                         "of the G-step to what the scaling curve exercises)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4"],
+                    help="c2 = the headline (BASELINE config 2); c4 = secondary line, SD3.5-large 1024^2 G=4 (BASELINE config 4 shapes)")
     return ap.parse_args()
 
 
-def build(device):
+def build(device, large=False):
     from adv_grpo_amd import synthetic, vit
     from adv_grpo_amd.mmdit import SD3Transformer2DModel
     from adv_grpo_amd.pipeline import SD3Pipeline
     from adv_grpo_amd.vae import AutoencoderKLDecoder
     from adv_grpo_amd.model_configs import ClipConfig, MMDiTConfig, VaeConfig
     mcfg, vcfg, ccfg = MMDiTConfig(), VaeConfig(), ClipConfig()
+    if large:     # stabilityai/stable-diffusion-3.5-large: 38 joint blocks, 38 heads x 64 = 2432, no dual-attention blocks
+        mcfg = MMDiTConfig(num_layers=38, num_heads=38, dual_attention_layers=(), pos_embed_max_size=192)
     with synthetic.on_device(device):
         tr = SD3Transformer2DModel(synthetic.mmdit_weights(mcfg, 1234), mcfg, device)
         vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(vcfg, 4321), vcfg, device)
@@ -57,20 +63,23 @@ def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate runs of this same command, scripts/pmc_traffic.py: (2*FETCH_SIZE + WRITE_SIZE)*1024, the factor 2 being
     the gfx950 correction of MI355X_MICROARCH.md)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None, None
-    want = {kernel}
-    tot, n = 0.0, 0
-    for name, v in json.load(open(path)).items():
-        short = name.replace(" ", "").split("advgrpo::")[-1]
-        if short in want:
-            tot += v["hbm_bytes_per_launch"] * v["launches"]
-            n += v["launches"]
-    return (round(tot / n) if n else None), "profiles/r1_pmc_traffic.json"
+    root = os.path.dirname(os.path.abspath(__file__))
+    for rel in ("profiles/r2_pmc_traffic.json", "profiles/r1_pmc_traffic.json"):
+        path = os.path.join(root, rel)
+        if not os.path.exists(path):
+            continue
+        tot, n = 0.0, 0
+        for name, v in json.load(open(path)).items():
+            short = name.replace(" ", "").split("advgrpo::")[-1]
+            if short == kernel or short.startswith(kernel + "<"):        # all template instantiations of the kernel
+                tot += v["hbm_bytes_per_launch"] * v["launches"]
+                n += v["launches"]
+        if n:
+            return round(tot / n), rel
+    return None, None
 
 
-def full_epoch(device):
+def full_epoch(device, world=1, rank=0):
     """the whole sample -> score -> gather -> advantage -> G-step loop and its phases, outside the timed
     region of the headline metric: config 2 (pickscore_cotrain_sd3_fast preset, 8 images per prompt so that one rank
     holds whole groups), 2 prompt groups per epoch = 16 images, 2 optimizer steps; the second epoch is reported."""
@@ -82,7 +91,7 @@ def full_epoch(device):
     from adv_grpo_amd.pipeline import SD3Pipeline
     from adv_grpo_amd.trainer import SyntheticData, Trainer
     from adv_grpo_amd.vae import AutoencoderKLDecoder
-    cfg = get_config("pickscore_cotrain_sd3_fast", gpu_number=1)
+    cfg = get_config("pickscore_cotrain_sd3_fast", gpu_number=world)
     cfg.sample.num_image_per_prompt = 8
     cfg.sample.num_batches_per_epoch = 2
     cfg.train.gradient_accumulation_steps = 1
@@ -93,19 +102,28 @@ def full_epoch(device):
         vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321), VaeConfig(), device)
         scorer = PickScoreScorer(device, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
     trainer = Trainer(cfg, SD3Pipeline(tr, vae, device), SyntheticData(resolution=cfg.resolution, device=device), scorer,
-                      None, 0, 1, log_path=None)
+                      None, rank, world, log_path=None)
     trainer.run_epoch()                      # warm-up epoch
     trainer.timers.clear()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     trainer.run_epoch()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    images = cfg.sample.num_batches_per_epoch * cfg.sample.mini_num_image_per_prompt
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    images = world * cfg.sample.num_batches_per_epoch * cfg.sample.mini_num_image_per_prompt
     return {"images": images, "seconds": round(dt, 3), "images_per_s_full_epoch": round(images / dt, 3),
             "phases_s": {k: round(v, 4) for k, v in trainer.timers.items()},
             "note": "sample = rollout + VAE decode; score = PickScore of generated AND reference images; g_step = "
-                    "2 groups x 2 SDE timesteps fwd+bwd at CFG batch 16 + 2 clip+AdamW steps + EMA"}
+                    "2 groups x 2 SDE timesteps fwd+bwd at CFG batch 16 + 2 clip+AdamW steps + EMA (+ for N > 1 the all-reduce of "
+                    "the 37.6 MB flat LoRA gradient before each optimizer step); reward scoring runs on the worker stream and "
+                    "overlaps the next group's rollout, `score` is the wait at the end of the sampling loop"}
 
 
 def cpu_baseline():
@@ -141,9 +159,29 @@ def cpu_baseline():
                                            Wc["logit_scale"])
     dt = time.time() - t0
     assert torch.isfinite(s).all()
+    # ---- config 2's unit costs, measured (SURVEY 8d "one C2 step if time allows"): one CFG transformer forward for one
+    # image at 512^2 (batch 2, 1229 tokens), one 512^2 VAE decode, one PickScore pair -> 10 x forward + decode + score
+    with torch.no_grad():
+        x2 = torch.randn(2, 16, 64, 64)
+        t0 = time.time()
+        o_m.mmdit_forward(Wm, mcfg, x2, torch.full((2,), 900.0), torch.cat([npe, pe]), torch.cat([nppe, ppe]))
+        t_fwd = time.time() - t0
+        t0 = time.time()
+        img2 = o_v.postprocess(o_v.vae_decode(Wv, vcfg, torch.randn(1, 16, 64, 64) / vcfg.scaling_factor + vcfg.shift_factor))
+        t_vae = time.time() - t0
+        t0 = time.time()
+        px2 = torch.nn.functional.interpolate(img2, size=(224, 224), mode="bicubic", antialias=True)
+        o_rw.pickscore_from_embeddings(o_t.clip_image_features(Wc, ccfg, px2), o_t.clip_text_features(Wc, ccfg, ids[:1]), Wc["logit_scale"])
+        t_clip = time.time() - t0
+    c2_s_per_image = 10 * t_fwd + t_vae + t_clip
     return {"value": G / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"config 1: SD3.5-medium 256x256, 4 steps, G=2, CFG 4.5, VAE decode + PickScore, fp32 torch-CPU "
-                      f"oracle ({dt:.1f} s for {G} images); 512^2/10-step images cost ~6.8x more each"}
+            "sample": f"config 1 end to end: SD3.5-medium 256x256, 4 steps, G=2, CFG 4.5, VAE decode + PickScore, fp32 torch-CPU "
+                      f"oracle ({dt:.1f} s for {G} images); config 2 from its measured unit costs on the same cores: one CFG "
+                      f"transformer forward per image at 512^2 {t_fwd:.2f} s, one 512^2 VAE decode {t_vae:.2f} s, one PickScore "
+                      f"{t_clip:.2f} s -> 10 steps = {c2_s_per_image:.1f} s per sampled+scored image",
+            "config2_images_per_s": round(1.0 / c2_s_per_image, 5),
+            "config2_unit_costs_s": {"transformer_cfg_forward_512": round(t_fwd, 3), "vae_decode_512": round(t_vae, 3),
+                                     "pickscore": round(t_clip, 3)}}
 
 
 def main():
@@ -171,8 +209,9 @@ def main():
     from adv_grpo_amd.sampler import DistributedKRepeatSampler
     from adv_grpo_amd.trainer import rollout_seed
 
-    pipe, clip = build(device)
-    G, STEPS, T, RES = 8, 10, 2, 512
+    c4 = args.config == "c4"
+    pipe, clip = build(device, large=c4)
+    G, STEPS, T, RES = (4, 10, 2, 1024) if c4 else (8, 10, 2, 512)
     sampler = DistributedKRepeatSampler(range(25432), 1, 1, world, rank, seed=42)   # k = 1: one group per rank
     # synthetic prompts: one embedding set per dataset index is not needed for timing; a fixed set per rank
     pe, ppe, npe, nppe = (t.to(device=device, dtype=torch.bfloat16) for t in synthetic.prompt_embeddings(7 + rank))
@@ -231,26 +270,46 @@ def main():
                     "launches": n, "avg_launch_us": round(tsec / n * 1e6, 2),
                     "algorithmic_flops_per_launch": fl / n, "share_of_step_time": round(tsec / dt, 3)}
         images = world * G * args.steps
-        # algorithmic FLOPs per sampled+scored image: 10*2*2.219 + 2.51 + 0.38 TFLOP
-        per_image_tflop = 10 * 2 * 2.219 + 2.51 + 0.38
+        # algorithmic FLOPs per sampled+scored image: 10*2*2.219 + 2.51 + 0.38 TFLOP at config 2;
+        # SD3.5-large 1024^2 (config 4 shapes): 30.02 TFLOP per sample-forward, VAE x4 pixels
+        per_image_tflop = (10 * 2 * 30.02 + 4 * 2.51 + 0.38) if c4 else (10 * 2 * 2.219 + 2.51 + 0.38)
+        # the decoder on its own (bf16 MFMA / f32 accumulate; the reference decodes in fp32, TP:481 -- DESIGN 3 deviation 1)
+        lat = torch.randn(G, 16, RES // 8, RES // 8, device=device).to(torch.bfloat16)
+        pipe.vae.decode_to_image(lat)
+        torch.cuda.synchronize()
+        tv = time.perf_counter()
+        for _ in range(3):
+            pipe.vae.decode_to_image(lat)
+        torch.cuda.synchronize()
+        vae_ms = (time.perf_counter() - tv) / 3 * 1e3
         res = {
-            "metric": "sampled+scored images/sec (whole node), SD3-med 512^2 10-step G=8 GRPO",
+            "metric": "sampled+scored images/sec (whole node), SD3.5-large 1024^2 10-step G=4 (secondary line, BASELINE config 4 shapes)"
+            if c4 else "sampled+scored images/sec (whole node), SD3-med 512^2 10-step G=8 GRPO",
             "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: SD3.5-medium LoRA-merged 512x512, 10 steps, CFG 4.5, G=8, "
-                                   "SDE window 2 @ noise 0.8, VAE decode, PickScore (CLIP ViT-H/14) reward, "
-                                   "reward all-gather + group advantage", "global_batch": world * G,
+            "config": {"workload": ("BASELINE config 4 shapes: SD3.5-large (38 blocks, D=2432) LoRA-merged 1024x1024, 10 steps, CFG 4.5, "
+                                    "G=4, SDE window 2 @ noise 0.8, VAE decode, PickScore reward (the OCR half of the reward is a "
+                                    "host plugin outside the timed path), reward all-gather + group advantage") if c4 else
+                                   ("BASELINE config 2: SD3.5-medium LoRA-merged 512x512, 10 steps, CFG 4.5, G=8, "
+                                    "SDE window 2 @ noise 0.8, VAE decode, PickScore (CLIP ViT-H/14) reward, "
+                                    "reward all-gather + group advantage"), "global_batch": world * G,
                        "transformer_batch_per_gpu": 2 * G, "parallelism": f"dp{world} (prompt groups sharded)"},
             "effective_tflops_per_gpu": round(per_image_tflop * images / dt / world, 1),
             "frac_of_bf16_mfma_peak": round(per_image_tflop * images / dt / world / BF16_DENSE_PEAK_TFLOPS, 4),
             "roofline": roofline,
+            "vae": {"mode": "bf16 MFMA / f32 accumulate, bf16 activations", "ms_per_group_decode": round(vae_ms, 2),
+                    "share_of_step_time": round(vae_ms / (dt / args.steps * 1e3), 4)},
         }
-        if world == 1 and not args.no_epoch:
-            del pipe, clip
-            torch.cuda.empty_cache()
-            res["epoch"] = full_epoch(device)
-        if world == 1 and not args.no_cpu_baseline:
+    run_epoch = not c4 and not args.no_epoch and (world == 1 or args.epoch)
+    if run_epoch:                                   # every rank takes part (LoRA-gradient all-reduce, reward gather)
+        del pipe, clip
+        torch.cuda.empty_cache()
+        ep = full_epoch(device, world, rank)
+        if rank == 0:
+            res["epoch"] = ep
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline and not c4:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
     if dist is not None:

@@ -58,3 +58,43 @@ def test_two_rank_gather_advantage_ungather(tmp_path):
     gids = a[n_all * 2: n_all * 2 + n_all].reshape(2, 3, 4)[:, :, 0]
     assert np.array_equal(gids[0], gids[1])  # k = 2: both ranks draw the same prompt each iteration -> groups of 8
     assert len(set(gids[0])) == 3
+
+
+def _worker_update(rank, world, port, out_dir):
+    """The update half's exchange: ranks hold DIFFERENT gradients (their own prompt groups); after the
+    all-reduce + / world every rank feeds the optimizer the same vector, so identical Adam steps keep the replicated
+    LoRA / head parameters identical without ever broadcasting them again.  The trainable state itself starts from rank 0's
+    values (broadcast at construction)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from adv_grpo_amd import distributed as D
+    g = torch.Generator().manual_seed(100 + rank)                 # rank-dependent initial state and gradients
+    params = torch.randn(1000, generator=g)
+    head = torch.randn(77, generator=g)
+    D.broadcast_state([params, head])
+    lora_grad = torch.randn(1000, generator=g)
+    head_grad = torch.randn(77, generator=g)
+    mine = lora_grad.clone()
+    D.average_gradients(lora_grad)                                # G-step: trainer.g_step before optimizer_step
+    D.average_gradients(head_grad)                                # D-step: the closure handed to train_dino / train_pickscore
+    # a plain Adam step on the averaged gradient: identical inputs -> identical parameters on both ranks
+    opt = torch.optim.AdamW([torch.nn.Parameter(params.clone())], lr=3e-4, weight_decay=1e-4)
+    opt.param_groups[0]["params"][0].grad = lora_grad
+    opt.step()
+    np.save(os.path.join(out_dir, f"u{rank}.npy"), np.concatenate([params.numpy(), head.numpy(), lora_grad.numpy(), head_grad.numpy(),
+                                                                   opt.param_groups[0]["params"][0].detach().numpy()]))
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), mine.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_and_state_broadcast(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker_update, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "u0.npy"), np.load(tmp_path / "u1.npy")
+    assert np.array_equal(a, b)
+    g0, g1 = np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy")
+    assert not np.array_equal(g0, g1)
+    np.testing.assert_allclose(a[1077:2077], (g0 + g1) / 2, rtol=1e-6)     # the averaged LoRA gradient
+    # rank 0's initial state everywhere
+    g = torch.Generator().manual_seed(100)
+    np.testing.assert_array_equal(a[:1000], torch.randn(1000, generator=g).numpy())

@@ -83,3 +83,17 @@ def test_mmdit_sd35_large_width():
     e_hip, e_torch = _rel(out, ref), _rel(tb, ref)
     assert e_hip < max(2 * e_torch, 2e-2), (e_hip, e_torch)
     assert _rel(inter["x2"], rinter["x2"]) < 3e-2
+
+
+def test_mmdit_sd35_large_width_at_1024():
+    """BASELINE config 4's transformer shape, reduced depth: SD3.5-large width (D = 2432 = 38 heads x 64, no dual blocks)
+    at 1024 x 1024 -- 4096 image tokens + 205 text tokens, S = 4301, CFG pair.  This is where the 256x256 eight-phase GEMM
+    runs with N = 2432 (9.5 column tiles: a ragged last tile), K = 2432 = 38 k-tiles, and attention at S = 4301."""
+    from oracle.mmdit import MMDiTConfig
+    cfg = MMDiTConfig(num_layers=3, num_heads=38, pos_embed_max_size=192, dual_attention_layers=())
+    out, ref, tb, inter, rinter = _run(cfg, B=2, hw=128, Nt=205, seed=78)
+    assert out.shape == (2, 16, 128, 128)
+    e_hip, e_torch = _rel(out, ref), _rel(tb, ref)
+    print("SD3.5-large width @1024^2: rel err hip", e_hip, "torch-bf16", e_torch)
+    assert e_hip < max(2 * e_torch, 2e-2), (e_hip, e_torch)
+    assert _rel(inter["x3"], rinter["x3"]) < 3e-2

@@ -1,5 +1,7 @@
 """GPU: the epoch loop end to end on a reduced-depth stack -- D-step epoch then G-step epoch (DINO variant), and a
 G-step epoch with the PickScore reward; checks the plumbing (shapes, gate, optimizer step, parameter movement)."""
+import os
+
 import pytest
 import torch
 
@@ -265,3 +267,39 @@ def test_image_similarity_scorer_on_the_kernels():
     ea, eb = ea / ea.norm(dim=-1, keepdim=True), eb / eb.norm(dim=-1, keepdim=True)
     ref = (ea @ eb.T).max(dim=1).values
     assert s.shape == (3,) and (s - ref).abs().max().item() < 2e-2, (s, ref)
+
+
+def test_checkpoint_resume_restores_state_bit_exactly(tmp_path):
+    """f2: the resume file next to the PEFT adapter restores live LoRA weights, Adam moments, step counts, EMA and the
+    discriminator head (none of which upstream's save_ckpt writes, TP:389-398 / TD:592-603): a restored trainer takes the
+    SAME optimizer step from the same samples, bit for bit."""
+    from adv_grpo_amd import checkpoint
+    tr_a, model_a, head_a = _build("dino", d_times=2, save_dir=str(tmp_path))
+    tr_a.run_epoch()                       # D-step: moves the head and its Adam moments
+    tr_a.run_epoch()                       # G-step: moves the LoRA weights, moments, EMA bookkeeping
+    model_a.ema_step(7)
+    path = tr_a.save_checkpoint()
+    assert sorted(os.listdir(path)) == ["adapter_config.json", "adapter_model.safetensors", "trainer_state.json", "trainer_state.safetensors"]
+    tr_b, model_b, head_b = _build("dino", d_times=2, save_dir=str(tmp_path))
+    assert not torch.equal(model_b.params, model_a.params)
+    assert tr_b.load_checkpoint(path) is True
+    for x, y in ((model_a, model_b), (head_a, head_b)):
+        for f in ("params", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(getattr(x, f), getattr(y, f)), f
+        assert x.opt_step == y.opt_step
+    assert torch.equal(model_a.ema, model_b.ema) and (tr_a.global_step, tr_a.epoch) == (tr_b.global_step, tr_b.epoch)
+    # the adapter file alone (what upstream writes) still loads, with from_pretrained semantics
+    state, _ = checkpoint.load_lora(path)
+    assert torch.equal(state["transformer_blocks.0.attn.to_q.lora_A.weight"].cuda(),
+                       model_a.A_view(model_a.adapters["transformer_blocks.0.attn.to_q"], model_a.ema)[:32])
+    # same samples -> same G-step on both trainers
+    samples = tr_a.sample_epoch()
+    samples["advantages"] = torch.randn(samples["rewards"].shape[0], tr_a.cfg.sample.train_num_steps, device="cuda")
+    tr_a.g_step(samples)
+    tr_b.g_step(samples)
+    # (the backward accumulates the normalisation-layer gradients with f32 atomics, so a G-step repeats only up to summation
+    # order: Adam turns a last-bit difference of a near-zero gradient into up to one lr of parameter difference)
+    n_opt = tr_a.cfg.sample.num_batches_per_epoch            # optimizer steps inside one g_step here
+    assert (model_a.params - model_b.params).abs().max().item() <= 2 * (n_opt + 1) * tr_a.cfg.train.learning_rate
+    assert torch.allclose(model_a.exp_avg_sq, model_b.exp_avg_sq, rtol=1e-2, atol=1e-12)
+    assert tr_a.global_step == tr_b.global_step

@@ -40,6 +40,11 @@ def test_groupnorm_silu_and_softmax_rows():
     ops.softmax_rows_(s)
     assert (s.float() - ref).abs().max().item() < 1e-3
     assert ((s.float().sum(-1) - 1).abs() < 2e-2).all()
+    # long rows: the 16384 keys of the decoder's mid-block attention at 1024^2 (one workgroup per row)
+    s = (torch.randn(5, 16384, device="cuda", generator=g) * 3).to(torch.bfloat16)
+    ref = s.float().softmax(-1)
+    ops.softmax_rows_(s)
+    assert (s.float() - ref).abs().max().item() < 1e-3 and ((s.float().sum(-1) - 1).abs() < 2e-2).all()
 
 
 @pytest.mark.parametrize("B,hw", [(2, 16), (1, 64)])
