@@ -1,0 +1,519 @@
+// gemm8p_kernel.hpp -- device code of the 256 x 256 eight-phase persistent GEMM (see gemm8p.hip for the description) and the
+// launch helper shared by the translation units that instantiate its epilogue classes (gemm8p.hip: rollout classes,
+// gemm8p_train.hip: G-step classes -- two files so that the instantiations compile in parallel).
+#pragma once
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "gemm_device.hpp"
+
+namespace advgrpo {
+
+namespace {
+
+constexpr int P8_BM = 256, P8_BN = 256, P8_BK = 64;
+constexpr int P8_HALF = 128 * P8_BK * 2;          // one ring item: 128 rows x 128 B
+constexpr int P8_BUF = 4 * P8_HALF;               // one k-tile buffer: A sub 0, A sub 1, W sub 0, W sub 1
+constexpr int P8_LDS = 2 * P8_BUF;                // 128 KiB
+constexpr int P8_SCRATCH = 2 * 16 * 64 * 4;       // per-wave epilogue scratch: 2 slabs of 16 rows x 64 f32, inside buffer 1
+
+// One LDS-DMA instruction: 64 lanes x 16 bytes from (uniform base + per-lane 32-bit offset) to LDS [m0 .. m0 + 1 KiB).
+// Hand-written because the builtin form keeps every per-lane source as a 64-bit VGPR pair and re-adds the k offset on the
+// VALU: 24 VGPRs and 8 v_lshl_add_u64 per k-tile more than the SGPR-base form, enough to spill inside the main loop.
+__device__ __forceinline__ void p8_dma16(const char* base, uint32_t off, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const char* p) {
+    return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)(p));
+}
+// wait until at most `allowed` ring items (2 DMA instructions each) of this wave are still in flight
+__device__ __forceinline__ void p8_wait_inflight(int allowed) {
+    if (allowed >= 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (allowed == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (allowed == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (allowed == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (allowed == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// What a workgroup needs to stream one output tile: the problem, the tile origin and the per-lane DMA sources.  A ring
+// item is what every wave reads in ONE phase: item "A sub s" = rows {s*64 .. s*64+63} of both 128-row wave-row halves,
+// item "W sub s" = columns {s*32 .. s*32+31} of the four 64-wide wave columns; slot row r of the 128-row item image belongs
+// to wave row r >> 6 (A) / wave column r >> 5 (W).  Sources are 32-bit byte offsets from the uniform operand bases (the
+// DMA takes "SGPR base + VGPR offset").
+struct P8Tile {
+    bool second;                     // problem b of a paired launch
+    int m0, n0, nk;
+    const char* a_bytes;             // operand bases (uniform)
+    const char* w_bytes;
+    uint32_t a_off[2][2], b_off[2][2];
+};
+
+__device__ __forceinline__ void p8_setup(P8Tile& t, const GemmParams& pr, int id, int wave, int lane) {
+    const GemmParams* p = &pr;
+    const int tiles_n = (p->N + P8_BN - 1) / P8_BN, tiles_m = (p->M + P8_BM - 1) / P8_BM;
+    int tile_m, tile_n;
+    tile_coords(id, tiles_m, tiles_n, 4, tile_m, tile_n);
+    t.a_bytes = reinterpret_cast<const char*>(p->A);
+    t.w_bytes = reinterpret_cast<const char*>(p->W);
+    t.m0 = tile_m * P8_BM;
+    t.n0 = tile_n * P8_BN;
+    t.nk = p->K / P8_BK;
+    const int lrow = lane >> 3;                   // row inside an 8-row DMA instruction
+    const int schunk = (lane & 7) ^ lrow;         // pre-swizzled source chunk of this lane's LDS slot
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int sr = (wave + it * 8) * 8 + lrow;                    // slot row of this lane's 16 bytes
+            int r = t.m0 + (sr >> 6) * 128 + sub * 64 + (sr & 63);
+            r = r < p->M ? r : p->M - 1;
+            int64_t ar = r;
+            if (p->a_seg_rows > 0) {
+                const int bi = r / p->a_seg_rows;
+                ar = (int64_t)bi * p->a_seg_stride + p->a_seg_off + (r - bi * p->a_seg_rows);
+            }
+            t.a_off[sub][it] = (uint32_t)((ar * p->lda + schunk * 8) * 2);
+            int n = t.n0 + (sr >> 5) * 64 + sub * 32 + (sr & 31);
+            n = n < p->N ? n : p->N - 1;
+            t.b_off[sub][it] = (uint32_t)(((int64_t)n * p->ldw + schunk * 8) * 2);
+        }
+}
+
+// which = 0,1: A sub 0 / 1; 2,3: W sub 0 / 1
+__device__ __forceinline__ void p8_stage(const P8Tile& t, char* smem, int wave, int buf, int which, int kt) {
+    if (kt >= t.nk) return;
+    char* base = smem + buf * P8_BUF + which * P8_HALF;
+    const char* src = (which < 2 ? t.a_bytes : t.w_bytes) + kt * (P8_BK * 2);   // uniform
+    const uint32_t* off = which < 2 ? t.a_off[which] : t.b_off[which - 2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) p8_dma16(src, off[it], lds_addr(base + (wave + it * 8) * 1024));
+}
+
+// Fused epilogue.  Same arithmetic, in the same order, as gemm_epilogue_rows (gemm_device.hpp) -- results are bit-identical to
+// the other tile variants.  With one workgroup per CU nothing overlaps the epilogue, so it is built for a low instruction
+// count (the first version spent 16 us per tile here, 30 us being the whole k loop):
+//   * ONE copy of the code: a runtime loop over four rounds of two 16-row slabs.  Accumulators may only be indexed
+//     statically (a runtime-indexed accumulator array goes to scratch memory), so every round writes accumulator slabs 0
+//     and 1 to the wave's private 8 KiB of LDS and rotates the other slabs down by two; fully unrolled with every option the
+//     code of this tile is ~100k instructions and the instruction fetch alone cost 29 us per tile;
+//   * LDS bounce: f32 rows of 256 B, 16-byte chunk c of row r at slot c ^ (r & 7) -- conflict-free for the ds_write_b128
+//     of the accumulator layout (8 lanes = 8 rows, one chunk) and for the ds_read_b128 of the row layout (a lane ends
+//     with 8 consecutive columns of one row: 16-byte loads of bias / gate / residual / aux, 16-byte stores);
+//   * no integer division per row: the output-row map (row-segment scatter) and the gate index advance as wave-uniform
+//     (segment, remainder) pairs from slab to slab, a lane only checks whether ITS row wrapped into the next segment;
+//   * 32-bit element offsets from the uniform operand bases (host-checked), 24-bit multiplies;
+//   * residual rows and the gate vector of a slab are requested two slabs ahead of their use.
+//   * specialised at compile time for the four epilogues of the rollout (EPI_*): skipping the unused options with
+//     wave-uniform branches cost more than the arithmetic (a taken branch is an instruction-fetch bubble; the generic
+//     code took 22-28k cycles per tile, 55k being the k loop).
+// A class is a set of features fixed at compile time (EPI_GENERIC: everything decided at run time).
+enum { EPI_GENERIC = -1, F_BIAS = 1, F_RMS = 2 /* per-head QK RMSNorm */, F_GELU = 4 /* gelu_tanh */, F_GATE_RES = 8 /* * gate + residual */,
+       F_AUX_OUT = 16 /* keep the pre-activation (training forward) */, F_DGELU = 32 /* y *= gelu_tanh'(aux_in) (training backward) */ };
+enum { EPI_PLAIN = 0, EPI_BIAS = F_BIAS, EPI_BIAS_RMS = F_BIAS | F_RMS, EPI_BIAS_GELU = F_BIAS | F_GELU, EPI_BIAS_GATE_RES = F_BIAS | F_GATE_RES,
+       EPI_BIAS_GELU_AUX = F_BIAS | F_GELU | F_AUX_OUT, EPI_DGELU = F_DGELU };
+
+template <int EPI>
+__device__ __forceinline__ void p8_epilogue(const GemmParams& p, f32x4 (&acc)[8][4], int mw0, int nw0, int lane, char* scratch) {
+    constexpr bool G = EPI == EPI_GENERIC;
+    // features: compile-time constants in the specialised classes (bf16 output, alpha = 1 is NOT assumed)
+    const bool has_bias = G ? p.bias != nullptr : (EPI & F_BIAS) != 0;
+    const bool has_rms = G ? p.rms_w != nullptr : (EPI & F_RMS) != 0;
+    const bool has_gate = G ? p.gate != nullptr : (EPI & F_GATE_RES) != 0;
+    const bool has_res = G ? p.residual != nullptr : (EPI & F_GATE_RES) != 0;
+    const bool has_aux_out = G ? p.aux_out != nullptr : (EPI & F_AUX_OUT) != 0;
+    const bool out_bf16 = G ? p.out_dtype == ADVGRPO_BF16 : true;
+    const int mrow = lane & 15, q = lane >> 4;
+    const int orow_l = lane >> 3, c8 = (lane & 7) * 8;
+    const int n = nw0 + c8;
+    const bool n_ok = n < p.N;
+    auto unpack8 = [](const uint4& v, float (&f)[8]) __attribute__((always_inline)) {
+        f[0] = bf2f((bf16_t)(v.x & 0xffffu)); f[1] = bf2f((bf16_t)(v.x >> 16));
+        f[2] = bf2f((bf16_t)(v.y & 0xffffu)); f[3] = bf2f((bf16_t)(v.y >> 16));
+        f[4] = bf2f((bf16_t)(v.z & 0xffffu)); f[5] = bf2f((bf16_t)(v.z >> 16));
+        f[6] = bf2f((bf16_t)(v.w & 0xffffu)); f[7] = bf2f((bf16_t)(v.w >> 16));
+    };
+    auto pack8 = [](const float (&v)[8]) __attribute__((always_inline)) {
+        uint4 pk;
+        pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        pk.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+        pk.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        return pk;
+    };
+    auto ld16 = [](const bf16_t* base, uint32_t elem) __attribute__((always_inline)) {
+        return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + (size_t)(elem * 2u));
+    };
+    float bias8[8];
+    if (has_bias && n_ok) unpack8(*reinterpret_cast<const uint4*>(p.bias + n), bias8);
+    // wave-uniform bookkeeping of the slab's first row m_s: output row = seg_b * seg_stride + seg_off + seg_r (identity map:
+    // seg_rows = 0 -> one segment as long as M), gate vector = gate_b
+    const int seg_rows = p.seg_rows > 0 ? p.seg_rows : 0x7fffffff;
+    const int gate_rows = p.gate_rows > 0 ? p.gate_rows : 0x7fffffff;
+    const int seg_jump = p.seg_rows > 0 ? (int)p.seg_stride - p.seg_rows : 0;   // added to the row when it wraps
+    struct Cur { int seg_b, seg_r, gate_b, gate_r; };
+    auto start = [&](int m) __attribute__((always_inline)) {
+        Cur c;
+        c.seg_b = m / seg_rows; c.seg_r = m - c.seg_b * seg_rows;
+        c.gate_b = m / gate_rows; c.gate_r = m - c.gate_b * gate_rows;
+        return c;
+    };
+    auto advance = [&](Cur& c) __attribute__((always_inline)) {     // 16 rows further
+        c.seg_r += 16;
+        while (c.seg_r >= seg_rows) { c.seg_r -= seg_rows; ++c.seg_b; }
+        c.gate_r += 16;
+        while (c.gate_r >= gate_rows) { c.gate_r -= gate_rows; ++c.gate_b; }
+    };
+    // output row of (slab cursor, row inside the slab)
+    auto out_row = [&](const Cur& c, int row) __attribute__((always_inline)) -> uint32_t {
+        const int base = p.seg_rows > 0 ? c.seg_b * (int)p.seg_stride + (int)p.seg_off + c.seg_r : c.seg_r;
+        int r = base + row;
+        if (c.seg_r + row >= seg_rows) r += seg_jump * ((c.seg_r + row - seg_rows) / seg_rows + 1);   // (segments shorter than a slab: rare, exact)
+        return (uint32_t)r;
+    };
+    // what a slab needs from memory: its residual rows (two passes of 8 rows) and the gate vector of its first row
+    struct Pre { uint4 r[2]; uint4 g; };
+    auto prefetch = [&](const Cur& c, int i, Pre& f) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int row = ps * 8 + orow_l;
+            f.r[ps] = uint4{0u, 0u, 0u, 0u};
+            if (has_res && i < 8 && mw0 + i * 16 + row < p.M && n_ok)
+                f.r[ps] = ld16(p.residual, __umul24(out_row(c, row), (uint32_t)p.ldr) + n);
+        }
+        f.g = uint4{0u, 0u, 0u, 0u};
+        if (has_gate && i < 8 && mw0 + i * 16 < p.M && n_ok)     // (a slab past the last row has no gate vector: out of bounds)
+            f.g = ld16(p.gate, __umul24((uint32_t)c.gate_b, (uint32_t)p.gate_stride) + n);
+    };
+    Cur c0 = start(__builtin_amdgcn_readfirstlane(mw0)), c1 = c0, c2;
+    advance(c1);
+    c2 = c1;
+    Pre f0, f1, f2;
+    prefetch(c0, 0, f0);
+    prefetch(c1, 1, f1);
+    const int w_off = mrow * 256, w_sw = mrow & 7;
+    const int act = G ? p.act : ((EPI & F_GELU) ? (int)ACT_GELU_TANH : ((EPI & F_DGELU) ? (int)ACT_DGELU_TANH : (int)ACT_NONE));
+#pragma unroll 1
+    for (int rd = 0; rd < 4; ++rd) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x4*>(scratch + sl * 4096 + w_off + (((j * 4 + q) ^ w_sw) << 4)) = acc[sl][j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[k][j] = acc[k + 2][j];
+#pragma unroll 1
+        for (int sl = 0; sl < 2; ++sl) {
+            const int i = rd * 2 + sl;
+            const char* slab = scratch + sl * 4096;
+            advance(c2);
+            prefetch(c2, i + 2, f2);
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int row = ps * 8 + orow_l;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * 256 + ((((lane & 7) * 2) ^ (row & 7)) << 4));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * 256 + ((((lane & 7) * 2 + 1) ^ (row & 7)) << 4));
+                if (mw0 + i * 16 + row >= p.M || !n_ok) continue;
+                const uint32_t orow = out_row(c0, row);
+                // (contraction off for the scale / bias / gate / residual steps: where a specialised class makes two of them
+                // unconditional the compiler would fuse them into an fma and the classes would stop agreeing bit for bit)
+                float v[8];
+                {
+#pragma clang fp contract(off)
+                    v[0] = lo[0] * p.alpha; v[1] = lo[1] * p.alpha; v[2] = lo[2] * p.alpha; v[3] = lo[3] * p.alpha;
+                    v[4] = hi[0] * p.alpha; v[5] = hi[1] * p.alpha; v[6] = hi[2] * p.alpha; v[7] = hi[3] * p.alpha;
+                    if (has_bias) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] + bias8[e];
+                    }
+                }
+                if (has_rms) {   // QK-norm: the wave tile's 64 columns are one head, its row sits in 8 adjacent lanes
+                    const int hh = n >> 6;
+                    float sq = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v[e] = round_bf16(v[e]);
+                        sq += v[e] * v[e];
+                    }
+                    sq += __shfl_xor(sq, 1, 64);
+                    sq += __shfl_xor(sq, 2, 64);
+                    sq += __shfl_xor(sq, 4, 64);
+                    if (hh < p.rms_nheads) {
+                        const float rs = rsqrtf(sq * (1.0f / 64.0f) + p.rms_eps);
+                        if (p.rms_rs_out && (lane & 7) == 0) p.rms_rs_out[(size_t)orow * p.rms_nheads + hh] = rs;
+                        float w8[8];
+                        unpack8(*reinterpret_cast<const uint4*>(p.rms_w + (hh / p.rms_hpw) * 64 + c8), w8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = round_bf16(v[e] * rs) * w8[e];
+                    }
+                }
+                const uint32_t o_aux = __umul24(orow, (uint32_t)p.ld_aux) + n;
+                if (has_aux_out) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.aux_out) + (size_t)(o_aux * 2u)) = pack8(v);
+                if ((G || (EPI & F_DGELU)) && act >= ACT_DGELU_TANH) {
+                    float z[8];
+                    unpack8(ld16(p.aux_in, o_aux), z);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= dact_fn(z[e], act);
+                } else if (act == ACT_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = act_fn(v[e], ACT_GELU_TANH);
+                } else if (act != ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = act_fn(v[e], act);
+                }
+                if (has_gate) {
+                    uint4 gq = f0.g;
+                    if (c0.gate_r + row >= gate_rows) {   // this lane's row belongs to a later sample than the slab's first row
+                        const int gb = c0.gate_b + (c0.gate_r + row - gate_rows) / gate_rows + 1;
+                        gq = ld16(p.gate, __umul24((uint32_t)gb, (uint32_t)p.gate_stride) + n);
+                    }
+                    float g[8];
+                    unpack8(gq, g);
+                    {
+#pragma clang fp contract(off)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] * g[e];
+                    }
+                }
+                if (has_res) {
+                    float r[8];
+                    unpack8(f0.r[ps], r);
+                    {
+#pragma clang fp contract(off)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] + r[e];
+                    }
+                }
+                const uint32_t o = __umul24(orow, (uint32_t)p.ldc) + n;
+                if (out_bf16) {
+                    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.C) + (size_t)(o * 2u)) = pack8(v);
+                } else {
+                    float* c = reinterpret_cast<float*>(reinterpret_cast<char*>(p.C) + (size_t)o * 4u);
+                    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+            f0 = f1;
+            f1 = f2;
+            c0 = c1;
+            c1 = c2;
+        }
+    }
+}
+
+}  // namespace
+
+struct P8Sched { int tiles_a, tiles_total; unsigned long long* stamps; };   // stamps: experiment (ADVGRPO_P8_STAMPS)
+
+template <bool PAIR, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const P8Sched sc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;      // wave row (group) / wave column
+    // this wave's fragment bases inside a k-tile buffer
+    const int a_base = wr * 64 * 128;                     // + sub * P8_HALF + i * 16 * 128
+    const int b_base = 2 * P8_HALF + wc * 32 * 128;       // + sub * P8_HALF + j * 16 * 128
+    const int nwg = gridDim.x;
+
+    // tile -> (problem, tile id): every round of nwg tiles is dealt XCD-contiguously
+    auto locate = [&](int tile, P8Tile& t) __attribute__((always_inline)) {
+        const int round0 = tile - (int)blockIdx.x;
+        const int in_round = min(nwg, sc.tiles_total - round0);
+        int id = round0 + xcd_remap(blockIdx.x, in_round);
+        const bool second = PAIR && id >= sc.tiles_a;
+        if (second) id -= sc.tiles_a;
+        t.second = second;
+        if (second) p8_setup(t, pp.b, id, wave, lane);
+        else p8_setup(t, pp.a, id, wave, lane);
+    };
+    // the seven items the steady state would have issued before phase 0 of k-tile 0, in its order: A0 W0 W1 A1 of
+    // k-tile 0 (buffer 0), then A0 W0 W1 of k-tile 1 (buffer 1)
+    auto issue_first = [&](const P8Tile& t) __attribute__((always_inline)) {
+        p8_stage(t, smem, wave, 0, 0, 0); p8_stage(t, smem, wave, 0, 2, 0); p8_stage(t, smem, wave, 0, 3, 0); p8_stage(t, smem, wave, 0, 1, 0);
+    };
+    auto issue_second = [&](const P8Tile& t) __attribute__((always_inline)) {
+        p8_stage(t, smem, wave, 1, 0, 1); p8_stage(t, smem, wave, 1, 2, 1); p8_stage(t, smem, wave, 1, 3, 1);
+    };
+
+    // experiment: s_memtime at the tile milestones, wave 0 of every workgroup, 8 stamps per tile
+    int stamp_i = 0;
+    auto stamp = [&](int k) __attribute__((always_inline)) {
+        if (sc.stamps && wave == 0 && stamp_i < 8) {
+            const unsigned long long tm = __builtin_readcyclecounter();
+            if (lane == 0) sc.stamps[((size_t)blockIdx.x * 8 + stamp_i) * 8 + k] = tm;
+        }
+    };
+    P8Tile t;
+    locate(blockIdx.x, t);
+    issue_first(t);
+    issue_second(t);
+    for (int tile = blockIdx.x; tile < sc.tiles_total; tile += nwg) {
+        const int nk = t.nk;
+        const int n_items = 4 * nk;                       // ring items of this output tile, in issue (= first-read) order
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // per-lane fragment offsets, recomputed per tile from an opaque copy of the lane id: kept live across the epilogue
+        // they were spilled, and the reload's conservative s_waitcnt vmcnt(0) ended up INSIDE the k loop (draining the DMA)
+        int frag_off[2];
+        {
+            int l = lane;
+            asm volatile("" : "+v"(l));
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) frag_off[ks] = (l & 15) * 128 + (((ks * 4 + (l >> 4)) ^ (l & 7)) << 4);
+        }
+        // the first two items must have landed for the first reads
+        stamp(0);
+        p8_wait_inflight(min(7, n_items) - 2);
+        __builtin_amdgcn_s_barrier();
+        stamp(1);
+        if (wr == 1) __builtin_amdgcn_s_barrier();       // stagger: group 1 runs one barrier behind
+
+        bf16x8_t af0[2][4], af1[2][4], b0[2][2], b1[2][2];
+        auto read_a = [&](const char* buf, int sub, bf16x8_t (&a)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[ks][i] = *reinterpret_cast<const bf16x8_t*>(buf + a_base + sub * P8_HALF + i * 16 * 128 + frag_off[ks]);
+        };
+        auto read_b = [&](const char* buf, int sub, bf16x8_t (&b)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    b[ks][j] = *reinterpret_cast<const bf16x8_t*>(buf + b_base + sub * P8_HALF + j * 16 * 128 + frag_off[ks]);
+        };
+        // end of a load segment at global phase g (= 4 kt + ph): everything first read in phase g + 1 must have landed
+        // (items 0 .. g + 2 of the issue order); 8 + g items have been issued (capped by n_items)
+        auto close_load = [&](int g, bool steady) __attribute__((always_inline)) {
+            if (steady) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else p8_wait_inflight(min(8 + g, n_items) - min(g + 3, n_items));
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#define P8_COMPUTE(MH, NH, AF, BF)                                                                                      \
+        do {                                                                                                            \
+            __builtin_amdgcn_s_setprio(1);                                                                              \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                            \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+                        acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
+                            BF[ks][j], AF[ks][i], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0);                            \
+            __builtin_amdgcn_s_setprio(0);                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            __builtin_amdgcn_s_barrier();                                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+        } while (0)
+
+        // Phases of k-tile kt (buffer cur), fragments kept in registers:
+        //   ph0  read W sub 0            fill A1(kt+1)   compute (A0, W0)        [A sub 0 was read in ph3 of kt-1]
+        //   ph1  read W sub 1            fill A0(kt+2)   compute (A0, W1)
+        //   ph2  read A sub 1            fill W0(kt+2)   compute (A1, W1)
+        //   ph3  read A sub 0 of kt+1    fill W1(kt+2)   compute (A1, W0)
+        auto ktile = [&](int cur, int kt, bool steady) __attribute__((always_inline)) {
+            const char* buf = smem + cur * P8_BUF;
+            const char* nxt = smem + (cur ^ 1) * P8_BUF;
+            const int g = 4 * kt;
+            read_b(buf, 0, b0);
+            p8_stage(t, smem, wave, cur ^ 1, 1, kt + 1);
+            close_load(g, steady);
+            P8_COMPUTE(0, 0, af0, b0);
+            read_b(buf, 1, b1);
+            p8_stage(t, smem, wave, cur, 0, kt + 2);
+            close_load(g + 1, steady);
+            P8_COMPUTE(0, 1, af0, b1);
+            read_a(buf, 1, af1);
+            p8_stage(t, smem, wave, cur, 2, kt + 2);
+            close_load(g + 2, steady);
+            P8_COMPUTE(1, 1, af1, b1);
+            if (kt + 1 < nk) read_a(nxt, 0, af0);
+            p8_stage(t, smem, wave, cur, 3, kt + 2);
+            close_load(g + 3, steady);
+            P8_COMPUTE(1, 0, af1, b0);
+        };
+        read_a(smem, 0, af0);
+        int kt = 0;
+        for (; kt + 3 < nk; kt += 2) {                   // both k-tiles issue all of their re-fills: constant waits
+            ktile(0, kt, true);
+            ktile(1, kt + 1, true);
+        }
+        for (; kt < nk; kt += 2) {
+            ktile(0, kt, false);
+            if (kt + 1 < nk) ktile(1, kt + 1, false);
+        }
+#undef P8_COMPUTE
+        if (wr == 0) __builtin_amdgcn_s_barrier();       // matches group 1's stagger barrier: every ring read is complete
+        stamp(2);
+
+        // ---- tile boundary: request the next tile's first k-tile (buffer 0), run the epilogue through buffer 1, then
+        // request the rest of the next tile's pipeline fill
+        const bool cur_second = t.second;
+        const int mw0 = t.m0 + wr * 128, nw0 = t.n0 + wc * 64;
+        const bool more = tile + nwg < sc.tiles_total;
+        if (more) {
+            locate(tile + nwg, t);
+            issue_first(t);
+        }
+        stamp(3);
+        {
+            const GemmParams& p = (PAIR && cur_second) ? pp.b : pp.a;
+            p8_epilogue<EPI>(p, acc, mw0, nw0, lane, smem + P8_BUF + wave * P8_SCRATCH);
+        }
+        stamp(4);
+        if (more) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                 // every wave is done with its scratch in buffer 1
+            stamp(5);
+            issue_second(t);
+        }
+        ++stamp_i;
+    }
+}
+
+// experiment only: device buffer of the s_memtime stamps of the last launch (ADVGRPO_P8_STAMPS=1)
+extern unsigned long long* g_p8_stamps;
+
+template <int EPI>
+int launch8p(const GemmPair& pp, const P8Sched& sc, hipStream_t s) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            set_error("gemm8p: cannot query the device");
+            return -2;
+        }
+        cus = prop.multiProcessorCount;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<true, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+        attr_set = true;
+    }
+    const int grid = sc.tiles_total < cus ? sc.tiles_total : cus;
+    P8Sched sc2 = sc;
+    {
+        static unsigned long long* stamps = nullptr;
+        static int want = -1;
+        if (want < 0) { const char* e = getenv("ADVGRPO_P8_STAMPS"); want = (e && atoi(e)) ? 1 : 0; }
+        if (want && !stamps) { (void)hipMalloc((void**)&stamps, 256 * 8 * 8 * 8); }
+        if (want) { (void)hipMemsetAsync(stamps, 0, 256 * 8 * 8 * 8, s); g_p8_stamps = stamps; }
+        sc2.stamps = want ? stamps : nullptr;
+    }
+    hipLaunchKernelGGL((gemm8p_kernel<true, EPI>), dim3(grid), dim3(512), P8_LDS, s, pp, sc2);   // a single problem is a pair with an empty second half
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+
+}  // namespace advgrpo
