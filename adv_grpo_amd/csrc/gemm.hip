@@ -176,7 +176,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
     }
 
     if (p.debug & 4) { if (acc[0][0][0] != 12345.678f) return; }
-    gemm_epilogue<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane, smem, wave);
+    gemm_epilogue<FM, FN, TM, TN, CONV>(p, acc, m0, n0, wm, wn, bz, lane, smem, wave);
 }
 
 // waves per SIMD the register allocation must leave room for: two workgroups per CU whenever their LDS fits (<= 80 KB
@@ -735,5 +735,25 @@ extern "C" int advgrpo_conv3x3_nhwc(const void* x, const void* w, void* y, int o
     p.conv = 1; p.Hout = Hout; p.Wout = Wout; p.Cin = Cin; p.ups = upsample ? 1 : 0;
     p.zero_page = (const bf16_t*)zero_page;
     p.splitk = 1;
+    return gemm_bf16(p, as_stream(stream));
+}
+
+/* the same convolution over split-bf16 operands (vae.hip: split8): x3 [B, Hin, Win, Cin3] bf16 with Cin3 = 3*C laid out
+ * [hi | hi | lo], w3 [Cout, 9*Cin3] with each tap's channels [hi | lo | hi]; bias / residual / y are f32 */
+extern "C" int advgrpo_conv3x3_nhwc_x3(const void* x3, const void* w3, float* y, int B, int Hout, int Wout, int Cin3,
+                                       int Cout, int upsample, const float* bias, int act, const float* residual,
+                                       const void* zero_page, void* stream) {
+    GemmParams p{};
+    p.A = (const bf16_t*)x3; p.W = (const bf16_t*)w3; p.C = y;
+    p.lda = Cin3; p.ldw = 9 * (int64_t)Cin3; p.ldc = Cout; p.out_dtype = ADVGRPO_F32;
+    p.M = B * Hout * Wout; p.N = Cout; p.K = 9 * Cin3;
+    p.bias = (const bf16_t*)bias; p.act = act; p.alpha = 1.0f;
+    p.residual = (const bf16_t*)residual; p.ldr = Cout;
+    p.batch = 1;
+    p.conv = 1; p.Hout = Hout; p.Wout = Wout; p.Cin = Cin3; p.ups = upsample ? 1 : 0;
+    p.zero_page = (const bf16_t*)zero_page;
+    p.splitk = 1;
+    p.f32_io = 1;
+    ADVGRPO_CHECK(Cin3 % 192 == 0, "conv3x3_x3: Cin3 must be 3 x (a multiple of 64) (Cin3=%d)", Cin3);
     return gemm_bf16(p, as_stream(stream));
 }

@@ -34,6 +34,7 @@ struct GemmParams {
     // projection: q heads then k heads, V untouched): y = bf16(bf16(x) * rsqrt(mean(x^2) + eps)) * w[(head / hpw), :];
     // rms_rs_out[orow, head] (f32, optional) keeps 1/rms for the backward.  Needs a 64-wide wave tile.
     const bf16_t* rms_w; int rms_nheads; int rms_hpw; float rms_eps; float* rms_rs_out;
+    int f32_io;  // convolutions only: bias / residual / C are f32 (the split-bf16 VAE mode keeps f32 between kernels)
     int debug;   // experiments only (ADVGRPO_GEMM_DEBUG): bit0 = skip steady-state DMA, bit1 = skip LDS fragment reads
 };
 

@@ -291,10 +291,60 @@ __device__ __forceinline__ void gemm_epilogue_frag(const GemmParams& p, f32x4 (&
     });
 }
 
-// all waves of the workgroup must be past their last main-loop LDS read when this is called (it syncs itself)
+// f32 in / f32 out epilogue of the split-bf16 VAE convolutions (GemmParams::f32_io): y = act(acc + bias_f32[n]) +
+// residual_f32[m, n], f32 store, straight from the accumulator layout (a lane's 4 consecutive columns are one float4;
+// the 4 lanes of a row cover 64 contiguous bytes).  Only the convolution kernels instantiate it.
 template <int FM, int FN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_f32io(const GemmParams& p, f32x4 (&acc)[FM][FN], int m0, int n0, int wm,
+                                                    int wn, int lane) {
+    const int mrow = lane & 15, ncol = (lane >> 4) * 4;
+    const float* bias = reinterpret_cast<const float*>(p.bias);
+    const float* res = reinterpret_cast<const float*>(p.residual);
+    float* out = reinterpret_cast<float*>(p.C);
+    const bool vec_ok = ((p.ldc | p.ldr) & 3) == 0 && (p.N & 3) == 0;
+    static_for<FM * FN>([&](auto idx) {
+        constexpr int i = decltype(idx)::value / FN, j = decltype(idx)::value % FN;
+        const int m = m0 + wm * TM + i * 16 + mrow;
+        const int n = n0 + wn * TN + j * 16 + ncol;
+        if (m >= p.M || n >= p.N) return;
+        const f32x4 a4 = acc[i][j];
+        float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+        if (vec_ok) {
+            if (bias) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+                v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_fn(v[e], p.act);
+            if (res) {
+                const float4 r4 = *reinterpret_cast<const float4*>(res + (int64_t)m * p.ldr + n);
+                v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+            }
+            *reinterpret_cast<float4*>(out + (int64_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e >= p.N) continue;
+                float y = v[e];
+                if (bias) y += bias[n + e];
+                y = act_fn(y, p.act);
+                if (res) y += res[(int64_t)m * p.ldr + n + e];
+                out[(int64_t)m * p.ldc + n + e] = y;
+            }
+        }
+    });
+}
+
+// all waves of the workgroup must be past their last main-loop LDS read when this is called (it syncs itself)
+template <int FM, int FN, int TM, int TN, bool F32IO = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[FM][FN], int m0, int n0, int wm, int wn,
                                               int bz, int lane, char* smem, int wave) {
+    if constexpr (F32IO) {
+        if (p.f32_io) {
+            gemm_epilogue_f32io<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, lane);
+            return;
+        }
+    }
     if (epilogue_rows_ok(p) && !(p.debug & 16)) {
         __syncthreads();
         gemm_epilogue_rows<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane, smem + wave * (16 * (TN * 4 + 16)));

@@ -36,7 +36,32 @@ __device__ inline uint4 pack8v(const float o[8]) {
 // A thread owns one 8-channel slice (c8 = tid % (C/8)) => with C/G in {4, 8, 16} its 8 channels
 // belong to at most two groups... we keep per-thread sums per 4-channel half and reduce in LDS.
 // stats: [B, G, 2] f64 (sum, sumsq), zeroed by the caller.
-__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __restrict__ x, double* __restrict__ stats,
+template <typename T>
+__device__ inline void load8(const T* __restrict__ q, float o[8]) {
+    if constexpr (sizeof(T) == 2) {
+        unpack8v(*reinterpret_cast<const uint4*>(q), o);
+    } else {
+        const float4 a = *reinterpret_cast<const float4*>(q), b = *reinterpret_cast<const float4*>(q + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+}
+// split-bf16 ("bf16x3") representation of an f32 value: hi = bf16(v), lo = bf16(v - hi) (the subtraction is exact);
+// hi + lo carries 16 significand bits.  A product x*w is then formed on the bf16 MFMA as xh*wh + xh*wl + xl*wh (f32
+// accumulate; the dropped xl*wl term is 2^-16 relative), by laying the K axis out three times: activations as
+// [hi | hi | lo], weights as [hi | lo | hi].
+__device__ inline void split8(const float v[8], uint4& hi, uint4& lo) {
+    float h[8], l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        h[k] = round_bf16(v[k]);
+        l[k] = v[k] - h[k];
+    }
+    hi = pack8v(h);
+    lo = pack8v(l);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restrict__ x, double* __restrict__ stats,
                                                               int HW, int C, int G, int ppb) {
     __shared__ float s_sum[64], s_sq[64];   // G <= 64
     const int b = blockIdx.y;
@@ -47,10 +72,10 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __re
     __syncthreads();
     float sum[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};   // halves: channels [0,4) and [4,8) of the slice
     const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
-    const bf16_t* xb = x + (int64_t)b * HW * C;
+    const T* xb = x + (int64_t)b * HW * C;
     for (int p = p0 + prow; p < p1; p += pstep) {
         float v[8];
-        unpack8v(*reinterpret_cast<const uint4*>(xb + (int64_t)p * C + slice * 8), v);
+        load8(xb + (int64_t)p * C + slice * 8, v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             sum[k >> 2] += v[k];
@@ -70,9 +95,12 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __re
     }
 }
 
-__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+// T = bf16_t: bf16 in / bf16 affine / bf16 out.  T = float (split-bf16 mode): f32 in, f32 affine, output row of 3C bf16
+// = [hi | hi | lo] of the normalised value.
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restrict__ x, bf16_t* __restrict__ y,
                                                               const double* __restrict__ stats,
-                                                              const bf16_t* __restrict__ w, const bf16_t* __restrict__ bb,
+                                                              const T* __restrict__ w, const T* __restrict__ bb,
                                                               int HW, int C, int G, float eps, int silu, int64_t total8) {
     const int c8n = C >> 3, cpg = C / G;
     const double cnt = (double)HW * cpg;
@@ -81,9 +109,9 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
         const int64_t pix = i / c8n;
         const int b = pix / HW;
         float v[8], ww[8], bv[8];
-        unpack8v(*reinterpret_cast<const uint4*>(x + i * 8), v);
-        unpack8v(*reinterpret_cast<const uint4*>(w + slice * 8), ww);
-        unpack8v(*reinterpret_cast<const uint4*>(bb + slice * 8), bv);
+        load8(x + i * 8, v);
+        load8(w + slice * 8, ww);
+        load8(bb + slice * 8, bv);
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
             const int g = (slice * 8 + hlf * 4) / cpg;
@@ -98,7 +126,100 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
                 v[k] = t;
             }
         }
-        *reinterpret_cast<uint4*>(y + i * 8) = pack8v(v);
+        if constexpr (sizeof(T) == 2) {
+            *reinterpret_cast<uint4*>(y + i * 8) = pack8v(v);
+        } else {
+            uint4 hi, lo;
+            split8(v, hi, lo);
+            bf16_t* row = y + pix * 3 * C + slice * 8;
+            *reinterpret_cast<uint4*>(row) = hi;
+            *reinterpret_cast<uint4*>(row + C) = hi;
+            *reinterpret_cast<uint4*>(row + 2 * C) = lo;
+        }
+    }
+}
+
+// f32 [rows, K] (+ bias[K]) -> bf16 [rows, 3K]: order 0 = [hi | hi | lo] (left operand: activations), 1 = [hi | lo | hi]
+// (right operand: weights)
+__global__ __launch_bounds__(256) void split_x3_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                       bf16_t* __restrict__ out, int K, int order, int64_t total8) {
+    const int k8n = K >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int slice = i % k8n;
+        const int64_t r = i / k8n;
+        float v[8];
+        load8(x + i * 8, v);
+        if (bias) {
+            float b8[8];
+            load8(bias + slice * 8, b8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += b8[k];
+        }
+        uint4 hi, lo;
+        split8(v, hi, lo);
+        bf16_t* row = out + r * 3 * K + slice * 8;
+        *reinterpret_cast<uint4*>(row) = hi;
+        *reinterpret_cast<uint4*>(row + K) = order ? lo : hi;
+        *reinterpret_cast<uint4*>(row + 2 * K) = order ? hi : lo;
+    }
+}
+
+// y = a + b + bias[c] (f32): the attention block's output projection + bias + skip in the split-bf16 mode
+__global__ __launch_bounds__(256) void add_rows_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int C,
+                                                           int64_t total4) {
+    const int c4n = C >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 u = reinterpret_cast<const float4*>(a)[i];
+        if (b) {
+            const float4 w = reinterpret_cast<const float4*>(b)[i];
+            u.x += w.x; u.y += w.y; u.z += w.z; u.w += w.w;
+        }
+        if (bias) {
+            const float4 w = reinterpret_cast<const float4*>(bias)[i % c4n];
+            u.x += w.x; u.y += w.y; u.z += w.z; u.w += w.w;
+        }
+        reinterpret_cast<float4*>(y)[i] = u;
+    }
+}
+
+// softmax over f32 rows [rows, n] written as the left operand of the P.V product in the split-bf16 mode:
+// out [rows, 3n] bf16 = [hi | hi | lo].  One workgroup per row, three passes over a row that stays in L2.
+__global__ __launch_bounds__(256) void softmax_rows_x3_kernel(const float* __restrict__ s, bf16_t* __restrict__ out, int n) {
+    __shared__ float red[4];
+    const float* r = s + (int64_t)blockIdx.x * n;
+    bf16_t* o = out + (int64_t)blockIdx.x * 3 * n;
+    const int n8 = n >> 3;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < n8; c += 256) {
+        float v[8];
+        load8(r + c * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mx = fmaxf(mx, v[k]);
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < n8; c += 256) {
+        float v[8];
+        load8(r + c * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += expf(v[k] - mx);
+    }
+    const float inv = 1.0f / block_sum<4>(sum, red);
+    for (int c = threadIdx.x; c < n8; c += 256) {
+        float v[8];
+        load8(r + c * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = expf(v[k] - mx) * inv;
+        uint4 hi, lo;
+        split8(v, hi, lo);
+        *reinterpret_cast<uint4*>(o + c * 8) = hi;
+        *reinterpret_cast<uint4*>(o + n + c * 8) = hi;
+        *reinterpret_cast<uint4*>(o + 2 * n + c * 8) = lo;
     }
 }
 
@@ -147,6 +268,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ 
 }
 
 // z [B,C,H,W] (f32 or bf16) -> NHWC bf16 [B,H,W,Cpad], value z*inv_scale + shift in channels < C, else 0
+template <bool X3>
 __global__ void latents_to_nhwc_kernel(const void* __restrict__ z, int z_dt, bf16_t* __restrict__ out, int B, int C,
                                        int H, int W, int Cpad, float scaling, float shift) {
     const int64_t total = (int64_t)B * H * W * Cpad;
@@ -160,6 +282,11 @@ __global__ void latents_to_nhwc_kernel(const void* __restrict__ z, int z_dt, bf1
             v = z_dt == ADVGRPO_BF16 ? bf2f(reinterpret_cast<const bf16_t*>(z)[src]) : reinterpret_cast<const float*>(z)[src];
             v = v / scaling + shift;   // latents / scaling_factor + shift_factor (PF:667), one f32 rounding each
         }
+        if constexpr (X3) {          // [hi | hi | lo] along a 3*Cpad channel axis
+            const float h = round_bf16(v);
+            bf16_t* row = out + pix * 3 * Cpad + c;
+            row[0] = f2bf(h); row[Cpad] = f2bf(h); row[2 * Cpad] = f2bf(v - h);
+        } else
         out[i] = f2bf(v);
     }
 }
@@ -192,14 +319,67 @@ extern "C" int advgrpo_groupnorm_nhwc(const void* x, void* y, double* stats, con
         return -2;
     }
     const int ppb = 512;  // pixels per block
-    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, s, (const bf16_t*)x, stats,
+    hipLaunchKernelGGL(groupnorm_stats_kernel<bf16_t>, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, s, (const bf16_t*)x, stats,
                        HW, C, G, ppb);
     ADVGRPO_LAUNCH_CHECK();
     const int64_t total8 = (int64_t)B * HW * (C / 8);
     int64_t blocks = (total8 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3((int)blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, stats,
+    hipLaunchKernelGGL(groupnorm_apply_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, stats,
                        (const bf16_t*)weight, (const bf16_t*)bias, HW, C, G, eps, silu, total8);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_groupnorm_nhwc_x3(const float* x, void* y3, double* stats, const float* weight, const float* bias,
+                                         int B, int HW, int C, int G, float eps, int silu, void* stream) {
+    ADVGRPO_CHECK(x && y3 && stats && weight && bias, "groupnorm_x3: null pointer");
+    ADVGRPO_CHECK(B > 0 && HW > 0 && C % 8 == 0 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 4 == 0 && 256 % (C / 8) == 0,
+                  "groupnorm_x3: unsupported shape C=%d G=%d", C, G);
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(double), s) != hipSuccess) {
+        set_error("groupnorm_x3: memset failed");
+        return -2;
+    }
+    const int ppb = 512;
+    hipLaunchKernelGGL(groupnorm_stats_kernel<float>, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, s, x, stats, HW, C, G, ppb);
+    ADVGRPO_LAUNCH_CHECK();
+    const int64_t total8 = (int64_t)B * HW * (C / 8);
+    int64_t blocks = (total8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(groupnorm_apply_kernel<float>, dim3((int)blocks), dim3(256), 0, s, x, (bf16_t*)y3, stats, weight, bias,
+                       HW, C, G, eps, silu, total8);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_split_bf16x3(const float* x, const float* bias, void* out, int64_t rows, int K, int order,
+                                    void* stream) {
+    ADVGRPO_CHECK(x && out && rows > 0 && K > 0 && K % 8 == 0 && (order == 0 || order == 1),
+                  "split_bf16x3: need K %% 8 == 0 and order 0|1 (K=%d)", K);
+    const int64_t total8 = rows * (K / 8);
+    int64_t blocks = (total8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(split_x3_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, bias, (bf16_t*)out, K, order,
+                       total8);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_add_rows_f32(const float* a, const float* b, const float* bias, float* y, int64_t rows, int C,
+                                    void* stream) {
+    ADVGRPO_CHECK(a && y && rows > 0 && C > 0 && C % 4 == 0, "add_rows_f32: need C %% 4 == 0 (C=%d)", C);
+    const int64_t total4 = rows * (C / 4);
+    int64_t blocks = (total4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(add_rows_f32_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), a, b, bias, y, C, total4);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_softmax_rows_x3(const float* s, void* out3, int64_t rows, int n, void* stream) {
+    ADVGRPO_CHECK(s && out3 && rows > 0 && n > 0 && n % 8 == 0 && rows < (1ll << 31), "softmax_rows_x3: need n %% 8 == 0 (n=%d)", n);
+    hipLaunchKernelGGL(softmax_rows_x3_kernel, dim3((unsigned)rows), dim3(256), 0, as_stream(stream), s, (bf16_t*)out3, n);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
@@ -251,8 +431,17 @@ extern "C" int advgrpo_softmax_rows(void* s, int64_t rows, int n, void* stream) 
 extern "C" int advgrpo_latents_to_nhwc(const void* z, int z_dtype, void* out, int B, int C, int H, int W, int Cpad,
                                        float scaling_factor, float shift_factor, void* stream) {
     ADVGRPO_CHECK(z && out && B > 0 && C > 0 && Cpad >= C, "latents_to_nhwc: bad argument");
-    hipLaunchKernelGGL(latents_to_nhwc_kernel, dim3(1024), dim3(256), 0, as_stream(stream), z, z_dtype, (bf16_t*)out, B, C,
+    hipLaunchKernelGGL(latents_to_nhwc_kernel<false>, dim3(1024), dim3(256), 0, as_stream(stream), z, z_dtype, (bf16_t*)out, B, C,
                        H, W, Cpad, scaling_factor, shift_factor);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_latents_to_nhwc_x3(const void* z, int z_dtype, void* out3, int B, int C, int H, int W, int Cpad,
+                                          float scaling_factor, float shift_factor, void* stream) {
+    ADVGRPO_CHECK(z && out3 && B > 0 && C > 0 && Cpad >= C, "latents_to_nhwc_x3: bad argument");
+    hipLaunchKernelGGL(latents_to_nhwc_kernel<true>, dim3(1024), dim3(256), 0, as_stream(stream), z, z_dtype, (bf16_t*)out3, B,
+                       C, H, W, Cpad, scaling_factor, shift_factor);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

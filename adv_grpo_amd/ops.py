@@ -310,6 +310,76 @@ def groupnorm_nhwc(x, weight, bias, groups=32, eps=1e-6, silu=False):
     return y
 
 
+# ---- split-bf16 ("bf16x3") VAE mode: f32 between the matrix products, operands as [hi|hi|lo] x [hi|lo|hi] (include/advgrpo.h)
+def split_x3(x, order=0, bias=None):
+    """f32 [..., K] (+ bias[K]) -> bf16 [..., 3K]; order 0 = left operand (activations), 1 = right operand (weights)."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    K = x.shape[-1]
+    out = torch.empty(*x.shape[:-1], 3 * K, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.advgrpo_split_bf16x3(x.data_ptr(), _lib.ptr(bias), out.data_ptr(), x.numel() // K, K, int(order),
+                                        _lib.stream_ptr()))
+    return out
+
+
+def conv3x3_x3(x3, w3, bias=None, upsample=False, act=None, residual=None):
+    """x3 NHWC split bf16 [B,Hin,Win,3C]; w3 [Cout, 9*3C]; bias / residual f32 -> f32 [B,Hout,Wout,Cout]."""
+    lib = _lib.load()
+    B, Hin, Win, Cin3 = x3.shape
+    Cout = w3.shape[0]
+    Hout, Wout = (Hin * 2, Win * 2) if upsample else (Hin, Win)
+    assert bias is None or bias.dtype == torch.float32
+    assert residual is None or (residual.dtype == torch.float32 and residual.is_contiguous())
+    y = torch.empty(B, Hout, Wout, Cout, dtype=torch.float32, device=x3.device)
+    with _Prof(B * Hout * Wout, Cout, 9 * Cin3, 1, 1):
+      _lib.check(lib.advgrpo_conv3x3_nhwc_x3(_lib.ptr(x3), _lib.ptr(w3), y.data_ptr(), B, Hout, Wout, Cin3, Cout, int(upsample),
+                                           _lib.ptr(bias), ACT[act], _lib.ptr(residual), zero_page(x3.device).data_ptr(),
+                                           _lib.stream_ptr()))
+    return y
+
+
+def groupnorm_nhwc_x3(x, weight, bias, groups=32, eps=1e-6, silu=False):
+    """f32 NHWC in, f32 affine -> split bf16 [..., 3C]."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and weight.dtype == torch.float32
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    y = torch.empty(*x.shape[:-1], 3 * C, dtype=torch.bfloat16, device=x.device)
+    stats = torch.empty(B * groups * 2, dtype=torch.float64, device=x.device)
+    _lib.check(lib.advgrpo_groupnorm_nhwc_x3(x.data_ptr(), y.data_ptr(), stats.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), B,
+                                             HW, C, groups, float(eps), int(silu), _lib.stream_ptr()))
+    return y
+
+
+def softmax_rows_x3(s):
+    """f32 [..., n] -> softmax rows as split bf16 [..., 3n]."""
+    lib = _lib.load()
+    assert s.dtype == torch.float32 and s.is_contiguous()
+    n = s.shape[-1]
+    out = torch.empty(*s.shape[:-1], 3 * n, dtype=torch.bfloat16, device=s.device)
+    _lib.check(lib.advgrpo_softmax_rows_x3(s.data_ptr(), out.data_ptr(), s.numel() // n, n, _lib.stream_ptr()))
+    return out
+
+
+def add_rows_f32(a, b=None, bias=None):
+    lib = _lib.load()
+    assert a.dtype == torch.float32 and a.is_contiguous() and (b is None or (b.dtype == torch.float32 and b.is_contiguous()))
+    C = a.shape[-1]
+    y = torch.empty_like(a)
+    _lib.check(lib.advgrpo_add_rows_f32(a.data_ptr(), _lib.ptr(b), _lib.ptr(bias), y.data_ptr(), a.numel() // C, C,
+                                        _lib.stream_ptr()))
+    return y
+
+
+def latents_to_nhwc_x3(z, cpad, scaling_factor, shift_factor):
+    lib = _lib.load()
+    B, C, H, W = z.shape
+    out = torch.empty(B, H, W, 3 * cpad, dtype=torch.bfloat16, device=z.device)
+    _lib.check(lib.advgrpo_latents_to_nhwc_x3(_lib.ptr(z.contiguous()), _lib.dtype_code(z.dtype), out.data_ptr(), B, C, H, W,
+                                              cpad, float(scaling_factor), float(shift_factor), _lib.stream_ptr()))
+    return out
+
+
 def softmax_rows_(s):
     lib = _lib.load()
     n = s.shape[-1]

@@ -9,8 +9,13 @@ gather, residual adds and biases into the convolution epilogue.
 
 DEVIATION from the reference: it runs the VAE in fp32 (train_sd3_fast_pickscore.py:481); fp32 matrix
 math on MI355X is 1/16 of the bf16 MFMA rate (no TF32 on gfx950), which would make decode as long as the
-whole rollout.  Here: bf16 operands, f32 accumulation, f32/f64 GroupNorm statistics.  Measured
-tolerance in tests/test_gpu_vae.py.
+whole rollout.  Two modes:
+  mode="bf16"    (default) bf16 operands and activations, f32 accumulation, f32/f64 GroupNorm statistics.
+  mode="bf16x3"  split-bf16: every f32 operand is carried as hi + lo bf16 halves and each product runs as
+                 xh*wh + xh*wl + xl*wh on the bf16 MFMA (3x the flops, ~2^-16 relative error per product);
+                 everything between two matrix products -- bias, residual adds, GroupNorm / softmax inputs --
+                 stays f32.  This is the fp32-equivalent decode; bench.py prices it next to the default.
+Measured tolerances of both in tests/test_gpu_vae.py.
 """
 import torch
 
@@ -18,7 +23,10 @@ from . import ops
 
 
 class AutoencoderKLDecoder:
-    def __init__(self, state_dict, cfg, device="cuda"):
+    def __init__(self, state_dict, cfg, device="cuda", mode="bf16"):
+        if mode not in ("bf16", "bf16x3"):
+            raise ValueError(f"AutoencoderKLDecoder: mode must be 'bf16' or 'bf16x3', got {mode!r}")
+        self.mode = mode
         self.cfg = cfg
         self.config = type("Cfg", (), {"scaling_factor": cfg.scaling_factor, "shift_factor": cfg.shift_factor})()
         self.dtype = torch.float32          # what the reference's vae.dtype says (PF:668 casts latents to it)
@@ -26,6 +34,9 @@ class AutoencoderKLDecoder:
         self.G = cfg.norm_num_groups
         self.w = {}
         bf = lambda t: t.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        if mode == "bf16x3":
+            self._load_x3(state_dict)
+            return
         for k, v in state_dict.items():
             if not k.startswith("decoder."):
                 continue
@@ -71,10 +82,84 @@ class AutoencoderKLDecoder:
         y = ops.gemm(o, w[f"{p}.to_out.0.weight"], bias=w[f"{p}.to_out.0.bias"], residual=x.view(B * T, C))
         return y.view(B, H, W, C)
 
+    # ------------------------------------------------------------------ split-bf16 mode
+    def _load_x3(self, state_dict):
+        f32 = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
+        w = self.w
+        for k, v in state_dict.items():
+            if not k.startswith("decoder."):
+                continue
+            if v.dim() == 4 and v.shape[-1] == 3:       # conv3x3 [Co,Ci,3,3] -> [Co, 9, Ci] -> split along Ci
+                v = f32(v)
+                co, ci = v.shape[:2]
+                if ci % 64:
+                    v = torch.cat([v, torch.zeros(co, 64 - ci % 64, 3, 3, dtype=v.dtype, device=v.device)], dim=1)
+                w[k] = ops.split_x3(v.permute(0, 2, 3, 1).contiguous(), order=1).reshape(co, -1)
+            elif v.dim() == 4:                          # conv1x1 -> linear
+                w[k] = ops.split_x3(f32(v).reshape(v.shape[0], v.shape[1]), order=1)
+            elif v.dim() == 2:                          # attention projections
+                w[k] = ops.split_x3(f32(v), order=1)
+            else:
+                w[k] = f32(v)
+        for k in [k for k in w if k.endswith(".conv_shortcut.bias")]:       # the 1x1 shortcut's bias rides on conv2's
+            pre = k[:-len(".conv_shortcut.bias")]
+            w[pre + ".conv2.bias"] = w[pre + ".conv2.bias"] + w[k]
+
+    def _conv3(self, name, x3, **kw):
+        return ops.conv3x3_x3(x3, self.w[name + ".weight"], bias=self.w[name + ".bias"], **kw)
+
+    def _gn3(self, name, x, silu):
+        return ops.groupnorm_nhwc_x3(x, self.w[name + ".weight"], self.w[name + ".bias"], self.G, 1e-6, silu)
+
+    def _res3(self, p, x):
+        h = self._conv3(f"{p}.conv1", self._gn3(f"{p}.norm1", x, True))
+        sc = x
+        if f"{p}.conv_shortcut.weight" in self.w:
+            B, H, W, C = x.shape
+            sc = ops.gemm(ops.split_x3(x).view(-1, 3 * C), self.w[f"{p}.conv_shortcut.weight"], out_dtype=torch.float32
+                          ).view(B, H, W, -1)
+        return self._conv3(f"{p}.conv2", self._gn3(f"{p}.norm2", h, True), residual=sc)
+
+    def _attn3(self, p, x):
+        B, H, W, C = x.shape
+        T = H * W
+        w = self.w
+        f32 = torch.float32
+        h3 = self._gn3(f"{p}.group_norm", x, False).view(B * T, 3 * C)
+        q3 = ops.split_x3(ops.gemm(h3, w[f"{p}.to_q.weight"], out_dtype=f32), 0, bias=w[f"{p}.to_q.bias"]).view(B, T, 3 * C)
+        k3 = ops.split_x3(ops.gemm(h3, w[f"{p}.to_k.weight"], out_dtype=f32), 1, bias=w[f"{p}.to_k.bias"]).view(B, T, 3 * C)
+        # V^T[b] = Wv . h[b]^T; the weight is the [hi|lo|hi] side, the activations the [hi|hi|lo] side: same three products
+        vt = ops.bmm_nt(w[f"{p}.to_v.weight"].unsqueeze(0).expand(B, C, 3 * C), h3.view(B, T, 3 * C), out_dtype=f32)
+        vt3 = ops.split_x3(vt, 1)                                                                   # [B, C, 3T]
+        s = ops.bmm_nt(q3, k3, alpha=C ** -0.5, out_dtype=f32)                                      # [B, T, T] f32
+        p3 = ops.softmax_rows_x3(s)                                                                 # [B, T, 3T]
+        del s
+        o = ops.bmm_nt(p3, vt3, out_dtype=f32)                                                      # [B, T, C]
+        o3 = ops.split_x3(o.view(B * T, C), 0, bias=w[f"{p}.to_v.bias"])    # + bv after P.V: rows of P sum to one
+        y = ops.gemm(o3, w[f"{p}.to_out.0.weight"], out_dtype=f32)
+        return ops.add_rows_f32(y, x.view(B * T, C), bias=w[f"{p}.to_out.0.bias"]).view(B, H, W, C)
+
+    def _decode_x3(self, latents):
+        cfg = self.cfg
+        x = self._conv3("decoder.conv_in", ops.latents_to_nhwc_x3(latents, 64, cfg.scaling_factor, cfg.shift_factor))
+        x = self._res3("decoder.mid_block.resnets.0", x)
+        x = self._attn3("decoder.mid_block.attentions.0", x)
+        x = self._res3("decoder.mid_block.resnets.1", x)
+        n = len(cfg.block_out_channels)
+        for i in range(n):
+            for j in range(cfg.layers_per_block + 1):
+                x = self._res3(f"decoder.up_blocks.{i}.resnets.{j}", x)
+            if i < n - 1:
+                x = self._conv3(f"decoder.up_blocks.{i}.upsamplers.0.conv", ops.split_x3(x), upsample=True)
+        y = self._conv3("decoder.conv_out", self._gn3("decoder.conv_norm_out", x, True))
+        return ops.image_postprocess(y)
+
     @torch.no_grad()
     def decode_to_image(self, latents):
         """latents [B,16,h,w] (pre-scaling, as held by the rollout) -> image [B,3,8h,8w] f32 in [0,1]
         (= PF:667-670: rescale, decode, postprocess)."""
+        if self.mode == "bf16x3":
+            return self._decode_x3(latents)
         cfg = self.cfg
         x = ops.latents_to_nhwc(latents, 64, cfg.scaling_factor, cfg.shift_factor)
         x = self._conv("decoder.conv_in", x)

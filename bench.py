@@ -40,10 +40,13 @@ def parse():
                                                          "of the G-step to what the scaling curve exercises)")
     ap.add_argument("--config", default="c2", choices=["c2", "c4"],
                     help="c2 = the headline (BASELINE config 2); c4 = secondary line, SD3.5-large 1024^2 G=4 (BASELINE config 4 shapes)")
+    ap.add_argument("--vae-mode", default="bf16", choices=["bf16", "bf16x3"],
+                    help="decoder arithmetic inside the timed step: bf16 (default) or the fp32-equivalent split-bf16 mode; the "
+                         "'vae' object of the JSON line prices both either way")
     return ap.parse_args()
 
 
-def build(device, large=False):
+def build(device, large=False, vae_mode="bf16"):
     from adv_grpo_amd import synthetic, vit
     from adv_grpo_amd.mmdit import SD3Transformer2DModel
     from adv_grpo_amd.pipeline import SD3Pipeline
@@ -54,7 +57,7 @@ def build(device, large=False):
         mcfg = MMDiTConfig(num_layers=38, num_heads=38, dual_attention_layers=(), pos_embed_max_size=192)
     with synthetic.on_device(device):
         tr = SD3Transformer2DModel(synthetic.mmdit_weights(mcfg, 1234), mcfg, device)
-        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(vcfg, 4321), vcfg, device)
+        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(vcfg, 4321), vcfg, device, mode=vae_mode)
         clip = vit.CLIPModel(synthetic.clip_weights(ccfg, 777), ccfg, device)
     return SD3Pipeline(tr, vae, device), clip
 
@@ -210,7 +213,7 @@ def main():
     from adv_grpo_amd.trainer import rollout_seed
 
     c4 = args.config == "c4"
-    pipe, clip = build(device, large=c4)
+    pipe, clip = build(device, large=c4, vae_mode=args.vae_mode)
     G, STEPS, T, RES = (4, 10, 2, 1024) if c4 else (8, 10, 2, 512)
     sampler = DistributedKRepeatSampler(range(25432), 1, 1, world, rank, seed=42)   # k = 1: one group per rank
     # synthetic prompts: one embedding set per dataset index is not needed for timing; a fixed set per rank
@@ -274,14 +277,26 @@ def main():
         # SD3.5-large 1024^2 (config 4 shapes): 30.02 TFLOP per sample-forward, VAE x4 pixels
         per_image_tflop = (10 * 2 * 30.02 + 4 * 2.51 + 0.38) if c4 else (10 * 2 * 2.219 + 2.51 + 0.38)
         # the decoder on its own (bf16 MFMA / f32 accumulate; the reference decodes in fp32, TP:481 -- DESIGN 3 deviation 1)
+        # and the fp32-equivalent split-bf16 mode (3 bf16 MFMA products per f32 product, f32 between the kernels) beside it
+        from adv_grpo_amd import synthetic
+        from adv_grpo_amd.vae import AutoencoderKLDecoder
         lat = torch.randn(G, 16, RES // 8, RES // 8, device=device).to(torch.bfloat16)
-        pipe.vae.decode_to_image(lat)
-        torch.cuda.synchronize()
-        tv = time.perf_counter()
-        for _ in range(3):
-            pipe.vae.decode_to_image(lat)
-        torch.cuda.synchronize()
-        vae_ms = (time.perf_counter() - tv) / 3 * 1e3
+        vae_ms = {}
+        for mode in ("bf16", "bf16x3"):
+            if mode == pipe.vae.mode:
+                dec = pipe.vae
+            else:
+                with synthetic.on_device(device):
+                    dec = AutoencoderKLDecoder(synthetic.vae_decoder_weights(pipe.vae.cfg, 4321), pipe.vae.cfg, device, mode=mode)
+            dec.decode_to_image(lat)
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(3):
+                dec.decode_to_image(lat)
+            torch.cuda.synchronize()
+            vae_ms[mode] = (time.perf_counter() - tv) / 3 * 1e3
+            del dec
+        step_ms = dt / args.steps * 1e3
         res = {
             "metric": "sampled+scored images/sec (whole node), SD3.5-large 1024^2 10-step G=4 (secondary line, BASELINE config 4 shapes)"
             if c4 else "sampled+scored images/sec (whole node), SD3-med 512^2 10-step G=8 GRPO",
@@ -298,8 +313,14 @@ def main():
             "effective_tflops_per_gpu": round(per_image_tflop * images / dt / world, 1),
             "frac_of_bf16_mfma_peak": round(per_image_tflop * images / dt / world / BF16_DENSE_PEAK_TFLOPS, 4),
             "roofline": roofline,
-            "vae": {"mode": "bf16 MFMA / f32 accumulate, bf16 activations", "ms_per_group_decode": round(vae_ms, 2),
-                    "share_of_step_time": round(vae_ms / (dt / args.steps * 1e3), 4)},
+            "vae": {"mode": pipe.vae.mode,
+                    "modes": {"bf16": "bf16 operands and activations, f32 accumulate",
+                              "bf16x3": "split-bf16 (hi+lo) operands, 3 MFMA products per f32 product, f32 between kernels: "
+                                        "image within 3e-5 of the fp32 decode (tests/test_gpu_vae.py)"},
+                    "ms_per_group_decode": {k: round(v, 2) for k, v in vae_ms.items()},
+                    "share_of_step_time": round(vae_ms[pipe.vae.mode] / step_ms, 4),
+                    # what the headline would be with the other decoder swapped in (only the decode time changes)
+                    "value_if_bf16x3": round(images / (dt + args.steps * (vae_ms["bf16x3"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)},
         }
     run_epoch = not c4 and not args.no_epoch and (world == 1 or args.epoch)
     if run_epoch:                                   # every rank takes part (LoRA-gradient all-reduce, reward gather)

@@ -210,6 +210,29 @@ int advgrpo_latents_to_nhwc(const void* z, int z_dtype, void* out, int B, int C,
 int advgrpo_image_postprocess(const void* y, int y_dtype, int ldc, float* image, int B, int H, int W,
                               void* stream);
 
+/* ---- split-bf16 ("bf16x3") decode mode: closes the gap to the reference's fp32 VAE (train_sd3_fast_pickscore.py:481)
+ * without fp32 matrix math.  An f32 value v is carried as hi = bf16(v), lo = bf16(v - hi); x*w = xh*wh + xh*wl + xl*wh on
+ * the bf16 MFMA with f32 accumulation (3x the flops of the bf16 mode, ~2^-16 relative error per product).  Left operands
+ * (activations) are laid out along K as [hi | hi | lo] (order 0), right operands (weights) as [hi | lo | hi] (order 1);
+ * everything between two matrix products (bias, residual, GroupNorm input, softmax input) stays f32. */
+/* f32 [rows, K] (+ bias[K], optional) -> bf16 [rows, 3K];  K % 8 == 0 */
+int advgrpo_split_bf16x3(const float* x, const float* bias, void* out, int64_t rows, int K, int order, void* stream);
+/* advgrpo_conv3x3_nhwc over split operands: x3 [B,Hin,Win,Cin3=3C], w3 [Cout, 9*Cin3] (each tap [hi|lo|hi]); bias,
+ * residual, y: f32 */
+int advgrpo_conv3x3_nhwc_x3(const void* x3, const void* w3, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
+                            int upsample, const float* bias, int act, const float* residual, const void* zero_page,
+                            void* stream);
+/* GroupNorm over f32 NHWC [B,HW,C], f32 affine (+ SiLU) -> split output [B,HW,3C] */
+int advgrpo_groupnorm_nhwc_x3(const float* x, void* y3, double* stats, const float* weight, const float* bias, int B,
+                              int HW, int C, int G, float eps, int silu, void* stream);
+/* softmax over f32 rows [rows, n] -> split rows [rows, 3n] (left operand of P.V) */
+int advgrpo_softmax_rows_x3(const float* s, void* out3, int64_t rows, int n, void* stream);
+/* y[r, c] = a[r, c] + b[r, c] (optional) + bias[c] (optional), f32; C % 4 == 0 */
+int advgrpo_add_rows_f32(const float* a, const float* b, const float* bias, float* y, int64_t rows, int C, void* stream);
+/* advgrpo_latents_to_nhwc writing the split layout [B,H,W,3*Cpad] */
+int advgrpo_latents_to_nhwc_x3(const void* z, int z_dtype, void* out3, int B, int C, int H, int W, int Cpad,
+                               float scaling_factor, float shift_factor, void* stream);
+
 /* ------------------------------------------------------------------ reward preprocessing + epilogues
  * CLIP path: (x*255).round().clamp -> uint8 (adv_grpo/rewards.py:567), Pillow 8-bit antialiased bicubic
  * resize H x W -> OH x OW (bit-exact emulation of CLIPProcessor's PIL resize, pickscore_scorer.py:21-27),
