@@ -39,6 +39,8 @@ int gemm8p_launch_train_class(int epi, const GemmPair& pp, const P8Sched& sc, hi
 // every operand of the fused epilogue can be accessed as aligned 16-byte row segments (the dispatcher asks before choosing)
 bool gemm8p_ok(const GemmParams& p) {
     auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    // (the epilogue lets a 16-row slab straddle at most one segment / gate-vector boundary)
+    if ((p.seg_rows > 0 && p.seg_rows < 16) || (p.gate && p.gate_rows > 0 && p.gate_rows < 16)) return false;
     return p.batch == 1 && p.splitk == 1 && !p.conv && (p.N & 7) == 0 &&
            ((p.ldc | p.ldr | p.gate_stride | p.ld_aux) & 7) == 0 && a16(p.C) && a16(p.bias) && a16(p.gate) &&
            a16(p.residual) && a16(p.aux_out) && a16(p.aux_in) && a16(p.rms_w);

@@ -114,6 +114,8 @@ enum { EPI_GENERIC = -1, F_BIAS = 1, F_RMS = 2 /* per-head QK RMSNorm */, F_GELU
 enum { EPI_PLAIN = 0, EPI_BIAS = F_BIAS, EPI_BIAS_RMS = F_BIAS | F_RMS, EPI_BIAS_GELU = F_BIAS | F_GELU, EPI_BIAS_GATE_RES = F_BIAS | F_GATE_RES,
        EPI_BIAS_GELU_AUX = F_BIAS | F_GELU | F_AUX_OUT, EPI_DGELU = F_DGELU };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int EPI>
 __device__ __forceinline__ void p8_epilogue(const GemmParams& p, f32x4 (&acc)[8][4], int mw0, int nw0, int lane, char* scratch) {
     constexpr bool G = EPI == EPI_GENERIC;
@@ -128,25 +130,40 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, f32x4 (&acc)[8]
     const int orow_l = lane >> 3, c8 = (lane & 7) * 8;
     const int n = nw0 + c8;
     const bool n_ok = n < p.N;
-    auto unpack8 = [](const uint4& v, float (&f)[8]) __attribute__((always_inline)) {
-        f[0] = bf2f((bf16_t)(v.x & 0xffffu)); f[1] = bf2f((bf16_t)(v.x >> 16));
-        f[2] = bf2f((bf16_t)(v.y & 0xffffu)); f[3] = bf2f((bf16_t)(v.y >> 16));
-        f[4] = bf2f((bf16_t)(v.z & 0xffffu)); f[5] = bf2f((bf16_t)(v.z >> 16));
-        f[6] = bf2f((bf16_t)(v.w & 0xffffu)); f[7] = bf2f((bf16_t)(v.w >> 16));
+    // bf16 pair in a dword -> two f32 (shift / mask), and back with the hardware conversion (round-to-nearest-even)
+    auto up2 = [](uint32_t w) __attribute__((always_inline)) {
+        return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
     };
-    auto pack8 = [](const float (&v)[8]) __attribute__((always_inline)) {
-        uint4 pk;
-        pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        pk.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-        pk.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-        return pk;
+    auto unpack4 = [&](const uint4& q4, f32x2 (&f)[4]) __attribute__((always_inline)) {
+        f[0] = up2(q4.x); f[1] = up2(q4.y); f[2] = up2(q4.z); f[3] = up2(q4.w);
+    };
+    auto pk2 = [](f32x2 x) __attribute__((always_inline)) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2_t));
+    };
+    auto pack4 = [&](const f32x2 (&x)[4]) __attribute__((always_inline)) {
+        return uint4{pk2(x[0]), pk2(x[1]), pk2(x[2]), pk2(x[3])};
     };
     auto ld16 = [](const bf16_t* base, uint32_t elem) __attribute__((always_inline)) {
         return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + (size_t)(elem * 2u));
     };
-    float bias8[8];
-    if (has_bias && n_ok) unpack8(*reinterpret_cast<const uint4*>(p.bias + n), bias8);
+    // alpha as ONE scalar register for the whole epilogue: left to the compiler the two problems' alphas of a paired launch
+    // sat in VGPRs, were spilled, and every pass reloaded both from scratch memory -- a memory operation whose
+    // s_waitcnt vmcnt(0) also drained the residual prefetch
+    int alpha_bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.alpha));
+    asm volatile("" : "+s"(alpha_bits));
+    const float alpha = __builtin_bit_cast(float, alpha_bits);
+    // QK-norm: the wave tile's 64 columns are ONE head -- its weight vector and whether it is normalised at all (q / k heads
+    // yes, v heads no) are fixed for the tile: loaded once here, not once per pass (a load + full wait 16 times per tile)
+    f32x2 rms_w2[4];
+    bool rms_on = false;
+    if (has_rms) {
+        const int hh = n >> 6;
+        rms_on = hh < p.rms_nheads && n_ok;
+        if (rms_on) unpack4(*reinterpret_cast<const uint4*>(p.rms_w + (hh / p.rms_hpw) * 64 + c8), rms_w2);
+    }
+    f32x2 bias2[4];
+    if (has_bias && n_ok) unpack4(*reinterpret_cast<const uint4*>(p.bias + n), bias2);
     // wave-uniform bookkeeping of the slab's first row m_s: output row = seg_b * seg_stride + seg_off + seg_r (identity map:
     // seg_rows = 0 -> one segment as long as M), gate vector = gate_b
     const int seg_rows = p.seg_rows > 0 ? p.seg_rows : 0x7fffffff;
@@ -166,142 +183,149 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, f32x4 (&acc)[8]
         while (c.gate_r >= gate_rows) { c.gate_r -= gate_rows; ++c.gate_b; }
     };
     // output row of (slab cursor, row inside the slab)
+    // (segments and gate groups are at least a slab long, gemm8p_ok: a slab crosses at most one boundary)
     auto out_row = [&](const Cur& c, int row) __attribute__((always_inline)) -> uint32_t {
         const int base = p.seg_rows > 0 ? c.seg_b * (int)p.seg_stride + (int)p.seg_off + c.seg_r : c.seg_r;
-        int r = base + row;
-        if (c.seg_r + row >= seg_rows) r += seg_jump * ((c.seg_r + row - seg_rows) / seg_rows + 1);   // (segments shorter than a slab: rare, exact)
-        return (uint32_t)r;
+        return (uint32_t)(base + row + (c.seg_r + row >= seg_rows ? seg_jump : 0));
     };
-    // what a slab needs from memory: its residual rows (two passes of 8 rows) and the gate vector of its first row
-    struct Pre { uint4 r[2]; uint4 g; };
+    // what a slab needs from memory: its residual rows (two passes of 8 rows) and the gate vector of its first row.
+    // The loads are UNCONDITIONAL (rows / columns past the edge read element 0 instead): with a load inside a branch the
+    // compiler can no longer count the younger memory operations and waits with vmcnt(0) -- which also waits for the
+    // prefetch it has just issued for the slab after next, so every slab paid a full memory latency (measured: 32 k
+    // cycles for the gate + residual epilogue against 15 k for bias + GELU).
+    struct Pre { uint4 r[2]; uint4 g[2]; };     // (g[ps]: the gate vector of THIS lane's row in pass ps -- no reload branch)
     auto prefetch = [&](const Cur& c, int i, Pre& f) __attribute__((always_inline)) {
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
             const int row = ps * 8 + orow_l;
             f.r[ps] = uint4{0u, 0u, 0u, 0u};
-            if (has_res && i < 8 && mw0 + i * 16 + row < p.M && n_ok)
-                f.r[ps] = ld16(p.residual, __umul24(out_row(c, row), (uint32_t)p.ldr) + n);
+            if (has_res) {
+                const bool ok = mw0 + i * 16 + row < p.M && n_ok;
+                f.r[ps] = ld16(p.residual, ok ? __umul24(out_row(c, row), (uint32_t)p.ldr) + n : 0u);
+            }
         }
-        f.g = uint4{0u, 0u, 0u, 0u};
-        if (has_gate && i < 8 && mw0 + i * 16 < p.M && n_ok)     // (a slab past the last row has no gate vector: out of bounds)
-            f.g = ld16(p.gate, __umul24((uint32_t)c.gate_b, (uint32_t)p.gate_stride) + n);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int row = ps * 8 + orow_l;
+            f.g[ps] = uint4{0u, 0u, 0u, 0u};
+            if (has_gate) {     // (a row past the last one has no gate vector)
+                const bool ok = mw0 + i * 16 + row < p.M && n_ok;
+                const uint32_t gb = (uint32_t)(c.gate_b + (c.gate_r + row >= gate_rows ? 1 : 0));
+                f.g[ps] = ld16(p.gate, ok ? __umul24(gb, (uint32_t)p.gate_stride) + n : 0u);
+            }
+        }
     };
-    Cur c0 = start(__builtin_amdgcn_readfirstlane(mw0)), c1 = c0, c2;
-    advance(c1);
-    c2 = c1;
-    Pre f0, f1, f2;
-    prefetch(c0, 0, f0);
-    prefetch(c1, 1, f1);
+    Cur cur = start(__builtin_amdgcn_readfirstlane(mw0)), cpre = cur;
+    Pre f[3];
+    prefetch(cpre, 0, f[0]);
+    advance(cpre);
+    prefetch(cpre, 1, f[1]);
     const int w_off = mrow * 256, w_sw = mrow & 7;
     const int act = G ? p.act : ((EPI & F_GELU) ? (int)ACT_GELU_TANH : ((EPI & F_DGELU) ? (int)ACT_DGELU_TANH : (int)ACT_NONE));
-#pragma unroll 1
-    for (int rd = 0; rd < 4; ++rd) {
+    static_for<4>([&](auto rdc) {
+        constexpr int rd = decltype(rdc)::value;
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<f32x4*>(scratch + sl * 4096 + w_off + (((j * 4 + q) ^ w_sw) << 4)) = acc[sl][j];
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[k][j] = acc[k + 2][j];
-#pragma unroll 1
-        for (int sl = 0; sl < 2; ++sl) {
-            const int i = rd * 2 + sl;
+                *reinterpret_cast<f32x4*>(scratch + sl * 4096 + w_off + (((j * 4 + q) ^ w_sw) << 4)) = acc[rd * 2 + sl][j];
+        static_for<2>([&](auto slc) {
+            constexpr int sl = decltype(slc)::value;
+            constexpr int i = rd * 2 + sl;
             const char* slab = scratch + sl * 4096;
-            advance(c2);
-            prefetch(c2, i + 2, f2);
+            const Pre& f0 = f[i % 3];
+            const Cur c0 = cur;
+            if constexpr (i + 2 < 8) {
+                advance(cpre);
+                prefetch(cpre, i + 2, f[(i + 2) % 3]);
+            }
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {
                 const int row = ps * 8 + orow_l;
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * 256 + ((((lane & 7) * 2) ^ (row & 7)) << 4));
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * 256 + ((((lane & 7) * 2 + 1) ^ (row & 7)) << 4));
-                if (mw0 + i * 16 + row >= p.M || !n_ok) continue;
+                if (mw0 + i * 16 + row >= p.M || !n_ok) continue;   // (unrolled: skips to the next pass)
                 const uint32_t orow = out_row(c0, row);
                 // (contraction off for the scale / bias / gate / residual steps: where a specialised class makes two of them
                 // unconditional the compiler would fuse them into an fma and the classes would stop agreeing bit for bit)
-                float v[8];
+                // The arithmetic is written on explicit PAIRS (columns 2k, 2k+1 of the lane's eight): v_pk_mul / v_pk_add_f32
+                // on the register pairs the LDS read delivers and one v_cvt_pk_bf16_f32 per output dword.  Left to the
+                // auto-vectoriser the same code paired columns (0,2), (1,3) and re-interleaved them with 14 moves / and / or
+                // per pass (a third of the bias-only epilogue).
+                f32x2 v[4] = {f32x2{lo[0], lo[1]}, f32x2{lo[2], lo[3]}, f32x2{hi[0], hi[1]}, f32x2{hi[2], hi[3]}};
                 {
 #pragma clang fp contract(off)
-                    v[0] = lo[0] * p.alpha; v[1] = lo[1] * p.alpha; v[2] = lo[2] * p.alpha; v[3] = lo[3] * p.alpha;
-                    v[4] = hi[0] * p.alpha; v[5] = hi[1] * p.alpha; v[6] = hi[2] * p.alpha; v[7] = hi[3] * p.alpha;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = v[k] * alpha;
                     if (has_bias) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = v[e] + bias8[e];
+                        for (int k = 0; k < 4; ++k) v[k] = v[k] + bias2[k];
                     }
                 }
                 if (has_rms) {   // QK-norm: the wave tile's 64 columns are one head, its row sits in 8 adjacent lanes
                     const int hh = n >> 6;
                     float sq = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        v[e] = round_bf16(v[e]);
-                        sq += v[e] * v[e];
+                    for (int k = 0; k < 4; ++k) {
+                        v[k] = f32x2{round_bf16(v[k].x), round_bf16(v[k].y)};
+                        sq += v[k].x * v[k].x;
+                        sq += v[k].y * v[k].y;
                     }
                     sq += __shfl_xor(sq, 1, 64);
                     sq += __shfl_xor(sq, 2, 64);
                     sq += __shfl_xor(sq, 4, 64);
-                    if (hh < p.rms_nheads) {
+                    if (rms_on) {
                         const float rs = rsqrtf(sq * (1.0f / 64.0f) + p.rms_eps);
                         if (p.rms_rs_out && (lane & 7) == 0) p.rms_rs_out[(size_t)orow * p.rms_nheads + hh] = rs;
-                        float w8[8];
-                        unpack8(*reinterpret_cast<const uint4*>(p.rms_w + (hh / p.rms_hpw) * 64 + c8), w8);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = round_bf16(v[e] * rs) * w8[e];
+                        for (int k = 0; k < 4; ++k)
+                            v[k] = f32x2{round_bf16(v[k].x * rs) * rms_w2[k].x, round_bf16(v[k].y * rs) * rms_w2[k].y};
                     }
                 }
                 const uint32_t o_aux = __umul24(orow, (uint32_t)p.ld_aux) + n;
-                if (has_aux_out) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.aux_out) + (size_t)(o_aux * 2u)) = pack8(v);
+                if (has_aux_out) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.aux_out) + (size_t)(o_aux * 2u)) = pack4(v);
                 if ((G || (EPI & F_DGELU)) && act >= ACT_DGELU_TANH) {
-                    float z[8];
-                    unpack8(ld16(p.aux_in, o_aux), z);
+                    f32x2 z[4];
+                    unpack4(ld16(p.aux_in, o_aux), z);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= dact_fn(z[e], act);
+                    for (int k = 0; k < 4; ++k) v[k] = f32x2{v[k].x * dact_fn(z[k].x, act), v[k].y * dact_fn(z[k].y, act)};
                 } else if (act == ACT_GELU_TANH) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = act_fn(v[e], ACT_GELU_TANH);
+                    for (int k = 0; k < 4; ++k) v[k] = f32x2{act_fn(v[k].x, ACT_GELU_TANH), act_fn(v[k].y, ACT_GELU_TANH)};
                 } else if (act != ACT_NONE) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = act_fn(v[e], act);
+                    for (int k = 0; k < 4; ++k) v[k] = f32x2{act_fn(v[k].x, act), act_fn(v[k].y, act)};
                 }
                 if (has_gate) {
-                    uint4 gq = f0.g;
-                    if (c0.gate_r + row >= gate_rows) {   // this lane's row belongs to a later sample than the slab's first row
-                        const int gb = c0.gate_b + (c0.gate_r + row - gate_rows) / gate_rows + 1;
-                        gq = ld16(p.gate, __umul24((uint32_t)gb, (uint32_t)p.gate_stride) + n);
-                    }
-                    float g[8];
-                    unpack8(gq, g);
+                    f32x2 g[4];
+                    unpack4(f0.g[ps], g);
                     {
 #pragma clang fp contract(off)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = v[e] * g[e];
+                        for (int k = 0; k < 4; ++k) v[k] = v[k] * g[k];
                     }
                 }
                 if (has_res) {
-                    float r[8];
-                    unpack8(f0.r[ps], r);
+                    f32x2 r[4];
+                    unpack4(f0.r[ps], r);
                     {
 #pragma clang fp contract(off)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = v[e] + r[e];
+                        for (int k = 0; k < 4; ++k) v[k] = v[k] + r[k];
                     }
                 }
                 const uint32_t o = __umul24(orow, (uint32_t)p.ldc) + n;
                 if (out_bf16) {
-                    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.C) + (size_t)(o * 2u)) = pack8(v);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.C) + (size_t)(o * 2u)) = pack4(v);
                 } else {
                     float* c = reinterpret_cast<float*>(reinterpret_cast<char*>(p.C) + (size_t)o * 4u);
-                    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    *reinterpret_cast<float4*>(c) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+                    *reinterpret_cast<float4*>(c + 4) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
                 }
             }
-            f0 = f1;
-            f1 = f2;
-            c0 = c1;
-            c1 = c2;
-        }
-    }
+            advance(cur);
+        });
+    });
 }
 
 }  // namespace
