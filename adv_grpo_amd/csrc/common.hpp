@@ -73,6 +73,18 @@ __device__ __forceinline__ float wave_allreduce(float v, Op op) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // halves of the wave
     return op(a, b);
 }
+// sum over each aligned group of 8 lanes, result in all 8 (same partners and order as three __shfl_xor 1 / 2 / 4 steps, on the
+// VALU's DPP path instead of three dependent ds_bpermute round trips)
+__device__ __forceinline__ float group8_sum(float v) {
+    auto dpp = [](float x, auto ctrl) __attribute__((always_inline)) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
+                                                                     0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});    // lane ^ 1
+    v += dpp(v, std::integral_constant<int, 0x4E>{});    // lane ^ 2
+    v += dpp(v, std::integral_constant<int, 0x141>{});   // the other quad of the 8-lane half (every lane of a quad holds its sum)
+    return v;
+}
 __device__ inline float wave_sum(float v) {
     return wave_allreduce(v, [](float x, float y) { return x + y; });
 }

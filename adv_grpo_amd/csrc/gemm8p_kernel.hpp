@@ -267,19 +267,16 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, f32x4 (&acc)[8]
                     float sq = 0.f;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        v[k] = f32x2{round_bf16(v[k].x), round_bf16(v[k].y)};
+                        v[k] = up2(pk2(v[k]));             // the Linear's bf16 output is what gets normalised
                         sq += v[k].x * v[k].x;
                         sq += v[k].y * v[k].y;
                     }
-                    sq += __shfl_xor(sq, 1, 64);
-                    sq += __shfl_xor(sq, 2, 64);
-                    sq += __shfl_xor(sq, 4, 64);
+                    sq = group8_sum(sq);
                     if (rms_on) {
                         const float rs = rsqrtf(sq * (1.0f / 64.0f) + p.rms_eps);
                         if (p.rms_rs_out && (lane & 7) == 0) p.rms_rs_out[(size_t)orow * p.rms_nheads + hh] = rs;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            v[k] = f32x2{round_bf16(v[k].x * rs) * rms_w2[k].x, round_bf16(v[k].y * rs) * rms_w2[k].y};
+                        for (int k = 0; k < 4; ++k) v[k] = up2(pk2(v[k] * rs)) * rms_w2[k];
                     }
                 }
                 const uint32_t o_aux = __umul24(orow, (uint32_t)p.ld_aux) + n;

@@ -148,9 +148,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4 (&
                         v[e] = round_bf16(v[e]);          // the Linear's bf16 output is what gets normalised
                         sq += v[e] * v[e];
                     }
-                    sq += __shfl_xor(sq, 1, 64);
-                    sq += __shfl_xor(sq, 2, 64);
-                    sq += __shfl_xor(sq, 4, 64);
+                    sq = group8_sum(sq);
                     if (hh < p.rms_nheads) {
                         const float rs = rsqrtf(sq * (1.0f / 64.0f) + p.rms_eps);
                         if (p.rms_rs_out && (lane & 7) == 0) p.rms_rs_out[orow * p.rms_nheads + hh] = rs;
