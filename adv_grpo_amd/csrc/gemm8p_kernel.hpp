@@ -27,6 +27,14 @@ __device__ __forceinline__ void p8_dma16(const char* base, uint32_t off, uint32_
 __device__ __forceinline__ uint32_t lds_addr(const char* p) {
     return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)(p));
 }
+// The lane id, re-derived where it is needed (two VALU instructions) instead of kept live: held across the k loop it was
+// spilled, and each reload at the tile boundary was a scratch-memory load followed by s_waitcnt vmcnt(0) -- 18 serialised
+// memory round trips made up most of the ~2.5-3.5k cycles a wave spent between two tiles.
+__device__ __forceinline__ int p8_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 // wait until at most `allowed` ring items (2 DMA instructions each) of this wave are still in flight
 __device__ __forceinline__ void p8_wait_inflight(int allowed) {
     if (allowed >= 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -50,8 +58,9 @@ struct P8Tile {
     uint32_t a_off[2][2], b_off[2][2];
 };
 
-__device__ __forceinline__ void p8_setup(P8Tile& t, const GemmParams& pr, int id, int wave, int lane) {
+__device__ __forceinline__ void p8_setup(P8Tile& t, const GemmParams& pr, int id, int wave) {
     const GemmParams* p = &pr;
+    const int lane = p8_lane();
     const int tiles_n = (p->N + P8_BN - 1) / P8_BN, tiles_m = (p->M + P8_BM - 1) / P8_BM;
     int tile_m, tile_n;
     tile_coords(id, tiles_m, tiles_n, 4, tile_m, tile_n);
@@ -117,7 +126,8 @@ enum { EPI_PLAIN = 0, EPI_BIAS = F_BIAS, EPI_BIAS_RMS = F_BIAS | F_RMS, EPI_BIAS
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int EPI>
-__device__ __forceinline__ void p8_epilogue(const GemmParams& p, f32x4 (&acc)[8][4], int mw0, int nw0, int lane, char* scratch) {
+__device__ __forceinline__ void p8_epilogue(const GemmParams& p, f32x4 (&acc)[8][4], int mw0, int nw0, char* scratch) {
+    const int lane = p8_lane();
     constexpr bool G = EPI == EPI_GENERIC;
     // features: compile-time constants in the specialised classes (bf16 output, alpha = 1 is NOT assumed)
     const bool has_bias = G ? p.bias != nullptr : (EPI & F_BIAS) != 0;
@@ -332,8 +342,7 @@ struct P8Sched { int tiles_a, tiles_total; unsigned long long* stamps; };   // s
 template <bool PAIR, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const P8Sched sc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;      // wave row (group) / wave column
     // this wave's fragment bases inside a k-tile buffer
     const int a_base = wr * 64 * 128;                     // + sub * P8_HALF + i * 16 * 128
@@ -348,8 +357,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
         const bool second = PAIR && id >= sc.tiles_a;
         if (second) id -= sc.tiles_a;
         t.second = second;
-        if (second) p8_setup(t, pp.b, id, wave, lane);
-        else p8_setup(t, pp.a, id, wave, lane);
+        if (second) p8_setup(t, pp.b, id, wave);
+        else p8_setup(t, pp.a, id, wave);
     };
     // the seven items the steady state would have issued before phase 0 of k-tile 0, in its order: A0 W0 W1 A1 of
     // k-tile 0 (buffer 0), then A0 W0 W1 of k-tile 1 (buffer 1)
@@ -365,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
     auto stamp = [&](int k) __attribute__((always_inline)) {
         if (sc.stamps && wave == 0 && stamp_i < 8) {
             const unsigned long long tm = __builtin_readcyclecounter();
-            if (lane == 0) sc.stamps[((size_t)blockIdx.x * 8 + stamp_i) * 8 + k] = tm;
+            if (p8_lane() == 0) sc.stamps[((size_t)blockIdx.x * 8 + stamp_i) * 8 + k] = tm;
         }
     };
     P8Tile t;
@@ -385,8 +394,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
         // they were spilled, and the reload's conservative s_waitcnt vmcnt(0) ended up INSIDE the k loop (draining the DMA)
         int frag_off[2];
         {
-            int l = lane;
-            asm volatile("" : "+v"(l));
+            const int l = p8_lane();
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) frag_off[ks] = (l & 15) * 128 + (((ks * 4 + (l >> 4)) ^ (l & 7)) << 4);
         }
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
         stamp(3);
         {
             const GemmParams& p = (PAIR && cur_second) ? pp.b : pp.a;
-            p8_epilogue<EPI>(p, acc, mw0, nw0, lane, smem + P8_BUF + wave * P8_SCRATCH);
+            p8_epilogue<EPI>(p, acc, mw0, nw0, smem + P8_BUF + wave * P8_SCRATCH);
         }
         stamp(4);
         if (more) {
