@@ -279,6 +279,16 @@ __device__ __forceinline__ float xor32_add(float v) { float a = v, b = v; ADVGRP
 typedef __attribute__((address_space(3))) void* att_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* att_gptr_t;
 
+// One LDS-DMA instruction (64 lanes x 16 bytes -> LDS [lds, lds + 1 KiB)), hand-written: issued through the builtin the
+// compiler treats the DMA as a possible alias of every later ds_read and puts s_waitcnt vmcnt(0) in front of the first K
+// fragment read of the SAME iteration -- i.e. each wave waited for the tile it had just requested two iterations ahead,
+// and the three-slot ring hid nothing inside a wave.  The ring's hazards are covered by the counted wait + barrier at the
+// top of the loop (RAW) and by that same barrier coming after every read of the slot being refilled (WAR).
+__device__ __forceinline__ void att_dma16(const void* src, const char* lds) {
+    const uint32_t l = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)(lds));
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory");
+}
+
 template <bool BIAS>
 __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnParams p) {
     constexpr int HD = 64, NS = 3, TILE_B = ATT_KB * 128;   // 8 KiB per K or V tile
@@ -335,8 +345,8 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnPa
                 ks = kp + (int64_t)r * p.ldk + k_src_chunk * 8;
                 vs = vp + (int64_t)r * p.ldv + v_chunk[i];
             }
-            __builtin_amdgcn_global_load_lds((att_gptr_t)ks, (att_lds_ptr_t)(base + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((att_gptr_t)vs, (att_lds_ptr_t)(base + TILE_B + j * 1024), 16, 0, 0);
+            att_dma16(ks, base + j * 1024);
+            att_dma16(vs, base + TILE_B + j * 1024);
             k_src[i] += k_step;
             v_src[i] += v_step;
         }
@@ -360,6 +370,13 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnPa
     const int v_sw = (g * 2 + (t >> 3)) & 3;              // ((row >> 1) & 3) for that row (16 | row base)
     const int v_base = v_row * 128 + (t & 3) * 8;
 
+    // the Q fragments must have ARRIVED, in the compiler's own bookkeeping, before the first DMA is issued: otherwise it keeps
+    // "s_waitcnt vmcnt(3) ... vmcnt(0)" for them in front of the loop's first MFMAs, and with the (to it invisible) DMA
+    // instructions in flight behind them those waits drain the ring in every iteration
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) asm volatile("" ::"v"(qf[qb][ks]));
     stage(0, 0);
     if (nt > 1) stage(1, ATT_KB);
     int slot = 0;
