@@ -146,17 +146,8 @@ class SD3Transformer2DModel:
             #     (ops.gemm_grouped) and the QK RMSNorm is the epilogue of the fused QKV projection.
             rms_x = (b["rms_x"], 2 * H, H, 1e-6, None) if cfg.qk_norm else None
             rms_c = (b["rms_c"], 2 * H, H, 1e-6, None) if cfg.qk_norm else None
-            d_x = ops.gemm_desc(nx, b["qkv.w"], bias=b["qkv.b"], out=qkv, seg=(Ni, S, 0), rms=rms_x)
-            d_c = ops.gemm_desc(nc, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni), rms=rms_c)
-            if b["dual"]:
-                # dual-attention block: the image QKV shares its launch with the second attention's QKV (same rows, same
-                # class: 2 x 1152 tiles = 9 full rounds of 256 CUs) and the text QKV goes alone, instead of image + text
-                # (1386 tiles, 6 rounds) followed by the second QKV on its own (1152 tiles, 5 rounds)
-                rms_2 = (b["rms_2"], 2 * H, H, 1e-6, None) if cfg.qk_norm else None
-                _, qkv2 = ops.gemm_grouped([d_x, ops.gemm_desc(nx2, b["qkv2.w"], bias=b["qkv2.b"], rms=rms_2)])
-                ops.gemm_grouped([d_c])
-            else:
-                ops.gemm_grouped([d_x, d_c])
+            ops.gemm_grouped([ops.gemm_desc(nx, b["qkv.w"], bias=b["qkv.b"], out=qkv, seg=(Ni, S, 0), rms=rms_x),
+                              ops.gemm_desc(nc, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni), rms=rms_c)])
             ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att)
             outs = [ops.gemm_desc(att2d, b["out.w"], bias=b["out.b"], gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x,
                                   a_seg=(Ni, S, 0), M=B * Ni)]
@@ -165,6 +156,8 @@ class SD3Transformer2DModel:
                                           out=c, a_seg=(Nt, S, Ni), M=B * Nt))
             ops.gemm_grouped(outs)
             if b["dual"]:
+                rms_2 = (b["rms_2"], 2 * H, H, 1e-6, None) if cfg.qk_norm else None
+                (qkv2,) = ops.gemm_grouped([ops.gemm_desc(nx2, b["qkv2.w"], bias=b["qkv2.b"], rms=rms_2)])
                 q3 = qkv2.view(B, Ni, 3 * D)
                 o2 = ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], H)
                 ops.gemm(o2.view(B * Ni, D), b["out2.w"], bias=b["out2.b"], gate=mod(kx, 8), gate_rows=Ni, residual=x,

@@ -224,15 +224,9 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             qkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
             qkv3 = qkv.view(B, S, 3 * D)
             rs = torch.empty(B * S, 2 * H, dtype=torch.float32, device=dev)
-            d_x = ops.gemm_desc(nx, b["qkv.w"], bias=b["qkv.b"], out=qkv, seg=(Ni, S, 0), rms=(b["rms_x"], 2 * H, H, 1e-6, rs))
-            d_c = ops.gemm_desc(nc, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni), rms=(b["rms_c"], 2 * H, H, 1e-6, rs))
-            if b["dual"]:       # image QKV + second-attention QKV in one launch (9 full rounds), text QKV alone: see mmdit.py
-                rs2 = torch.empty(B * Ni, 2 * H, dtype=torch.float32, device=dev)
-                _, qkv2 = ops.gemm_grouped([d_x, ops.gemm_desc(nx2, b["qkv2.w"], bias=b["qkv2.b"],
-                                                               rms=(b["rms_2"], 2 * H, H, 1e-6, rs2))])
-                ops.gemm_grouped([d_c])
-            else:
-                ops.gemm_grouped([d_x, d_c])
+            ops.gemm_grouped([
+                ops.gemm_desc(nx, b["qkv.w"], bias=b["qkv.b"], out=qkv, seg=(Ni, S, 0), rms=(b["rms_x"], 2 * H, H, 1e-6, rs)),
+                ops.gemm_desc(nc, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni), rms=(b["rms_c"], 2 * H, H, 1e-6, rs))])
             att = torch.empty(B, S, D, dtype=bf16, device=dev)
             lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
             ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att, lse=lse)
@@ -245,6 +239,9 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             ops.gemm_grouped(outs)
             s.update(nx=nx, nc=nc, qkv=qkv, rs=rs, att=att, lse=lse)
             if b["dual"]:
+                rs2 = torch.empty(B * Ni, 2 * H, dtype=torch.float32, device=dev)
+                (qkv2,) = ops.gemm_grouped([ops.gemm_desc(nx2, b["qkv2.w"], bias=b["qkv2.b"],
+                                                          rms=(b["rms_2"], 2 * H, H, 1e-6, rs2))])
                 q3 = qkv2.view(B, Ni, 3 * D)
                 lse2 = torch.empty(B, H, Ni, dtype=torch.float32, device=dev)
                 o2 = ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], H, lse=lse2)
