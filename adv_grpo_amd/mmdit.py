@@ -84,6 +84,18 @@ class SD3Transformer2DModel:
         self.n_mod = off
         self.w = w
 
+    lora_ext = (0, 0)          # side columns of the (QKV, out-projection) inputs; set by SD3TransformerLoRA(lora_mode="side")
+
+    def _lora_side(self, b, key, buf, D, seg=None, M=None):
+        """buf [rows, D + E]: fill the E side columns with u = buf[:, :D] . A^T for the adapted Linear `key` (rows through
+        the row-segment map `seg` for the joint attention buffer).  Returns what the Linear reads: the whole buffer when the
+        side path is on, the plain [rows, D] view otherwise."""
+        A = b.get(key + ".A")
+        if A is None:
+            return buf[:, :D] if buf.shape[1] != D else buf
+        ops.gemm(buf[:, :D], A, out=buf[:, D:], seg=seg, a_seg=seg, M=M)
+        return buf
+
     def _pos(self, B, hh, ww):
         key = (B, hh, ww)
         if key not in self._pos_cache:
@@ -127,21 +139,28 @@ class SD3Transformer2DModel:
 
         qkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
         qkv3 = qkv.view(B, S, 3 * D)
-        att = torch.empty(B, S, D, dtype=bf16, device=dev)
-        att2d = att.view(B * S, D)
+        # LoRA side path (SD3TransformerLoRA(lora_mode="side")): the input of an adapted Linear is kept in a buffer with E extra
+        # columns that receive u = x A^T, and the Linear runs over K + E with the weight [W | s B]; E = 0 otherwise
+        Eq, Eo = self.lora_ext
+        att_ext = torch.empty(B, S, D + Eo, dtype=bf16, device=dev)
+        att = att_ext[:, :, :D]
+        att2d = att_ext.view(B * S, D + Eo)
+        nx_buf = torch.empty(B * Ni, D + Eq, dtype=bf16, device=dev)
+        nc_buf = torch.empty(B * Nt, D + Eq, dtype=bf16, device=dev)
         for i, b in enumerate(self.blocks):
             kx, kc = ("x", i), ("c", i)
             # --- norms + modulation (chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
             #     [, shift_msa2, scale_msa2, gate_msa2]); AdaLayerNormContinuous (last context): scale, shift
             if b["dual"]:
-                nx, nx2 = ops.layernorm_mod(x, scale=mod(kx, 1), shift=mod(kx, 0), scale2=mod(kx, 7), shift2=mod(kx, 6),
-                                            rows_per_batch=Ni)
+                _, nx2 = ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), scale2=mod(kx, 7),
+                                           shift2=mod(kx, 6), rows_per_batch=Ni)
             else:
-                nx = ops.layernorm_mod(x, scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
+                ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
             if b["last"]:
-                nc = ops.layernorm_mod(c, scale=mod(kc, 0), shift=mod(kc, 1), rows_per_batch=Nt)
+                ops.layernorm_mod(c, out=nc_buf[:, :D], scale=mod(kc, 0), shift=mod(kc, 1), rows_per_batch=Nt)
             else:
-                nc = ops.layernorm_mod(c, scale=mod(kc, 1), shift=mod(kc, 0), rows_per_batch=Nt)
+                ops.layernorm_mod(c, out=nc_buf[:, :D], scale=mod(kc, 1), shift=mod(kc, 0), rows_per_batch=Nt)
+            nx, nc = self._lora_side(b, "qkv", nx_buf, D), self._lora_side(b, "cqkv", nc_buf, D)
             # --- joint attention.  Each text-stream Linear rides in the launch of its image-stream twin
             #     (ops.gemm_grouped) and the QK RMSNorm is the epilogue of the fused QKV projection.
             rms_x = (b["rms_x"], 2 * H, H, 1e-6, None) if cfg.qk_norm else None
@@ -149,6 +168,10 @@ class SD3Transformer2DModel:
             ops.gemm_grouped([ops.gemm_desc(nx, b["qkv.w"], bias=b["qkv.b"], out=qkv, seg=(Ni, S, 0), rms=rms_x),
                               ops.gemm_desc(nc, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni), rms=rms_c)])
             ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att)
+            if Eo:
+                self._lora_side(b, "out", att2d, D, seg=(Ni, S, 0), M=B * Ni)
+                if not b["last"]:
+                    self._lora_side(b, "cout", att2d, D, seg=(Nt, S, Ni), M=B * Nt)
             outs = [ops.gemm_desc(att2d, b["out.w"], bias=b["out.b"], gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x,
                                   a_seg=(Ni, S, 0), M=B * Ni)]
             if not b["last"]:

@@ -6,9 +6,14 @@ add_k_proj,add_v_proj,to_add_out}), torch autograd through diffusers' SD3Transfo
 gradient accumulation + clip_grad_norm_ + AdamW (TP:1165-1171, TP:554-561) and EMAModuleWrapper (adv_grpo/ema.py).
 
 MI355X-first choices:
-  * LoRA is MERGED into the bf16 weights (W_eff = W + (alpha/r) B A, and the transposed copy used by the
-    data-gradient GEMMs); forward and dgrad therefore run at full-GEMM efficiency with no rank-32 side path.  The
-    LoRA weight gradients are recovered from (X, dY) of each adapted Linear:
+  * lora_mode="merged" (default): LoRA is MERGED into the bf16 weights (W_eff = W + (alpha/r) B A, and the transposed
+    copy used by the data-gradient GEMMs); forward and dgrad therefore run at full-GEMM efficiency with no rank-32 side
+    path.  lora_mode="side": PEFT's arithmetic -- y = x W^T + s (x A^T) B^T with W untouched -- as a K-EXTENSION of the
+    same GEMM: the adapted Linear's input lives in a buffer with E extra columns that a skinny GEMM fills with
+    u = x A^T, and the Linear contracts [x | u] with [W | s B] over K + E (E = 192 for the fused QKV, 64 for the output
+    projections).  An update of B then reaches the log-probs at full bf16 resolution of s B instead of being rounded
+    into W (deviation 2).  The backward still uses the merged transposes for dX (gradient-side rounding only).
+    The LoRA weight gradients are recovered from (X, dY) of each adapted Linear:
         dB = s * dY^T (X A^T),   dA = s * (dY B)^T X
     as split-K GEMMs over the token axis accumulating atomically into the flat f32 gradient vector.
   * No activation recomputation: with 288 GB of HBM every tensor the backward needs is kept (~0.6 GB per block per
@@ -38,9 +43,14 @@ class _Adapter:
 
 
 class SD3TransformerLoRA(SD3Transformer2DModel):
-    def __init__(self, state_dict, cfg, device="cuda", lora_alpha=64, seed=0, lora_state=None):
+    def __init__(self, state_dict, cfg, device="cuda", lora_alpha=64, seed=0, lora_state=None, lora_mode="merged"):
+        if lora_mode not in ("merged", "side"):
+            raise ValueError(f"lora_mode must be 'merged' or 'side', got {lora_mode!r}")
+        self.lora_mode = lora_mode
         self._base_sd = {k: v for k, v in state_dict.items()}
         super().__init__(state_dict, cfg, device)
+        if lora_mode == "side":
+            self.lora_ext = (3 * RPAD, RPAD)
         self.scale = lora_alpha / RANK
         D = cfg.dim
         # ---- flat parameter vector: per adapter A_pad [64, K] then B_pad [N, 64]
@@ -166,7 +176,7 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                 groups["cout"] = ["to_add_out"]
             for gk, names in groups.items():
                 base, baseT = self._base_T[i][gk]
-                w = b[gk + ".w"]
+                w = b[gk + ".w"] if self.lora_mode == "merged" else None
                 wT = b.get(gk + ".wT")
                 if wT is None:
                     wT = b[gk + ".wT"] = torch.empty(base.shape[1], base.shape[0], dtype=torch.bfloat16, device=self.device)
@@ -178,11 +188,27 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                     AT = ops.transpose(A16)                                      # [K, 64]
                     sl = slice(j * D, (j + 1) * D)
                     # W_eff[n,k] = W + s * B A ;  W_eff^T[k,n] = W^T + s * A^T B^T
-                    ops.gemm(B16, AT, alpha=self.scale, residual=base[sl], out=w[sl])
+                    if w is not None:
+                        ops.gemm(B16, AT, alpha=self.scale, residual=base[sl], out=w[sl])
                     ops.gemm(AT, B16, alpha=self.scale, residual=baseT[:, sl], out=wT[:, sl])
                     As.append(A16)
                     Bts.append(ops.transpose(B16))                               # [64, N]
-                self._lora[(i, gk)] = (torch.cat(As, 0).contiguous(), Bts, [self.adapters[f"{p}.{n}"] for n in names])
+                A_cat = torch.cat(As, 0).contiguous()
+                self._lora[(i, gk)] = (A_cat, Bts, [self.adapters[f"{p}.{n}"] for n in names])
+                if self.lora_mode == "side":
+                    # forward weight [W | s B]: the base weight is left as loaded, each adapter's s * B (bf16; s = 2 is exact)
+                    # sits in its own 64 side columns of its output rows
+                    K = base.shape[1]
+                    E = RPAD * len(names)
+                    wx = b.get(gk + ".wx")
+                    if wx is None:
+                        wx = b[gk + ".wx"] = torch.zeros(base.shape[0], K + E, dtype=torch.bfloat16, device=self.device)
+                        wx[:, :K] = base
+                    for j, n in enumerate(names):
+                        B16 = self.B_view(self.adapters[f"{p}.{n}"], self.params_bf16)
+                        wx[j * D:(j + 1) * D, K + j * RPAD:K + (j + 1) * RPAD] = (self.scale * B16.float()).to(torch.bfloat16)
+                    b[gk + ".w"] = wx
+                    b[gk + ".A"] = A_cat
 
     # ------------------------------------------------------------------ forward with saved activations
     @torch.no_grad()
@@ -214,27 +240,38 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
         for i, b in enumerate(self.blocks):
             kx, kc = ("x", i), ("c", i)
             s = {"x_in": x.clone(), "c_in": c.clone()}
+            Eq, Eo = self.lora_ext
+            nx_buf = torch.empty(B * Ni, D + Eq, dtype=bf16, device=dev)
+            nc_buf = torch.empty(B * Nt, D + Eq, dtype=bf16, device=dev)
             if b["dual"]:
-                nx, nx2 = ops.layernorm_mod(x, scale=mod(kx, 1), shift=mod(kx, 0), scale2=mod(kx, 7), shift2=mod(kx, 6),
-                                            rows_per_batch=Ni)
+                _, nx2 = ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), scale2=mod(kx, 7),
+                                           shift2=mod(kx, 6), rows_per_batch=Ni)
             else:
-                nx = ops.layernorm_mod(x, scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
-            nc = ops.layernorm_mod(c, scale=mod(kc, 0 if b["last"] else 1), shift=mod(kc, 1 if b["last"] else 0),
-                                   rows_per_batch=Nt)
+                ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
+            ops.layernorm_mod(c, out=nc_buf[:, :D], scale=mod(kc, 0 if b["last"] else 1), shift=mod(kc, 1 if b["last"] else 0),
+                              rows_per_batch=Nt)
+            nx_in, nc_in = self._lora_side(b, "qkv", nx_buf, D), self._lora_side(b, "cqkv", nc_buf, D)
+            nx, nc = nx_buf[:, :D], nc_buf[:, :D]                   # what the backward keeps: the Linear's input proper
             qkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
             qkv3 = qkv.view(B, S, 3 * D)
             rs = torch.empty(B * S, 2 * H, dtype=torch.float32, device=dev)
             ops.gemm_grouped([
-                ops.gemm_desc(nx, b["qkv.w"], bias=b["qkv.b"], out=qkv, seg=(Ni, S, 0), rms=(b["rms_x"], 2 * H, H, 1e-6, rs)),
-                ops.gemm_desc(nc, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni), rms=(b["rms_c"], 2 * H, H, 1e-6, rs))])
-            att = torch.empty(B, S, D, dtype=bf16, device=dev)
+                ops.gemm_desc(nx_in, b["qkv.w"], bias=b["qkv.b"], out=qkv, seg=(Ni, S, 0), rms=(b["rms_x"], 2 * H, H, 1e-6, rs)),
+                ops.gemm_desc(nc_in, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni), rms=(b["rms_c"], 2 * H, H, 1e-6, rs))])
+            att_ext = torch.empty(B, S, D + Eo, dtype=bf16, device=dev)
+            att = att_ext[:, :, :D]
             lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
             ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att, lse=lse)
-            att2d = att.view(B * S, D)
-            outs = [ops.gemm_desc(att2d, b["out.w"], bias=b["out.b"], gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x,
+            att_in = att_ext.view(B * S, D + Eo)
+            if Eo:
+                self._lora_side(b, "out", att_in, D, seg=(Ni, S, 0), M=B * Ni)
+                if not b["last"]:
+                    self._lora_side(b, "cout", att_in, D, seg=(Nt, S, Ni), M=B * Nt)
+            att2d = att_in[:, :D]
+            outs = [ops.gemm_desc(att_in, b["out.w"], bias=b["out.b"], gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x,
                                   a_seg=(Ni, S, 0), M=B * Ni)]
             if not b["last"]:
-                outs.append(ops.gemm_desc(att2d, b["cout.w"], bias=b["cout.b"], gate=mod(kc, 2), gate_rows=Nt, residual=c,
+                outs.append(ops.gemm_desc(att_in, b["cout.w"], bias=b["cout.b"], gate=mod(kc, 2), gate_rows=Nt, residual=c,
                                           out=c, a_seg=(Nt, S, Ni), M=B * Nt))
             ops.gemm_grouped(outs)
             s.update(nx=nx, nc=nc, qkv=qkv, rs=rs, att=att, lse=lse)

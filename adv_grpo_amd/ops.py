@@ -207,7 +207,8 @@ def layernorm_mod(x, out=None, w=None, b=None, scale=None, shift=None, scale2=No
     lib = _lib.load()
     M, D = x.shape
     out = torch.empty(M, D, dtype=torch.bfloat16, device=x.device) if out is None else out
-    out2 = torch.empty_like(out) if scale2 is not None else None
+    # (out2 shares out's row pitch: one ldo for both in the C entry)
+    out2 = torch.empty_strided(out.shape, out.stride(), dtype=out.dtype, device=out.device) if scale2 is not None else None
     ms = scale.stride(0) if scale is not None else 0
     if scale is not None:
         assert shift.stride(0) == ms and scale.stride(1) == 1

@@ -297,6 +297,23 @@ def main():
             vae_ms[mode] = (time.perf_counter() - tv) / 3 * 1e3
             del dec
         step_ms = dt / args.steps * 1e3
+        # the rollout with PEFT's LoRA arithmetic (side path as a K-extension of the adapted Linears, mmdit_train.py) instead
+        # of LoRA merged into the bf16 weights: same step, other transformer object
+        lora_ms = {"merged": round(step_ms, 2)}
+        if not c4 and world == 1:
+            from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
+            merged_tr = pipe.transformer
+            with synthetic.on_device(device):
+                pipe.transformer = SD3TransformerLoRA(synthetic.mmdit_weights(merged_tr.cfg, 1234), merged_tr.cfg, device,
+                                                      lora_mode="side")
+            step(0)
+            torch.cuda.synchronize()
+            tl = time.perf_counter()
+            for it in range(2):
+                step(1 + it)
+            torch.cuda.synchronize()
+            lora_ms["side"] = round((time.perf_counter() - tl) / 2 * 1e3, 2)
+            pipe.transformer = merged_tr
         res = {
             "metric": "sampled+scored images/sec (whole node), SD3.5-large 1024^2 10-step G=4 (secondary line, BASELINE config 4 shapes)"
             if c4 else "sampled+scored images/sec (whole node), SD3-med 512^2 10-step G=8 GRPO",
@@ -321,6 +338,13 @@ def main():
                     "share_of_step_time": round(vae_ms[pipe.vae.mode] / step_ms, 4),
                     # what the headline would be with the other decoder swapped in (only the decode time changes)
                     "value_if_bf16x3": round(images / (dt + args.steps * (vae_ms["bf16x3"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)},
+            "lora": {"mode": "merged",
+                     "modes": {"merged": "W_eff = bf16(W + s B A) in the rollout and training forward (the timed configuration)",
+                               "side": "PEFT's y = W x + s B (A x) as K + 192 / K + 64 extra columns of the adapted Linears: the "
+                                       "product's log-prob change after the first AdamW step is within 0.2 % of the exact one "
+                                       "(merged: 2.2 %; tests/test_gpu_train.py)"},
+                     "ms_per_step": lora_ms,
+                     "value_if_side": round(world * G / (lora_ms["side"] * 1e-3), 3) if "side" in lora_ms else None},
         }
     run_epoch = not c4 and not args.no_epoch and (world == 1 or args.epoch)
     if run_epoch:                                   # every rank takes part (LoRA-gradient all-reduce, reward gather)

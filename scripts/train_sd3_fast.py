@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--eval", action="store_true", help="run the eval loop every eval_freq epochs (with the co-trained scorer: "
                     "the stand-alone PickScore / image-similarity scorers need real checkpoints)")
     ap.add_argument("--log", default="logs/train.jsonl")
+    ap.add_argument("--lora-mode", default="merged", choices=["merged", "side"],
+                    help="merged: LoRA folded into the bf16 weights (default); side: PEFT's side-path arithmetic (TP:490-511)")
     ap.add_argument("--vae-mode", default="bf16", choices=["bf16", "bf16x3"],
                     help="decoder arithmetic: bf16 (default) or the fp32-equivalent split-bf16 mode (the reference decodes in fp32, TP:481)")
     args = ap.parse_args()
@@ -53,7 +55,7 @@ def main():
     mcfg = MMDiTConfig() if args.layers is None else MMDiTConfig(num_layers=args.layers,
                                                                  dual_attention_layers=tuple(range(min(13, args.layers))))
     with synthetic.on_device(device):
-        tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, device, seed=cfg.seed)
+        tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, device, seed=cfg.seed, lora_mode=args.lora_mode)
         vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321), VaeConfig(), device, mode=args.vae_mode)
         head = None
         if any(k.startswith("dino") for k in cfg.reward_fn.keys()):

@@ -413,3 +413,106 @@ def test_merged_bf16_lora_log_prob_drift_is_bounded():
             assert rel <= (0.05 if k == 1 else 0.01), (k, rel)
             assert (torch.sign(lp_m - lp_base) == torch.sign(d_pol)).all()
             assert (torch.sign(prod - lp0.double()) == torch.sign(d_pol)).all()   # and so does the product's bf16 forward
+
+
+def test_lora_side_path_mode_small_model_exactness_and_grads():
+    """lora_mode="side" (PEFT's y = W x + s B (A x) as a K-extension of the same GEMM, DESIGN.md 3 deviation 2) on a small
+    MMDiT: with B = 0 the side columns contribute exact zeros, so rollout forward, training forward and log-probs are
+    bit-identical to the merged mode; with B != 0 both modes agree within bf16 resolution, __call__ and forward_train stay
+    bit-identical to each other (ratio = 1 while the weights are unchanged), and the LoRA gradients of the two modes
+    agree (same backward; the forward activations differ by bf16 rounding only)."""
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
+    from adv_grpo_amd.model_configs import MMDiTConfig
+    cfg = MMDiTConfig(num_layers=3, num_heads=4, joint_attention_dim=128, pooled_projection_dim=64, pos_embed_max_size=16,
+                      dual_attention_layers=(0,))
+    W = {k: v.to(torch.bfloat16) for k, v in synthetic.mmdit_weights(cfg, 3).items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4, 16, 16, 16, generator=g).to(torch.bfloat16).cuda()
+    t = torch.tensor([700.0] * 4).cuda()
+    ctx = torch.randn(4, 37, 128, generator=g).to(torch.bfloat16).cuda()
+    pooled = torch.randn(4, 64, generator=g).to(torch.bfloat16).cuda()
+    m0 = SD3TransformerLoRA(W, cfg, "cuda", seed=1)
+    s0 = SD3TransformerLoRA(W, cfg, "cuda", seed=1, lora_mode="side")
+    y_m, y_s = m0(x, t, ctx, pooled)[0], s0(x, t, ctx, pooled)[0]
+    assert torch.equal(y_m, y_s)                                             # B = 0: exact zeros from the side columns
+    lora = {k: (v + 0.02 * torch.randn(v.shape, generator=g).to(v.device)) if "lora_B" in k else v
+            for k, v in m0.lora_state_dict().items()}
+    m0.load_lora_state(lora); s0.load_lora_state(lora)
+    y_m, y_s = m0(x, t, ctx, pooled)[0].float(), s0(x, t, ctx, pooled)[0].float()
+    assert not torch.equal(y_m, y_s)
+    rel = ((y_m - y_s).norm() / y_m.norm()).item()
+    print("side vs merged forward rel L2", rel)
+    assert rel < 2e-2
+    yt, ctx_t = s0.forward_train(x, t, ctx, pooled)
+    assert torch.equal(yt.float(), y_s)                                      # rollout forward == training forward
+    dv = torch.randn(yt.shape, generator=g).to(torch.bfloat16).cuda()
+    s0.grads.zero_(); s0.backward(ctx_t, dv)
+    _, ctx_m = m0.forward_train(x, t, ctx, pooled)
+    m0.grads.zero_(); m0.backward(ctx_m, dv)
+    cos = torch.nn.functional.cosine_similarity(s0.grads, m0.grads, dim=0).item()
+    print("LoRA gradient cosine side vs merged", cos)
+    assert cos > 0.99
+    with pytest.raises(ValueError):
+        SD3TransformerLoRA(W, cfg, "cuda", lora_mode="peft")
+
+
+def test_lora_side_path_tracks_exact_policy_change_at_full_size():
+    """Full size (24 blocks, D = 1536, 512^2, G = 8): one real AdamW step from B = 0 at lr 3e-4 in both modes (identical
+    gradients: at B = 0 the two forwards are bit-identical), then the product's own log-prob change against the fp32 oracle
+    with the exact effective weights: mean |product change - exact change| / mean |exact change| is 2.2 % in merged mode
+    (the bf16 rounding of W + s B A swallows part of the first update) and 0.18 % in side mode (asserted: side <= 1 %, less
+    than half of merged)."""
+    from adv_grpo_amd import g_step, synthetic
+    from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
+    from adv_grpo_amd.model_configs import MMDiTConfig
+    from adv_grpo_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from oracle import lora as o_lora
+    from oracle import mmdit as o
+    from oracle import rollout as o_roll
+    from oracle.scheduler import FlowMatchEulerScheduler
+    cfg, ocfg = MMDiTConfig(), o.MMDiTConfig()
+    W = {k: v.to(torch.bfloat16) for k, v in synthetic.mmdit_weights(cfg, 1234).items()}
+    G = 8
+    g = torch.Generator().manual_seed(5)
+    sch = FlowMatchEulerDiscreteScheduler(device="cuda"); sch.set_timesteps(10)
+    osch = FlowMatchEulerScheduler(); osch.device = "cuda"; osch.set_timesteps(10)
+    x = torch.randn(G, 16, 64, 64, generator=g).to(torch.bfloat16)
+    nxt = (x.float() * 0.95 + 0.3 * torch.randn(G, 16, 64, 64, generator=g)).to(torch.bfloat16)
+    embeds = torch.randn(2 * G, 205, 4096, generator=g).to(torch.bfloat16).cuda()
+    pooled = torch.randn(2 * G, 2048, generator=g).to(torch.bfloat16).cuda()
+    adv = torch.randn(G, generator=g).cuda()
+    sample = {"latents": x[:, None].cuda(), "next_latents": nxt[:, None].cuda(), "timesteps": sch.timesteps[1].repeat(G)[:, None]}
+    kw = dict(guidance_scale=4.5, noise_level=0.8, adv_clip_max=5, clip_range=1e-5)
+    W32 = {k: t.float().cuda() for k, t in W.items()}
+
+    @torch.no_grad()
+    def oracle_lp(weights):
+        tr = lambda xx, tt, cc, pp: o.mmdit_forward(weights, ocfg, xx.float(), tt, cc.float(), pp.float())
+        return o_roll.compute_log_prob(tr, osch, dict(sample), 0, embeds, pooled, guidance_scale=4.5, noise_level=0.8)[1].double()
+    lp_base = oracle_lp(W32)
+    res = {}
+    for mode in ("merged", "side"):
+        model = SD3TransformerLoRA(W, cfg, "cuda", seed=42, lora_mode=mode)
+        lp0 = g_step.micro_step(model, sch, sample, 0, embeds, pooled, torch.zeros(G, device="cuda"), adv, **kw)["log_prob"].clone()
+        model.grads.zero_()
+        again = g_step.micro_step(model, sch, sample, 0, embeds, pooled, lp0, adv, **kw)
+        assert torch.equal(again["log_prob"], lp0) and again["clipfrac"].item() == 0
+        model.grads.zero_()
+        g_step.micro_step(model, sch, sample, 0, embeds, pooled, lp0, adv, **kw)
+        model.optimizer_step(lr=3e-4, weight_decay=1e-4, max_grad_norm=1.0)
+        lp1 = g_step.micro_step(model, sch, sample, 0, embeds, pooled, lp0, adv, **kw)["log_prob"].double()
+        lora = {n: t.float() for n, t in model.lora_state_dict().items()}
+        res[mode] = (lp0.double(), lp1, lora)
+        del model
+        torch.cuda.empty_cache()
+    assert torch.equal(res["merged"][0], res["side"][0])                     # B = 0: same log-probs, hence the same update
+    for n in res["merged"][2]:
+        assert torch.equal(res["merged"][2][n], res["side"][2][n])
+    d_pol = oracle_lp(o_lora.effective_weights(W32, res["side"][2])) - lp_base
+    err = {m: ((res[m][1] - res[m][0]) - d_pol).abs().mean().item() / d_pol.abs().mean().item() for m in res}
+    print(f"|d_pol| {d_pol.abs().mean():.3e}; product log-prob change vs exact: merged {100 * err['merged']:.2f} %, side {100 * err['side']:.2f} %")
+    assert (torch.sign(res["side"][1] - res["side"][0]) == torch.sign(d_pol)).all()
+    # measured: merged 2.2 %, side 0.18 %
+    assert err["side"] <= 0.01 and err["side"] < 0.5 * err["merged"] and err["merged"] <= 0.05, err
+
