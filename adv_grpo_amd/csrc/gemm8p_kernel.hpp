@@ -124,6 +124,9 @@ enum { EPI_PLAIN = 0, EPI_BIAS = F_BIAS, EPI_BIAS_RMS = F_BIAS | F_RMS, EPI_BIAS
        EPI_BIAS_GELU_AUX = F_BIAS | F_GELU | F_AUX_OUT, EPI_DGELU = F_DGELU };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef P8_EPI_AHEAD
+#define P8_EPI_AHEAD 3
+#endif
 
 template <int EPI>
 __device__ __forceinline__ void p8_epilogue(const GemmParams& p, f32x4 (&acc)[8][4], int mw0, int nw0, char* scratch) {
@@ -226,10 +229,14 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, f32x4 (&acc)[8]
         }
     };
     Cur cur = start(__builtin_amdgcn_readfirstlane(mw0)), cpre = cur;
-    Pre f[3];
+    constexpr int AHEAD = P8_EPI_AHEAD;       // slabs requested ahead of the one being written out
+    Pre f[AHEAD + 1];
     prefetch(cpre, 0, f[0]);
-    advance(cpre);
-    prefetch(cpre, 1, f[1]);
+#pragma unroll
+    for (int a = 1; a < AHEAD; ++a) {
+        advance(cpre);
+        prefetch(cpre, a, f[a]);
+    }
     const int w_off = mrow * 256, w_sw = mrow & 7;
     const int act = G ? p.act : ((EPI & F_GELU) ? (int)ACT_GELU_TANH : ((EPI & F_DGELU) ? (int)ACT_DGELU_TANH : (int)ACT_NONE));
     static_for<4>([&](auto rdc) {
@@ -243,11 +250,11 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, f32x4 (&acc)[8]
             constexpr int sl = decltype(slc)::value;
             constexpr int i = rd * 2 + sl;
             const char* slab = scratch + sl * 4096;
-            const Pre& f0 = f[i % 3];
+            const Pre& f0 = f[i % (AHEAD + 1)];
             const Cur c0 = cur;
-            if constexpr (i + 2 < 8) {
+            if constexpr (i + AHEAD < 8) {
                 advance(cpre);
-                prefetch(cpre, i + 2, f[(i + 2) % 3]);
+                prefetch(cpre, i + AHEAD, f[(i + AHEAD) % (AHEAD + 1)]);
             }
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {
