@@ -128,10 +128,60 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define P8_EPI_AHEAD 3
 #endif
 
+// a value pinned into scalar registers (opaque to the optimiser from here on)
+template <class T>
+__device__ __forceinline__ T p8_sgpr(T v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+__device__ __forceinline__ float p8_sgpr(float v) { return __builtin_bit_cast(float, p8_sgpr(__builtin_bit_cast(int, v))); }
+
+// The epilogue's own copy of the problem description, chosen ONCE per tile.  Reading the fields through
+// "second ? pp.b : pp.a" the compiler kept BOTH problems of a paired launch in scalar registers and selected at every use:
+// the ~120 SGPRs that needs were spilled to VGPR lanes, and the gate + residual / QK-norm epilogues executed 400-500
+// v_readlane (plus their hazard wait states) per tile.  32-bit copies of what is 64-bit on the host side (pitches, segment
+// strides: all host-checked to fit) halve the register count again.
+struct P8EpiArgs {
+    int M, N, act, out_dtype;
+    float alpha, rms_eps;
+    const bf16_t *bias, *gate, *residual, *rms_w, *aux_in;
+    bf16_t* aux_out;
+    void* C;
+    float* rms_rs_out;
+    int rms_nheads, rms_hpw, gate_rows, seg_rows, seg_stride, seg_off;
+    uint32_t gate_stride, ldc, ldr, ld_aux;
+};
 template <int EPI>
-__device__ __forceinline__ void p8_epilogue(const GemmParams& p, f32x4 (&acc)[8][4], int mw0, int nw0, char* scratch) {
+__device__ __forceinline__ P8EpiArgs p8_epi_args(const GemmParams& g) {
+    constexpr bool G = EPI == EPI_GENERIC;
+    constexpr bool BIAS = G || (EPI & F_BIAS), RMS = G || (EPI & F_RMS), GR = G || (EPI & F_GATE_RES), AUXO = G || (EPI & F_AUX_OUT),
+                   AUXI = G || (EPI & F_DGELU);
+    P8EpiArgs e{};
+    e.M = p8_sgpr(g.M); e.N = p8_sgpr(g.N);
+    e.alpha = p8_sgpr(g.alpha);
+    e.C = p8_sgpr(g.C); e.ldc = p8_sgpr((uint32_t)g.ldc);
+    e.seg_rows = p8_sgpr(g.seg_rows); e.seg_stride = p8_sgpr((int)g.seg_stride); e.seg_off = p8_sgpr((int)g.seg_off);
+    if constexpr (G) { e.act = p8_sgpr(g.act); e.out_dtype = p8_sgpr(g.out_dtype); }
+    if constexpr (BIAS) e.bias = p8_sgpr(g.bias);
+    if constexpr (RMS) {
+        e.rms_w = p8_sgpr(g.rms_w); e.rms_rs_out = p8_sgpr(g.rms_rs_out); e.rms_nheads = p8_sgpr(g.rms_nheads);
+        e.rms_hpw = p8_sgpr(g.rms_hpw); e.rms_eps = p8_sgpr(g.rms_eps);
+    }
+    if constexpr (GR) {
+        e.gate = p8_sgpr(g.gate); e.gate_stride = p8_sgpr((uint32_t)g.gate_stride); e.gate_rows = p8_sgpr(g.gate_rows);
+        e.residual = p8_sgpr(g.residual); e.ldr = p8_sgpr((uint32_t)g.ldr);
+    }
+    if constexpr (AUXO) e.aux_out = p8_sgpr(g.aux_out);
+    if constexpr (AUXI) e.aux_in = p8_sgpr(g.aux_in);
+    if constexpr (AUXO || AUXI) e.ld_aux = p8_sgpr((uint32_t)g.ld_aux);
+    return e;
+}
+
+template <int EPI>
+__device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)[8][4], int mw0, int nw0, char* scratch) {
     const int lane = p8_lane();
     constexpr bool G = EPI == EPI_GENERIC;
+    const P8EpiArgs p = p8_epi_args<EPI>(p_in);
     // features: compile-time constants in the specialised classes (bf16 output, alpha = 1 is NOT assumed)
     const bool has_bias = G ? p.bias != nullptr : (EPI & F_BIAS) != 0;
     const bool has_rms = G ? p.rms_w != nullptr : (EPI & F_RMS) != 0;
@@ -163,9 +213,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, f32x4 (&acc)[8]
     // alpha as ONE scalar register for the whole epilogue: left to the compiler the two problems' alphas of a paired launch
     // sat in VGPRs, were spilled, and every pass reloaded both from scratch memory -- a memory operation whose
     // s_waitcnt vmcnt(0) also drained the residual prefetch
-    int alpha_bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.alpha));
-    asm volatile("" : "+s"(alpha_bits));
-    const float alpha = __builtin_bit_cast(float, alpha_bits);
+    const float alpha = p.alpha;
     // QK-norm: the wave tile's 64 columns are ONE head -- its weight vector and whether it is normalised at all (q / k heads
     // yes, v heads no) are fixed for the tile: loaded once here, not once per pass (a load + full wait 16 times per tile)
     f32x2 rms_w2[4];
