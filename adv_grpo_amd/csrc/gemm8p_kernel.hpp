@@ -128,6 +128,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define P8_EPI_AHEAD 3
 #endif
 
+typedef const __attribute__((address_space(1))) char* p8_gcptr;
+typedef __attribute__((address_space(1))) char* p8_gptr;
+typedef uint32_t p8_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 p8_gld16(p8_gcptr base, uint32_t byte_off) {
+    const p8_u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) p8_u32x4*>(base + byte_off);
+    return uint4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void p8_gst16(p8_gptr base, size_t byte_off, const uint4& v) {
+    *reinterpret_cast<__attribute__((address_space(1))) p8_u32x4*>(base + byte_off) = p8_u32x4{v.x, v.y, v.z, v.w};
+}
 // a value pinned into scalar registers (opaque to the optimiser from here on)
 template <class T>
 __device__ __forceinline__ T p8_sgpr(T v) {
@@ -144,10 +154,10 @@ __device__ __forceinline__ float p8_sgpr(float v) { return __builtin_bit_cast(fl
 struct P8EpiArgs {
     int M, N, act, out_dtype;
     float alpha, rms_eps;
-    const bf16_t *bias, *gate, *residual, *rms_w, *aux_in;
-    bf16_t* aux_out;
-    void* C;
-    float* rms_rs_out;
+    // (explicitly GLOBAL pointers: a pointer that went through the register pin has lost the address space the compiler
+    // infers for kernel arguments and would be accessed with flat_load / flat_store)
+    p8_gcptr bias, gate, residual, rms_w, aux_in;
+    p8_gptr aux_out, C, rms_rs_out;
     int rms_nheads, rms_hpw, gate_rows, seg_rows, seg_stride, seg_off;
     uint32_t gate_stride, ldc, ldr, ld_aux;
 };
@@ -159,20 +169,20 @@ __device__ __forceinline__ P8EpiArgs p8_epi_args(const GemmParams& g) {
     P8EpiArgs e{};
     e.M = p8_sgpr(g.M); e.N = p8_sgpr(g.N);
     e.alpha = p8_sgpr(g.alpha);
-    e.C = p8_sgpr(g.C); e.ldc = p8_sgpr((uint32_t)g.ldc);
+    e.C = (p8_gptr)p8_sgpr((uintptr_t)g.C); e.ldc = p8_sgpr((uint32_t)g.ldc);
     e.seg_rows = p8_sgpr(g.seg_rows); e.seg_stride = p8_sgpr((int)g.seg_stride); e.seg_off = p8_sgpr((int)g.seg_off);
     if constexpr (G) { e.act = p8_sgpr(g.act); e.out_dtype = p8_sgpr(g.out_dtype); }
-    if constexpr (BIAS) e.bias = p8_sgpr(g.bias);
+    if constexpr (BIAS) e.bias = (p8_gcptr)p8_sgpr((uintptr_t)g.bias);
     if constexpr (RMS) {
-        e.rms_w = p8_sgpr(g.rms_w); e.rms_rs_out = p8_sgpr(g.rms_rs_out); e.rms_nheads = p8_sgpr(g.rms_nheads);
+        e.rms_w = (p8_gcptr)p8_sgpr((uintptr_t)g.rms_w); e.rms_rs_out = (p8_gptr)p8_sgpr((uintptr_t)g.rms_rs_out); e.rms_nheads = p8_sgpr(g.rms_nheads);
         e.rms_hpw = p8_sgpr(g.rms_hpw); e.rms_eps = p8_sgpr(g.rms_eps);
     }
     if constexpr (GR) {
-        e.gate = p8_sgpr(g.gate); e.gate_stride = p8_sgpr((uint32_t)g.gate_stride); e.gate_rows = p8_sgpr(g.gate_rows);
-        e.residual = p8_sgpr(g.residual); e.ldr = p8_sgpr((uint32_t)g.ldr);
+        e.gate = (p8_gcptr)p8_sgpr((uintptr_t)g.gate); e.gate_stride = p8_sgpr((uint32_t)g.gate_stride); e.gate_rows = p8_sgpr(g.gate_rows);
+        e.residual = (p8_gcptr)p8_sgpr((uintptr_t)g.residual); e.ldr = p8_sgpr((uint32_t)g.ldr);
     }
-    if constexpr (AUXO) e.aux_out = p8_sgpr(g.aux_out);
-    if constexpr (AUXI) e.aux_in = p8_sgpr(g.aux_in);
+    if constexpr (AUXO) e.aux_out = (p8_gptr)p8_sgpr((uintptr_t)g.aux_out);
+    if constexpr (AUXI) e.aux_in = (p8_gcptr)p8_sgpr((uintptr_t)g.aux_in);
     if constexpr (AUXO || AUXI) e.ld_aux = p8_sgpr((uint32_t)g.ld_aux);
     return e;
 }
@@ -207,9 +217,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
     auto pack4 = [&](const f32x2 (&x)[4]) __attribute__((always_inline)) {
         return uint4{pk2(x[0]), pk2(x[1]), pk2(x[2]), pk2(x[3])};
     };
-    auto ld16 = [](const bf16_t* base, uint32_t elem) __attribute__((always_inline)) {
-        return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + (size_t)(elem * 2u));
-    };
+    auto ld16 = [](p8_gcptr base, uint32_t elem) __attribute__((always_inline)) { return p8_gld16(base, elem * 2u); };
     // alpha as ONE scalar register for the whole epilogue: left to the compiler the two problems' alphas of a paired launch
     // sat in VGPRs, were spilled, and every pass reloaded both from scratch memory -- a memory operation whose
     // s_waitcnt vmcnt(0) also drained the residual prefetch
@@ -221,10 +229,10 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
     if (has_rms) {
         const int hh = n >> 6;
         rms_on = hh < p.rms_nheads && n_ok;
-        if (rms_on) unpack4(*reinterpret_cast<const uint4*>(p.rms_w + (hh / p.rms_hpw) * 64 + c8), rms_w2);
+        if (rms_on) unpack4(ld16(p.rms_w, (uint32_t)((hh / p.rms_hpw) * 64 + c8)), rms_w2);
     }
     f32x2 bias2[4];
-    if (has_bias && n_ok) unpack4(*reinterpret_cast<const uint4*>(p.bias + n), bias2);
+    if (has_bias && n_ok) unpack4(ld16(p.bias, (uint32_t)n), bias2);
     // wave-uniform bookkeeping of the slab's first row m_s: output row = seg_b * seg_stride + seg_off + seg_r (identity map:
     // seg_rows = 0 -> one segment as long as M), gate vector = gate_b
     const int seg_rows = p.seg_rows > 0 ? p.seg_rows : 0x7fffffff;
@@ -339,13 +347,14 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
                     sq = group8_sum(sq);
                     if (rms_on) {
                         const float rs = rsqrtf(sq * (1.0f / 64.0f) + p.rms_eps);
-                        if (p.rms_rs_out && (lane & 7) == 0) p.rms_rs_out[(size_t)orow * p.rms_nheads + hh] = rs;
+                        if (p.rms_rs_out && (lane & 7) == 0)
+                            *reinterpret_cast<__attribute__((address_space(1))) float*>(p.rms_rs_out + ((size_t)orow * p.rms_nheads + hh) * 4) = rs;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] = up2(pk2(v[k] * rs)) * rms_w2[k];
                     }
                 }
                 const uint32_t o_aux = __umul24(orow, (uint32_t)p.ld_aux) + n;
-                if (has_aux_out) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.aux_out) + (size_t)(o_aux * 2u)) = pack4(v);
+                if (has_aux_out) p8_gst16(p.aux_out, (size_t)(o_aux * 2u), pack4(v));
                 if ((G || (EPI & F_DGELU)) && act >= ACT_DGELU_TANH) {
                     f32x2 z[4];
                     unpack4(ld16(p.aux_in, o_aux), z);
@@ -378,11 +387,10 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
                 }
                 const uint32_t o = __umul24(orow, (uint32_t)p.ldc) + n;
                 if (out_bf16) {
-                    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.C) + (size_t)(o * 2u)) = pack4(v);
+                    p8_gst16(p.C, (size_t)(o * 2u), pack4(v));
                 } else {
-                    float* c = reinterpret_cast<float*>(reinterpret_cast<char*>(p.C) + (size_t)o * 4u);
-                    *reinterpret_cast<float4*>(c) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
-                    *reinterpret_cast<float4*>(c + 4) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+                    p8_gst16(p.C, (size_t)o * 4u, __builtin_bit_cast(uint4, make_float4(v[0].x, v[0].y, v[1].x, v[1].y)));
+                    p8_gst16(p.C, (size_t)o * 4u + 16, __builtin_bit_cast(uint4, make_float4(v[2].x, v[2].y, v[3].x, v[3].y)));
                 }
             }
             advance(cur);
