@@ -245,17 +245,23 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
         c.gate_b = m / gate_rows; c.gate_r = m - c.gate_b * gate_rows;
         return c;
     };
-    auto advance = [&](Cur& c) __attribute__((always_inline)) {     // 16 rows further
+    // 16 rows further; segments / gate groups are at least 16 rows (gemm8p_ok): at most one wrap, done with scalar selects
+    // (as loops these were four real branches per slab, and a taken branch is an instruction-fetch bubble)
+    auto advance = [&](Cur& c) __attribute__((always_inline)) {
         c.seg_r += 16;
-        while (c.seg_r >= seg_rows) { c.seg_r -= seg_rows; ++c.seg_b; }
+        const int ws = c.seg_r >= seg_rows ? 1 : 0;
+        c.seg_r -= ws ? seg_rows : 0;
+        c.seg_b += ws;
         c.gate_r += 16;
-        while (c.gate_r >= gate_rows) { c.gate_r -= gate_rows; ++c.gate_b; }
+        const int wg = c.gate_r >= gate_rows ? 1 : 0;
+        c.gate_r -= wg ? gate_rows : 0;
+        c.gate_b += wg;
     };
     // output row of (slab cursor, row inside the slab)
     // (segments and gate groups are at least a slab long, gemm8p_ok: a slab crosses at most one boundary)
     auto out_row = [&](const Cur& c, int row) __attribute__((always_inline)) -> uint32_t {
         const int base = p.seg_rows > 0 ? c.seg_b * (int)p.seg_stride + (int)p.seg_off + c.seg_r : c.seg_r;
-        return (uint32_t)(base + row + (c.seg_r + row >= seg_rows ? seg_jump : 0));
+        return (uint32_t)(base + row + (seg_jump & -(int)(c.seg_r + row >= seg_rows)));
     };
     // what a slab needs from memory: its residual rows (two passes of 8 rows) and the gate vector of its first row.
     // The loads are UNCONDITIONAL (rows / columns past the edge read element 0 instead): with a load inside a branch the
@@ -270,7 +276,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
             f.r[ps] = uint4{0u, 0u, 0u, 0u};
             if (has_res) {
                 const bool ok = mw0 + i * 16 + row < p.M && n_ok;
-                f.r[ps] = ld16(p.residual, ok ? __umul24(out_row(c, row), (uint32_t)p.ldr) + n : 0u);
+                f.r[ps] = ld16(p.residual, (__umul24(out_row(c, row), (uint32_t)p.ldr) + n) & (0u - (uint32_t)ok));
             }
         }
 #pragma unroll
@@ -279,8 +285,8 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
             f.g[ps] = uint4{0u, 0u, 0u, 0u};
             if (has_gate) {     // (a row past the last one has no gate vector)
                 const bool ok = mw0 + i * 16 + row < p.M && n_ok;
-                const uint32_t gb = (uint32_t)(c.gate_b + (c.gate_r + row >= gate_rows ? 1 : 0));
-                f.g[ps] = ld16(p.gate, ok ? __umul24(gb, (uint32_t)p.gate_stride) + n : 0u);
+                const uint32_t gb = (uint32_t)(c.gate_b + (int)(c.gate_r + row >= gate_rows));
+                f.g[ps] = ld16(p.gate, (__umul24(gb, (uint32_t)p.gate_stride) + n) & (0u - (uint32_t)ok));
             }
         }
     };
