@@ -138,6 +138,10 @@ __device__ __forceinline__ uint4 p8_gld16(p8_gcptr base, uint32_t byte_off) {
 __device__ __forceinline__ void p8_gst16(p8_gptr base, size_t byte_off, const uint4& v) {
     *reinterpret_cast<__attribute__((address_space(1))) p8_u32x4*>(base + byte_off) = p8_u32x4{v.x, v.y, v.z, v.w};
 }
+// streaming (non-temporal) store: the output tile is not read again by this kernel
+__device__ __forceinline__ void p8_gst16_nt(p8_gptr base, size_t byte_off, const uint4& v) {
+    __builtin_nontemporal_store(p8_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<__attribute__((address_space(1))) p8_u32x4*>(base + byte_off));
+}
 // a value pinned into scalar registers (opaque to the optimiser from here on)
 template <class T>
 __device__ __forceinline__ T p8_sgpr(T v) {
@@ -393,7 +397,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
                 }
                 const uint32_t o = __umul24(orow, (uint32_t)p.ldc) + n;
                 if (out_bf16) {
-                    p8_gst16(p.C, (size_t)(o * 2u), pack4(v));
+                    p8_gst16_nt(p.C, (size_t)(o * 2u), pack4(v));
                 } else {
                     p8_gst16(p.C, (size_t)o * 4u, __builtin_bit_cast(uint4, make_float4(v[0].x, v[0].y, v[1].x, v[1].y)));
                     p8_gst16(p.C, (size_t)o * 4u + 16, __builtin_bit_cast(uint4, make_float4(v[2].x, v[2].y, v[3].x, v[3].y)));
