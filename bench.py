@@ -40,6 +40,9 @@ def parse():
                                                          "of the G-step to what the scaling curve exercises)")
     ap.add_argument("--config", default="c2", choices=["c2", "c4"],
                     help="c2 = the headline (BASELINE config 2); c4 = secondary line, SD3.5-large 1024^2 G=4 (BASELINE config 4 shapes)")
+    ap.add_argument("--no-pricing", action="store_true",
+                    help="skip the untimed legs that price the alternative modes (split-bf16 VAE, LoRA side path): profiling runs, "
+                         "so that the rocprof summary holds the timed configuration only")
     ap.add_argument("--vae-mode", default="bf16", choices=["bf16", "bf16x3"],
                     help="decoder arithmetic inside the timed step: bf16 (default) or the fp32-equivalent split-bf16 mode; the "
                          "'vae' object of the JSON line prices both either way")
@@ -283,6 +286,8 @@ def main():
         lat = torch.randn(G, 16, RES // 8, RES // 8, device=device).to(torch.bfloat16)
         vae_ms = {}
         for mode in ("bf16", "bf16x3"):
+            if args.no_pricing and mode != pipe.vae.mode:
+                continue
             if mode == pipe.vae.mode:
                 dec = pipe.vae
             else:
@@ -300,7 +305,7 @@ def main():
         # the rollout with PEFT's LoRA arithmetic (side path as a K-extension of the adapted Linears, mmdit_train.py) instead
         # of LoRA merged into the bf16 weights: same step, other transformer object
         lora_ms = {"merged": round(step_ms, 2)}
-        if not c4 and world == 1:
+        if not c4 and world == 1 and not args.no_pricing:
             from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
             merged_tr = pipe.transformer
             with synthetic.on_device(device):
@@ -337,7 +342,8 @@ def main():
                     "ms_per_group_decode": {k: round(v, 2) for k, v in vae_ms.items()},
                     "share_of_step_time": round(vae_ms[pipe.vae.mode] / step_ms, 4),
                     # what the headline would be with the other decoder swapped in (only the decode time changes)
-                    "value_if_bf16x3": round(images / (dt + args.steps * (vae_ms["bf16x3"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)},
+                    "value_if_bf16x3": round(images / (dt + args.steps * (vae_ms["bf16x3"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)
+                    if "bf16x3" in vae_ms else None},
             "lora": {"mode": "merged",
                      "modes": {"merged": "W_eff = bf16(W + s B A) in the rollout and training forward (the timed configuration)",
                                "side": "PEFT's y = W x + s B (A x) as K + 192 / K + 64 extra columns of the adapted Linears: the "
