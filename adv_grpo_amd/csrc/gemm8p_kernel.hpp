@@ -372,7 +372,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
                     for (int k = 0; k < 4; ++k) v[k] = f32x2{v[k].x * dact_fn(z[k].x, act), v[k].y * dact_fn(z[k].y, act)};
                 } else if (act == ACT_GELU_TANH) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = f32x2{act_fn(v[k].x, ACT_GELU_TANH), act_fn(v[k].y, ACT_GELU_TANH)};
+                    for (int k = 0; k < 4; ++k) v[k] = gelu_tanh_pk(v[k]);
                 } else if (act != ACT_NONE) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = f32x2{act_fn(v[k].x, act), act_fn(v[k].y, act)};

@@ -11,13 +11,33 @@ namespace advgrpo {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 
+// gelu_tanh(x) = 0.5 x (1 + tanh u), u = sqrt(2/pi) (x + 0.044715 x^3)  ==  x * sigmoid(2u)  ==  x / (1 + 2^(x (C1 + C2 x^2)))
+// with C1 = -2 sqrt(2/pi) log2(e), C2 = 0.044715 C1: one v_exp + one v_rcp, and five other operations written so that the
+// scalar form below and the two-column form of the eight-phase epilogue (gelu_tanh_pk: v_pk_mul / v_pk_fma / v_pk_add on
+// register pairs) execute the SAME IEEE operations per element -- the tile variants stay bit-identical.
+#define ADVGRPO_GELU_C1 (-2.3022081981f)
+#define ADVGRPO_GELU_C2 (-0.10294324f)
+__device__ __forceinline__ float gelu_tanh_f32(float x) {
+#pragma clang fp contract(off)
+    float t = x * x;
+    t = __builtin_fmaf(t, ADVGRPO_GELU_C2, ADVGRPO_GELU_C1);
+    t = t * x;
+    const float d = __builtin_amdgcn_exp2f(t) + 1.0f;
+    return x * __builtin_amdgcn_rcpf(d);
+}
+typedef float gelu_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gelu_f32x2 gelu_tanh_pk(gelu_f32x2 x) {
+#pragma clang fp contract(off)
+    gelu_f32x2 t = x * x;
+    t = __builtin_elementwise_fma(t, gelu_f32x2{ADVGRPO_GELU_C2, ADVGRPO_GELU_C2}, gelu_f32x2{ADVGRPO_GELU_C1, ADVGRPO_GELU_C1});
+    t = t * x;
+    gelu_f32x2 d = gelu_f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+    return x * gelu_f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+
 __device__ inline float act_fn(float x, int act) {
     switch (act) {
-        case ACT_GELU_TANH: {
-            // 0.5 x (1 + tanh u) == x * sigmoid(2u): one v_exp + one v_rcp instead of a tanhf expansion
-            const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);
-            return x * __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
-        }
+        case ACT_GELU_TANH: return gelu_tanh_f32(x);
         case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
         case ACT_SILU: return x / (1.0f + __expf(-x));
         case ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));

@@ -18,7 +18,14 @@ kw = dict(bias=b)
 if mode == "gelu": kw["act"] = "gelu_tanh"
 if mode == "gateres": kw.update(gate=rnd(16, N), gate_rows=M // 16, residual=rnd(M, N))
 if mode == "plain": kw = {}
-for _ in range(3): ops.gemm(a, w, out=out, **kw)
+if mode == "rms":      # the fused-QKV class: bias + per-head RMSNorm on the first 2/3 of the columns, row-segment scatter
+    H = N // 3 // 64
+    rw = rnd(2, 64)
+    big = torch.empty(M // 1024 * 1229, N, dtype=torch.bfloat16, device="cuda")
+    run = lambda: ops.gemm_grouped([ops.gemm_desc(a, w, bias=b, out=big, seg=(1024, 1229, 0), rms=(rw, 2 * H, H, 1e-6, None))])
+else:
+    run = lambda: ops.gemm(a, w, out=out, **kw)
+for _ in range(3): run()
 torch.cuda.synchronize()
 buf = np.zeros(256 * 8 * 8, dtype=np.uint64)
 assert lib.advgrpo_dbg_p8_stamps(buf.ctypes.data, buf.size) == 0
