@@ -101,20 +101,28 @@ __device__ __forceinline__ void p8_stage(const P8Tile& t, char* smem, int wave, 
 }
 
 // Fused epilogue.  Same arithmetic, in the same order, as gemm_epilogue_rows (gemm_device.hpp) -- results are bit-identical to
-// the other tile variants.  With one workgroup per CU nothing overlaps the epilogue, so it is built for a low instruction
-// count (the first version spent 16 us per tile here, 30 us being the whole k loop):
-//   * ONE copy of the code: a runtime loop over four rounds of two 16-row slabs.  Accumulators may only be indexed
-//     statically (a runtime-indexed accumulator array goes to scratch memory), so every round writes accumulator slabs 0
-//     and 1 to the wave's private 8 KiB of LDS and rotates the other slabs down by two; fully unrolled with every option the
-//     code of this tile is ~100k instructions and the instruction fetch alone cost 29 us per tile;
+// the other tile variants.  With one workgroup per CU nothing overlaps the epilogue, so every cycle in it is exposed (the
+// first version spent 16 us per tile here, 30 us being the whole k loop).  What it is built from, and why:
+//   * eight 16-row slabs in four STATIC rounds of two: accumulators may only be indexed statically (a runtime-indexed
+//     accumulator array goes to scratch memory); a round writes two slabs to the wave's private 8 KiB of LDS, then a
+//     static loop over the two slabs reads them back row-wise.  (A runtime round loop with the accumulators rotated down
+//     by `v_mov` cost ~190 v_mov_b64 per tile; fully unrolling every OPTION as well gave 100k instructions and 29 us of
+//     instruction fetch per tile -- the options are compile-time classes instead, below.)
 //   * LDS bounce: f32 rows of 256 B, 16-byte chunk c of row r at slot c ^ (r & 7) -- conflict-free for the ds_write_b128
 //     of the accumulator layout (8 lanes = 8 rows, one chunk) and for the ds_read_b128 of the row layout (a lane ends
 //     with 8 consecutive columns of one row: 16-byte loads of bias / gate / residual / aux, 16-byte stores);
-//   * no integer division per row: the output-row map (row-segment scatter) and the gate index advance as wave-uniform
-//     (segment, remainder) pairs from slab to slab, a lane only checks whether ITS row wrapped into the next segment;
+//   * no integer division per row and no branches: the output-row map (row-segment scatter) and the gate index advance as
+//     wave-uniform (segment, remainder) pairs from slab to slab with scalar selects; a lane adds the segment jump / next
+//     gate vector by comparison masks (segments and gate groups are at least a slab long: gemm8p_ok);
 //   * 32-bit element offsets from the uniform operand bases (host-checked), 24-bit multiplies;
-//   * residual rows and the gate vector of a slab are requested two slabs ahead of their use.
-//   * specialised at compile time for the four epilogues of the rollout (EPI_*): skipping the unused options with
+//   * residual rows and gate vectors are requested P8_EPI_AHEAD slabs ahead with UNCONDITIONAL loads (edge rows read
+//     element 0): a load inside a branch makes the compiler wait with vmcnt(0), which also waits for the prefetch just issued;
+//   * the problem description is selected once per tile into pinned scalar registers (P8EpiArgs), the lane id is
+//     re-derived (p8_lane): anything kept live across the k loop is spilled, and a spill reload is a memory operation
+//     whose vmcnt(0) drains the prefetches (VGPR) or hundreds of v_readlane (SGPR);
+//   * arithmetic on explicit column pairs (v_pk_mul / v_pk_add / v_pk_fma_f32, one v_cvt_pk_bf16_f32 per output dword);
+//   * streaming (nt) stores of the output tile;
+//   * specialised at compile time for the epilogues of the rollout and the G-step (EPI_*): skipping the unused options with
 //     wave-uniform branches cost more than the arithmetic (a taken branch is an instruction-fetch bubble; the generic
 //     code took 22-28k cycles per tile, 55k being the k loop).
 // A class is a set of features fixed at compile time (EPI_GENERIC: everything decided at run time).
