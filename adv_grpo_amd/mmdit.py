@@ -90,11 +90,22 @@ class SD3Transformer2DModel:
         """buf [rows, D + E]: fill the E side columns with u = buf[:, :D] . A^T for the adapted Linear `key` (rows through
         the row-segment map `seg` for the joint attention buffer).  Returns what the Linear reads: the whole buffer when the
         side path is on, the plain [rows, D] view otherwise."""
-        A = b.get(key + ".A")
-        if A is None:
-            return buf[:, :D] if buf.shape[1] != D else buf
-        ops.gemm(buf[:, :D], A, out=buf[:, D:], seg=seg, a_seg=seg, M=M)
-        return buf
+        return self._lora_side_pair(b, [(key, buf, seg, M)], D)[0]
+
+    def _lora_side_pair(self, b, items, D):
+        """_lora_side for the image-stream and text-stream twins of one Linear in ONE grouped launch (the text-stream u-GEMM
+        rides in the image-stream one's launch, like the Linears themselves).  items: (key, buf, seg, M) each."""
+        descs, outs = [], []
+        for key, buf, seg, M in items:
+            A = b.get(key + ".A")
+            if A is None:
+                outs.append(buf[:, :D] if buf.shape[1] != D else buf)
+                continue
+            descs.append(ops.gemm_desc(buf[:, :D], A, out=buf[:, D:], seg=seg, a_seg=seg, M=M))
+            outs.append(buf)
+        if descs:
+            ops.gemm_grouped(descs)
+        return outs
 
     def _pos(self, B, hh, ww):
         key = (B, hh, ww)
@@ -160,7 +171,7 @@ class SD3Transformer2DModel:
                 ops.layernorm_mod(c, out=nc_buf[:, :D], scale=mod(kc, 0), shift=mod(kc, 1), rows_per_batch=Nt)
             else:
                 ops.layernorm_mod(c, out=nc_buf[:, :D], scale=mod(kc, 1), shift=mod(kc, 0), rows_per_batch=Nt)
-            nx, nc = self._lora_side(b, "qkv", nx_buf, D), self._lora_side(b, "cqkv", nc_buf, D)
+            nx, nc = self._lora_side_pair(b, [("qkv", nx_buf, None, None), ("cqkv", nc_buf, None, None)], D)
             # --- joint attention.  Each text-stream Linear rides in the launch of its image-stream twin
             #     (ops.gemm_grouped) and the QK RMSNorm is the epilogue of the fused QKV projection.
             rms_x = (b["rms_x"], 2 * H, H, 1e-6, None) if cfg.qk_norm else None
@@ -169,9 +180,8 @@ class SD3Transformer2DModel:
                               ops.gemm_desc(nc, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni), rms=rms_c)])
             ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att)
             if Eo:
-                self._lora_side(b, "out", att2d, D, seg=(Ni, S, 0), M=B * Ni)
-                if not b["last"]:
-                    self._lora_side(b, "cout", att2d, D, seg=(Nt, S, Ni), M=B * Nt)
+                self._lora_side_pair(b, [("out", att2d, (Ni, S, 0), B * Ni)] +
+                                     ([] if b["last"] else [("cout", att2d, (Nt, S, Ni), B * Nt)]), D)
             outs = [ops.gemm_desc(att2d, b["out.w"], bias=b["out.b"], gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x,
                                   a_seg=(Ni, S, 0), M=B * Ni)]
             if not b["last"]:

@@ -250,7 +250,7 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                 ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
             ops.layernorm_mod(c, out=nc_buf[:, :D], scale=mod(kc, 0 if b["last"] else 1), shift=mod(kc, 1 if b["last"] else 0),
                               rows_per_batch=Nt)
-            nx_in, nc_in = self._lora_side(b, "qkv", nx_buf, D), self._lora_side(b, "cqkv", nc_buf, D)
+            nx_in, nc_in = self._lora_side_pair(b, [("qkv", nx_buf, None, None), ("cqkv", nc_buf, None, None)], D)
             nx, nc = nx_buf[:, :D], nc_buf[:, :D]                   # what the backward keeps: the Linear's input proper
             qkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
             qkv3 = qkv.view(B, S, 3 * D)
@@ -264,9 +264,8 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att, lse=lse)
             att_in = att_ext.view(B * S, D + Eo)
             if Eo:
-                self._lora_side(b, "out", att_in, D, seg=(Ni, S, 0), M=B * Ni)
-                if not b["last"]:
-                    self._lora_side(b, "cout", att_in, D, seg=(Nt, S, Ni), M=B * Nt)
+                self._lora_side_pair(b, [("out", att_in, (Ni, S, 0), B * Ni)] +
+                                     ([] if b["last"] else [("cout", att_in, (Nt, S, Ni), B * Nt)]), D)
             att2d = att_in[:, :D]
             outs = [ops.gemm_desc(att_in, b["out.w"], bias=b["out.b"], gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x,
                                   a_seg=(Ni, S, 0), M=B * Ni)]
