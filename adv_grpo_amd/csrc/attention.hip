@@ -289,9 +289,13 @@ __device__ __forceinline__ void att_dma16(const void* src, const char* lds) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory");
 }
 
+#ifndef ATT_NS
+#define ATT_NS 3
+#define ATT_WGS 3
+#endif
 template <bool BIAS>
-__global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnParams p) {
-    constexpr int HD = 64, NS = 3, TILE_B = ATT_KB * 128;   // 8 KiB per K or V tile
+__global__ __launch_bounds__(256, ATT_WGS) void attention_fwd_glds_kernel(const AttnParams p) {
+    constexpr int HD = 64, NS = ATT_NS, TILE_B = ATT_KB * 128;   // 8 KiB per K or V tile
     constexpr int LOADS = 4;                                 // DMA instructions per wave per tile (2 K + 2 V)
     __shared__ __attribute__((aligned(16))) char smem[NS * 2 * TILE_B];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -378,15 +382,15 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_glds_kernel(const AttnPa
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) asm volatile("" ::"v"(qf[qb][ks]));
     stage(0, 0);
-    if (nt > 1) stage(1, ATT_KB);
+    if (NS > 2 && nt > 1) stage(1, ATT_KB);
     int slot = 0;
     for (int it = 0; it < nt; ++it) {
         const int kv0 = it * ATT_KB;
-        if (it + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        if (NS > 2 && it + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int fill = slot == 0 ? NS - 1 : slot - 1;   // slot of tile it-1: free after this barrier
-        if (it + 2 < nt) stage(fill, kv0 + 2 * ATT_KB);
+        if (it + NS - 1 < nt) stage(fill, kv0 + (NS - 1) * ATT_KB);
         const char* Kt = smem + slot * 2 * TILE_B;
         const char* Vt = Kt + TILE_B;
         slot = slot == NS - 1 ? 0 : slot + 1;
