@@ -95,15 +95,26 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restric
     }
 }
 
+// per-(image, group) mean and 1/std in f32 from the f64 sums, once: done per element group inside the apply kernel the f64
+// division (and two f64 loads) per 4 channels made a streaming kernel run at 1.7 TB/s
+__global__ void groupnorm_finalize_kernel(const double* __restrict__ stats, float* __restrict__ mr, int n, double cnt, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double s = stats[2 * i], q = stats[2 * i + 1];
+    const double mean = s / cnt;
+    const double var = q / cnt - mean * mean;
+    mr[2 * i] = (float)mean;
+    mr[2 * i + 1] = rsqrtf(fmaxf((float)var, 0.f) + eps);
+}
+
 // T = bf16_t: bf16 in / bf16 affine / bf16 out.  T = float (split-bf16 mode): f32 in, f32 affine, output row of 3C bf16
 // = [hi | hi | lo] of the normalised value.
 template <typename T>
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restrict__ x, bf16_t* __restrict__ y,
-                                                              const double* __restrict__ stats,
+                                                              const float* __restrict__ mr,
                                                               const T* __restrict__ w, const T* __restrict__ bb,
-                                                              int HW, int C, int G, float eps, int silu, int64_t total8) {
+                                                              int HW, int C, int G, int silu, int64_t total8) {
     const int c8n = C >> 3, cpg = C / G;
-    const double cnt = (double)HW * cpg;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
         const int slice = i % c8n;
         const int64_t pix = i / c8n;
@@ -115,14 +126,12 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
             const int g = (slice * 8 + hlf * 4) / cpg;
-            const double s = stats[((int64_t)b * G + g) * 2], q = stats[((int64_t)b * G + g) * 2 + 1];
-            const double mean = s / cnt;
-            const double var = q / cnt - mean * mean;
-            const float mu = (float)mean, rstd = rsqrtf(fmaxf((float)var, 0.f) + eps);
+            const float2 m2 = *reinterpret_cast<const float2*>(mr + ((int64_t)b * G + g) * 2);
+            const float mu = m2.x, rstd = m2.y;
 #pragma unroll
             for (int k = hlf * 4; k < hlf * 4 + 4; ++k) {
                 float t = (v[k] - mu) * rstd * ww[k] + bv[k];
-                if (silu) t = t / (1.0f + __expf(-t));
+                if (silu) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));   // (v_rcp: the IEEE division costs ~10 more instructions per element)
                 v[k] = t;
             }
         }
@@ -322,11 +331,17 @@ extern "C" int advgrpo_groupnorm_nhwc(const void* x, void* y, double* stats, con
     hipLaunchKernelGGL(groupnorm_stats_kernel<bf16_t>, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, s, (const bf16_t*)x, stats,
                        HW, C, G, ppb);
     ADVGRPO_LAUNCH_CHECK();
+    // the f64 sums are followed by B*G (mean, 1/std) f32 pairs in the same scratch buffer (stats holds 2*B*G doubles; the
+    // pairs overwrite nothing: they are written behind them -- see the workspace size in the header)
+    float* mr = reinterpret_cast<float*>(stats + (size_t)B * G * 2);
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, s, stats, mr, B * G,
+                       (double)HW * (C / G), eps);
+    ADVGRPO_LAUNCH_CHECK();
     const int64_t total8 = (int64_t)B * HW * (C / 8);
     int64_t blocks = (total8 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(groupnorm_apply_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, stats,
-                       (const bf16_t*)weight, (const bf16_t*)bias, HW, C, G, eps, silu, total8);
+    hipLaunchKernelGGL(groupnorm_apply_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, mr,
+                       (const bf16_t*)weight, (const bf16_t*)bias, HW, C, G, silu, total8);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
@@ -344,11 +359,15 @@ extern "C" int advgrpo_groupnorm_nhwc_x3(const float* x, void* y3, double* stats
     const int ppb = 512;
     hipLaunchKernelGGL(groupnorm_stats_kernel<float>, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, s, x, stats, HW, C, G, ppb);
     ADVGRPO_LAUNCH_CHECK();
+    float* mr = reinterpret_cast<float*>(stats + (size_t)B * G * 2);
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, s, stats, mr, B * G,
+                       (double)HW * (C / G), eps);
+    ADVGRPO_LAUNCH_CHECK();
     const int64_t total8 = (int64_t)B * HW * (C / 8);
     int64_t blocks = (total8 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(groupnorm_apply_kernel<float>, dim3((int)blocks), dim3(256), 0, s, x, (bf16_t*)y3, stats, weight, bias,
-                       HW, C, G, eps, silu, total8);
+    hipLaunchKernelGGL(groupnorm_apply_kernel<float>, dim3((int)blocks), dim3(256), 0, s, x, (bf16_t*)y3, mr, weight, bias,
+                       HW, C, G, silu, total8);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
