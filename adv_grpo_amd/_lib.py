@@ -85,6 +85,7 @@ SIGNATURES = {
     "advgrpo_patchify": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "advgrpo_unpatchify": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "advgrpo_conv3x3_nhwc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
+    "advgrpo_groupnorm_scratch_bytes": (c_int64, [c_int, c_int, c_int]),
     "advgrpo_groupnorm_nhwc": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "advgrpo_softmax_rows": (c_int, [_P, c_int64, c_int, _P]),
     "advgrpo_latents_to_nhwc": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P]),

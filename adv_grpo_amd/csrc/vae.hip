@@ -60,16 +60,18 @@ __device__ inline void split8(const float v[8], uint4& hi, uint4& lo) {
     lo = pack8v(l);
 }
 
+// Deterministic: every sum is formed in a fixed order (per thread over its pixels, per block over its threads through LDS,
+// per image over the blocks in groupnorm_finalize_kernel) -- with float / f64 atomics the statistics differed in the last
+// bit from run to run, and 30 layers of a decoder amplify that to the bf16 level (two decodes of the same latents differed by
+// up to 2e-2 on the [0,1] image).  partial: [B, nchunks, G, 2] f64.
 template <typename T>
-__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restrict__ x, double* __restrict__ stats,
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restrict__ x, double* __restrict__ partial,
                                                               int HW, int C, int G, int ppb) {
-    __shared__ float s_sum[64], s_sq[64];   // G <= 64
+    __shared__ float s_part[256][4];         // per thread: sum / sum of squares of its two 4-channel halves
     const int b = blockIdx.y;
     const int c8n = C >> 3;                  // 8-channel slices per pixel
     const int slice = threadIdx.x % c8n, prow = threadIdx.x / c8n, pstep = blockDim.x / c8n;
     const int cpg = C / G;                   // channels per group (4, 8, 16, ...)
-    if (threadIdx.x < 64) { s_sum[threadIdx.x] = 0.f; s_sq[threadIdx.x] = 0.f; }
-    __syncthreads();
     float sum[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};   // halves: channels [0,4) and [4,8) of the slice
     const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
     const T* xb = x + (int64_t)b * HW * C;
@@ -82,25 +84,37 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restric
             sq[k >> 2] += v[k] * v[k];
         }
     }
-#pragma unroll
-    for (int hlf = 0; hlf < 2; ++hlf) {
-        const int g = (slice * 8 + hlf * 4) / cpg;
-        atomicAdd(&s_sum[g], sum[hlf]);
-        atomicAdd(&s_sq[g], sq[hlf]);
-    }
+    s_part[threadIdx.x][0] = sum[0]; s_part[threadIdx.x][1] = sq[0];
+    s_part[threadIdx.x][2] = sum[1]; s_part[threadIdx.x][3] = sq[1];
     __syncthreads();
-    if (threadIdx.x < G) {
-        atomicAdd(&stats[((int64_t)b * G + threadIdx.x) * 2], (double)s_sum[threadIdx.x]);
-        atomicAdd(&stats[((int64_t)b * G + threadIdx.x) * 2 + 1], (double)s_sq[threadIdx.x]);
+    if (threadIdx.x < G) {                   // group g = the 4-channel halves [g*cpg/4, (g+1)*cpg/4) of every pixel row
+        const int g = threadIdx.x, h0 = g * cpg / 4, h1 = (g + 1) * cpg / 4;
+        double ds = 0.0, dq = 0.0;
+        for (int pr = 0; pr < pstep; ++pr)
+            for (int h = h0; h < h1; ++h) {
+                const float* e = s_part[pr * c8n + (h >> 1)] + (h & 1) * 2;
+                ds += (double)e[0];
+                dq += (double)e[1];
+            }
+        double* o = partial + (((int64_t)b * gridDim.x + blockIdx.x) * G + g) * 2;
+        o[0] = ds;
+        o[1] = dq;
     }
 }
 
-// per-(image, group) mean and 1/std in f32 from the f64 sums, once: done per element group inside the apply kernel the f64
-// division (and two f64 loads) per 4 channels made a streaming kernel run at 1.7 TB/s
-__global__ void groupnorm_finalize_kernel(const double* __restrict__ stats, float* __restrict__ mr, int n, double cnt, float eps) {
+// per-(image, group) mean and 1/std in f32 from the blocks' f64 partial sums (added in block order), once: done per element
+// group inside the apply kernel the f64 division (and two f64 loads) per 4 channels slowed a streaming kernel down
+__global__ void groupnorm_finalize_kernel(const double* __restrict__ partial, float* __restrict__ mr, int B, int G, int nchunks,
+                                          double cnt, float eps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double s = stats[2 * i], q = stats[2 * i + 1];
+    if (i >= B * G) return;
+    const int b = i / G, g = i - b * G;
+    double s = 0.0, q = 0.0;
+    for (int c = 0; c < nchunks; ++c) {
+        const double* e = partial + (((int64_t)b * nchunks + c) * G + g) * 2;
+        s += e[0];
+        q += e[1];
+    }
     const double mean = s / cnt;
     const double var = q / cnt - mean * mean;
     mr[2 * i] = (float)mean;
@@ -317,24 +331,26 @@ __global__ void image_postprocess_kernel(const void* __restrict__ y, int y_dt, i
 
 using namespace advgrpo;
 
+// pixels per statistics block: 512, more for very large images so that an image has at most 512 blocks
+static int advgrpo_groupnorm_ppb(int HW) { return HW <= 512 * 512 ? 512 : (HW + 511) / 512; }
+
+extern "C" int64_t advgrpo_groupnorm_scratch_bytes(int B, int HW, int G) {
+    const int ppb = advgrpo_groupnorm_ppb(HW), nchunks = (HW + ppb - 1) / ppb;
+    return ((int64_t)B * nchunks * G * 2 + (int64_t)B * G) * 8;
+}
+
 extern "C" int advgrpo_groupnorm_nhwc(const void* x, void* y, double* stats, const void* weight, const void* bias, int B,
                                       int HW, int C, int G, float eps, int silu, void* stream) {
     ADVGRPO_CHECK(x && y && stats && weight && bias, "groupnorm: null pointer");
     ADVGRPO_CHECK(B > 0 && HW > 0 && C % 8 == 0 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 4 == 0 && 256 % (C / 8) == 0,
                   "groupnorm: unsupported shape C=%d G=%d", C, G);
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(double), s) != hipSuccess) {
-        set_error("groupnorm: memset failed");
-        return -2;
-    }
-    const int ppb = 512;  // pixels per block
-    hipLaunchKernelGGL(groupnorm_stats_kernel<bf16_t>, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, s, (const bf16_t*)x, stats,
-                       HW, C, G, ppb);
+    const int ppb = advgrpo_groupnorm_ppb(HW), nchunks = (HW + ppb - 1) / ppb;
+    hipLaunchKernelGGL(groupnorm_stats_kernel<bf16_t>, dim3(nchunks, B), dim3(256), 0, s, (const bf16_t*)x, stats, HW, C, G, ppb);
     ADVGRPO_LAUNCH_CHECK();
-    // the f64 sums are followed by B*G (mean, 1/std) f32 pairs in the same scratch buffer (stats holds 2*B*G doubles; the
-    // pairs overwrite nothing: they are written behind them -- see the workspace size in the header)
-    float* mr = reinterpret_cast<float*>(stats + (size_t)B * G * 2);
-    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, s, stats, mr, B * G,
+    // scratch layout: [B, nchunks, G, 2] f64 partial sums, then B*G (mean, 1/std) f32 pairs (advgrpo_groupnorm_scratch_bytes)
+    float* mr = reinterpret_cast<float*>(stats + (size_t)B * nchunks * G * 2);
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3((B * G + 63) / 64), dim3(64), 0, s, stats, mr, B, G, nchunks,
                        (double)HW * (C / G), eps);
     ADVGRPO_LAUNCH_CHECK();
     const int64_t total8 = (int64_t)B * HW * (C / 8);
@@ -352,15 +368,11 @@ extern "C" int advgrpo_groupnorm_nhwc_x3(const float* x, void* y3, double* stats
     ADVGRPO_CHECK(B > 0 && HW > 0 && C % 8 == 0 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 4 == 0 && 256 % (C / 8) == 0,
                   "groupnorm_x3: unsupported shape C=%d G=%d", C, G);
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(double), s) != hipSuccess) {
-        set_error("groupnorm_x3: memset failed");
-        return -2;
-    }
-    const int ppb = 512;
-    hipLaunchKernelGGL(groupnorm_stats_kernel<float>, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, s, x, stats, HW, C, G, ppb);
+    const int ppb = advgrpo_groupnorm_ppb(HW), nchunks = (HW + ppb - 1) / ppb;
+    hipLaunchKernelGGL(groupnorm_stats_kernel<float>, dim3(nchunks, B), dim3(256), 0, s, x, stats, HW, C, G, ppb);
     ADVGRPO_LAUNCH_CHECK();
-    float* mr = reinterpret_cast<float*>(stats + (size_t)B * G * 2);
-    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, s, stats, mr, B * G,
+    float* mr = reinterpret_cast<float*>(stats + (size_t)B * nchunks * G * 2);
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3((B * G + 63) / 64), dim3(64), 0, s, stats, mr, B, G, nchunks,
                        (double)HW * (C / G), eps);
     ADVGRPO_LAUNCH_CHECK();
     const int64_t total8 = (int64_t)B * HW * (C / 8);

@@ -305,7 +305,7 @@ def groupnorm_nhwc(x, weight, bias, groups=32, eps=1e-6, silu=False):
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
     y = torch.empty_like(x)
-    stats = torch.empty(B * groups * 3, dtype=torch.float64, device=x.device)
+    stats = torch.empty(lib.advgrpo_groupnorm_scratch_bytes(B, HW, groups) // 8, dtype=torch.float64, device=x.device)
     _lib.check(lib.advgrpo_groupnorm_nhwc(_lib.ptr(x), y.data_ptr(), stats.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), B,
                                           HW, C, groups, float(eps), int(silu), _lib.stream_ptr()))
     return y
@@ -346,7 +346,7 @@ def groupnorm_nhwc_x3(x, weight, bias, groups=32, eps=1e-6, silu=False):
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
     y = torch.empty(*x.shape[:-1], 3 * C, dtype=torch.bfloat16, device=x.device)
-    stats = torch.empty(B * groups * 3, dtype=torch.float64, device=x.device)
+    stats = torch.empty(lib.advgrpo_groupnorm_scratch_bytes(B, HW, groups) // 8, dtype=torch.float64, device=x.device)
     _lib.check(lib.advgrpo_groupnorm_nhwc_x3(x.data_ptr(), y.data_ptr(), stats.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), B,
                                              HW, C, groups, float(eps), int(silu), _lib.stream_ptr()))
     return y

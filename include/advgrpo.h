@@ -198,8 +198,9 @@ int advgrpo_attention_bwd(const void* q, const void* k, const void* v, const voi
 int advgrpo_conv3x3_nhwc(const void* x, const void* w, void* y, int out_dtype, int B, int Hout, int Wout,
                          int Cin, int Cout, int upsample, const void* bias, int act, const void* residual,
                          const void* zero_page, void* stream);
-/* GroupNorm(G) over NHWC [B, HW, C] + affine (+ SiLU): stats scratch of B*G*3 doubles (f64 sums [B, G, 2], then the f32
- * (mean, 1/std) pairs derived from them). */
+/* GroupNorm(G) over NHWC [B, HW, C] + affine (+ SiLU).  `stats`: scratch of advgrpo_groupnorm_scratch_bytes(B, HW, G) bytes
+ * (per-block f64 partial sums, added in a fixed order: the result is bitwise reproducible; then the f32 (mean, 1/std) pairs). */
+int64_t advgrpo_groupnorm_scratch_bytes(int B, int HW, int G);
 int advgrpo_groupnorm_nhwc(const void* x, void* y, double* stats, const void* weight, const void* bias,
                            int B, int HW, int C, int G, float eps, int silu, void* stream);
 /* in-place softmax over rows of a bf16 [rows, n] matrix (n % 8 == 0, n <= 8192). */
@@ -223,7 +224,7 @@ int advgrpo_split_bf16x3(const float* x, const float* bias, void* out, int64_t r
 int advgrpo_conv3x3_nhwc_x3(const void* x3, const void* w3, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
                             int upsample, const float* bias, int act, const float* residual, const void* zero_page,
                             void* stream);
-/* GroupNorm over f32 NHWC [B,HW,C], f32 affine (+ SiLU) -> split output [B,HW,3C]; stats scratch: B*G*3 doubles as above */
+/* GroupNorm over f32 NHWC [B,HW,C], f32 affine (+ SiLU) -> split output [B,HW,3C]; stats scratch as above */
 int advgrpo_groupnorm_nhwc_x3(const float* x, void* y3, double* stats, const float* weight, const float* bias, int B,
                               int HW, int C, int G, float eps, int silu, void* stream);
 /* softmax over f32 rows [rows, n] -> split rows [rows, 3n] (left operand of P.V) */

@@ -305,3 +305,24 @@ def test_checkpoint_resume_restores_state_bit_exactly(tmp_path):
         assert torch.isfinite(m.params).all() and not torch.equal(m.params, before)
         assert (m.params - before).abs().max().item() <= 4 * n_opt * tr_a.cfg.train.learning_rate   # |Adam step| <= (1-b1)/sqrt(1-b2) lr
     assert tr_a.global_step == tr_b.global_step and model_a.opt_step == model_b.opt_step
+
+
+def test_groups_in_flight_do_not_change_the_samples():
+    """sample_epoch with two prompt groups in flight (two HIP streams, two host threads) against one at a time: seeds depend on
+    (config seed, batch index, rank) only and every kernel on the path sums in a fixed order (GroupNorm's statistics used to
+    be accumulated with atomics: two decodes of the same latents then differed by up to 2e-2), so latents, log-probs, images
+    and rewards are bit-identical."""
+    tr_, _, _ = _build("pickscore", train_d=False)
+    tr_.cfg.sample.num_batches_per_epoch = 3
+    tr_.cfg.sample.groups_in_flight = 1
+    a = tr_.sample_epoch()
+    tr_.cfg.sample.groups_in_flight = 2
+    b = tr_.sample_epoch()
+    torch.cuda.synchronize()
+    assert set(a) == set(b) and tr_._rollout_pool._max_workers == 2
+    for k in a:
+        if isinstance(a[k], torch.Tensor):
+            assert torch.equal(a[k], b[k]), k
+        else:
+            assert a[k] == b[k], k
+    assert a["latents"].shape[0] == 3 * tr_.cfg.sample.mini_num_image_per_prompt
