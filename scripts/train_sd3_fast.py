@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--eval", action="store_true", help="run the eval loop every eval_freq epochs (with the co-trained scorer: "
                     "the stand-alone PickScore / image-similarity scorers need real checkpoints)")
     ap.add_argument("--log", default="logs/train.jsonl")
+    ap.add_argument("--groups-in-flight", type=int, default=None,
+                    help="override sample.groups_in_flight (prompt groups rolled out concurrently on separate HIP streams)")
     ap.add_argument("--lora-mode", default="merged", choices=["merged", "side"],
                     help="merged: LoRA folded into the bf16 weights (default); side: PEFT's side-path arithmetic (TP:490-511)")
     ap.add_argument("--vae-mode", default="bf16", choices=["bf16", "bf16x3"],
@@ -49,6 +51,8 @@ def main():
     cfg = parse_config_flag(args.config, gpu_number=world)
     if args.images_per_prompt:
         cfg.sample.num_image_per_prompt = args.images_per_prompt
+    if args.groups_in_flight:
+        cfg.sample.groups_in_flight = args.groups_in_flight
     if args.batches:
         cfg.sample.num_batches_per_epoch = args.batches
         cfg.train.gradient_accumulation_steps = max(1, args.batches // 2)
