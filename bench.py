@@ -346,6 +346,10 @@ def main():
             torch.cuda.synchronize()
             ov_ms = (time.perf_counter() - to) / 4 * 1e3
             overlap = {"groups_in_flight": 2, "ms_per_step": round(ov_ms, 2), "value": round(G / (ov_ms * 1e-3), 3),
+                       "effective_tflops_per_gpu": round(per_image_tflop * G / (ov_ms * 1e-3), 1),
+                       "frac_of_bf16_mfma_peak": round(per_image_tflop * G / (ov_ms * 1e-3) / BF16_DENSE_PEAK_TFLOPS, 4),
+                       "gemm8p_by_events_when_overlapped": "not meaningful: 0.28 of peak by per-launch HIP events, because a launch's "
+                                                           "event interval then includes the other stream's kernels (DESIGN.md 6)",
                        "note": "two independent prompt groups on two HIP streams, one host thread each; same kernels, same results"}
         res = {
             "metric": "sampled+scored images/sec (whole node), SD3.5-large 1024^2 10-step G=4 (secondary line, BASELINE config 4 shapes)"
