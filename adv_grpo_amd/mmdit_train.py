@@ -85,6 +85,8 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
         self.ema_wrapper = EMAModuleWrapper([self.params], decay=0.9, update_step_interval=8, device=dev)
         self.ema = self.ema_wrapper.ema_parameters[0]
         self._base_T = {}
+        self._wgrad_stream = None            # created by backward(): adapter-gradient launches run beside the main chain
+        self.overlap_wgrad = True
         self._prepare_transposes()
         self.refresh()
 
@@ -309,7 +311,20 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
 
     # ------------------------------------------------------------------ LoRA weight gradients of one Linear group
     def _lora_wgrad(self, key, X, x_rows, x_seg, dY, dy_seg):
-        """X: activations (rows via x_seg), dY: [.., n_adapters*D] output gradient (rows via dy_seg)."""
+        """The adapter gradients of one Linear group, on the side stream: they only read (X, dY) and add into the flat gradient
+        vector, so their ~20 small launches per block run beside the data-gradient chain of the next layers instead of in it.
+        X: activations (rows via x_seg), dY: [.., n_adapters*D] output gradient (rows via dy_seg)."""
+        if self._wgrad_stream is None:
+            return self._lora_wgrad_now(key, X, x_rows, x_seg, dY, dy_seg)
+        ready = torch.cuda.Event()
+        ready.record()                                   # X and dY are complete on the calling stream
+        self._wgrad_stream.wait_event(ready)
+        for t in (X, dY):                                # read on the side stream after their Python names are gone
+            t.record_stream(self._wgrad_stream)
+        with torch.cuda.stream(self._wgrad_stream):
+            self._lora_wgrad_now(key, X, x_rows, x_seg, dY, dy_seg)
+
+    def _lora_wgrad_now(self, key, X, x_rows, x_seg, dY, dy_seg):
         A_cat, Bts, ads = self._lora[key]
         D = self.cfg.dim
         M = x_rows
@@ -338,6 +353,12 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
         def mod(key, j):
             o = self.mod_off[key] + j * D
             return mods[:, o:o + D]
+        if self.overlap_wgrad and self._wgrad_stream is None:
+            self._wgrad_stream = torch.cuda.Stream(device=dev)
+        if not self.overlap_wgrad:
+            self._wgrad_stream = None
+        if self._wgrad_stream is not None:               # earlier work on the gradient vector (zeroing, previous micro-step)
+            self._wgrad_stream.wait_stream(torch.cuda.current_stream())
         # final layer: v = unpatchify(LNmod(x) Wp^T + b)
         dtok = self._patch_rows_of_output_grad(dv)                              # [B*Ni, 64]
         dnx = ops.gemm(dtok, w["proj_out.wT"])                                  # [B*Ni, D]
@@ -404,6 +425,8 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                 dc = ops.layernorm_mod_bwd(s["c_in"], dnc, scale0=mod(kc, 0), rows_per_batch=Nt)
             else:
                 dc = ops.layernorm_mod_bwd(s["c_in"], dnc, scale0=mod(kc, 1), dres=dc1, rows_per_batch=Nt)
+        if self._wgrad_stream is not None:               # the gradient vector is complete for whoever reads it next
+            torch.cuda.current_stream().wait_stream(self._wgrad_stream)
         return dx, dc
 
     def _patch_rows_of_output_grad(self, dv):
