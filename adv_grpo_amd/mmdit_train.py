@@ -85,8 +85,10 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
         self.ema_wrapper = EMAModuleWrapper([self.params], decay=0.9, update_step_interval=8, device=dev)
         self.ema = self.ema_wrapper.ema_parameters[0]
         self._base_T = {}
-        self._wgrad_stream = None            # created by backward(): adapter-gradient launches run beside the main chain
+        # adapter-gradient launches run on this stream beside the main chain (one stream for the model: the token-contracted
+        # GEMMs share a workspace, and micro-steps issued from two host threads must not each make their own)
         self.overlap_wgrad = True
+        self._wgrad_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == "cuda" and torch.cuda.is_available() else None
         self._prepare_transposes()
         self.refresh()
 
@@ -314,7 +316,7 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
         """The adapter gradients of one Linear group, on the side stream: they only read (X, dY) and add into the flat gradient
         vector, so their ~20 small launches per block run beside the data-gradient chain of the next layers instead of in it.
         X: activations (rows via x_seg), dY: [.., n_adapters*D] output gradient (rows via dy_seg)."""
-        if self._wgrad_stream is None:
+        if self._wgrad_stream is None or not self.overlap_wgrad:
             return self._lora_wgrad_now(key, X, x_rows, x_seg, dY, dy_seg)
         ready = torch.cuda.Event()
         ready.record()                                   # X and dY are complete on the calling stream
@@ -353,12 +355,9 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
         def mod(key, j):
             o = self.mod_off[key] + j * D
             return mods[:, o:o + D]
-        if self.overlap_wgrad and self._wgrad_stream is None:
-            self._wgrad_stream = torch.cuda.Stream(device=dev)
-        if not self.overlap_wgrad:
-            self._wgrad_stream = None
-        if self._wgrad_stream is not None:               # earlier work on the gradient vector (zeroing, previous micro-step)
-            self._wgrad_stream.wait_stream(torch.cuda.current_stream())
+        side = self._wgrad_stream if self.overlap_wgrad else None
+        if side is not None:                             # earlier work on the gradient vector (zeroing, previous micro-step)
+            side.wait_stream(torch.cuda.current_stream())
         # final layer: v = unpatchify(LNmod(x) Wp^T + b)
         dtok = self._patch_rows_of_output_grad(dv)                              # [B*Ni, 64]
         dnx = ops.gemm(dtok, w["proj_out.wT"])                                  # [B*Ni, D]
@@ -425,8 +424,8 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                 dc = ops.layernorm_mod_bwd(s["c_in"], dnc, scale0=mod(kc, 0), rows_per_batch=Nt)
             else:
                 dc = ops.layernorm_mod_bwd(s["c_in"], dnc, scale0=mod(kc, 1), dres=dc1, rows_per_batch=Nt)
-        if self._wgrad_stream is not None:               # the gradient vector is complete for whoever reads it next
-            torch.cuda.current_stream().wait_stream(self._wgrad_stream)
+        if side is not None:                             # the gradient vector is complete for whoever reads it next
+            torch.cuda.current_stream().wait_stream(side)
         return dx, dc
 
     def _patch_rows_of_output_grad(self, dv):
