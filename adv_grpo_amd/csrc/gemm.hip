@@ -557,6 +557,10 @@ static int gemm_variant(int M, int N, int K, int batch, int conv, int plain) {  
     {   // the 256x256 eight-phase kernel for the wide image-stream Linears (ADVGRPO_GEMM_NO8P=1: the 192x128 tile, A/B runs)
         static int no8p = -1;
         if (no8p < 0) { const char* e = getenv("ADVGRPO_GEMM_NO8P"); no8p = (e && atoi(e)) ? 1 : 0; }
+        static int use4w = -1;      // experiment (gemm4w.hip): 1 = every eligible Linear, 2 = only the short-K ones (K <= 2048)
+        if (use4w < 0) { const char* e = getenv("ADVGRPO_GEMM_4W"); use4w = e ? atoi(e) : 0; }
+        if (plain && M >= 8192 && N >= 1024 && batch == 1 && !no8p && N % 256 == 0 && (use4w == 1 || (use4w == 2 && K <= 2048)))
+            return 31;
         if (plain && M >= 8192 && N >= 1024 && batch == 1 && !no8p) return 30;
     }
     if (plain && M >= 8192 && N >= 1024) return 26;
@@ -622,6 +626,8 @@ int gemm_bf16_pair(const GemmParams& a_in, const GemmParams& b_in, hipStream_t s
     if (pairable && va == 26) return launch_pair<192, 128, 4, 2>(a, b, s);
     if (pairable && va == 27) return launch_pair<128, 192, 2, 4>(a, b, s);
     if (pairable && va == 30) return gemm8p_launch_pair(a, b, s);
+    if (pairable && va == 31 && gemm8p_ok(a) && gemm8p_ok(b) && a.N % 256 == 0 && b.N % 256 == 0 && a.K % 64 == 0 && b.K % 64 == 0)
+        return gemm4w_launch_pair(&a, &b, s);
     const int rc = gemm_bf16(a_in, s);
     return rc ? rc : gemm_bf16(b_in, s);
 }
@@ -647,6 +653,9 @@ int gemm_bf16(const GemmParams& p_in, hipStream_t s) {
         case 27: return launch<128, 192, 2, 4, false>(p, s);
         case 17: return launch_pipe<256, 128, 3, 4, 2>(p, s);
         case 30: return gemm8p_launch(p, s);
+        case 31:
+            if (gemm8p_ok(p) && p.N % 256 == 0 && p.K % 64 == 0) return gemm4w_launch_pair(&p, nullptr, s);
+            return launch<128, 128, 4, 2, false>(p, s);
     }
     set_error("gemm: bad variant %d", variant);
     return -1;
