@@ -542,9 +542,11 @@ int attention_fwd(const AttnParams& p_in, int B, int head_dim, hipStream_t s) {
     ADVGRPO_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0,
                   "attention: row pitches must keep 16-byte (q,k,v) / 8-byte (o) alignment");
     ADVGRPO_CHECK(!p.bias || head_dim == 64, "attention: the score bias is implemented for head dim 64");
-    static int use_glds = -1, xcd_local = -1;
-    if (use_glds < 0) { const char* e = getenv("ADVGRPO_ATTN_REGSTAGE"); use_glds = (e && atoi(e)) ? 0 : 1; }
-    if (xcd_local < 0) { const char* e = getenv("ADVGRPO_ATTN_NO_XCD"); xcd_local = (e && atoi(e)) ? 0 : 1; }   // A/B knob
+    int use_glds = 1, xcd_local = 1;
+#ifdef ADVGRPO_EXPERIMENTS   // A/B knobs of the experiments build only (the product library reads no environment)
+    { const char* e = getenv("ADVGRPO_ATTN_REGSTAGE"); if (e && atoi(e)) use_glds = 0; }
+    { const char* e = getenv("ADVGRPO_ATTN_NO_XCD"); if (e && atoi(e)) xcd_local = 0; }
+#endif
     p.nqb = (p.Sq + ATT_QB - 1) / ATT_QB;
     const int64_t nwg = (int64_t)p.nqb * p.H * B;
     ADVGRPO_CHECK(nwg < (1ll << 31), "attention: grid too large");

@@ -379,8 +379,10 @@ extern "C" int advgrpo_attention_bwd(const void* q, const void* k, const void* v
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)(((int64_t)B * Sq + 3) / 4)), dim3(256), 0, s, p, B);
     ADVGRPO_LAUNCH_CHECK();
-    static int xcd_local = -1;
-    if (xcd_local < 0) { const char* e = getenv("ADVGRPO_ATTN_NO_XCD"); xcd_local = (e && atoi(e)) ? 0 : 1; }
+    int xcd_local = 1;
+#ifdef ADVGRPO_EXPERIMENTS
+    { const char* e = getenv("ADVGRPO_ATTN_NO_XCD"); if (e && atoi(e)) xcd_local = 0; }
+#endif
     p.xcd_local = xcd_local;
     ADVGRPO_CHECK((int64_t)((Sq + 127) / 128) * H * B < (1ll << 31) && (int64_t)((Skv + 127) / 128) * H * B < (1ll << 31),
                   "attention_bwd: grid too large");

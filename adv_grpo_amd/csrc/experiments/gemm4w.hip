@@ -12,7 +12,7 @@
 //   There is no partner wave group inside the workgroup: a wave reads the fragments of the NEXT phase before it issues the
 //   MFMAs of the current one, and the second workgroup of the CU fills what is left.  Hazards: a request into a slot comes
 //   at least one barrier after every wave consumed the item that was there (RAW: counted vmcnt + barrier before the read).
-#include "gemm8p_kernel.hpp"
+#include "../gemm8p_kernel.hpp"
 
 namespace advgrpo {
 

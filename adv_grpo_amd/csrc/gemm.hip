@@ -199,277 +199,9 @@ __global__ __launch_bounds__(WM * WN * 64, (gemm_min_waves_per_simd<BM, BN, WM *
     else gemm_bf16_body<BM, BN, WM, WN, false>(pp.b, bid - pp.tiles_a, 0, smem);
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Deep-pipelined variant for short-K problems (the MMDiT's K = 1536 Linears): BK = 32, a 4-slot LDS ring, LDS-DMA
-// for three tiles kept in flight ACROSS the workgroup barrier (counted s_waitcnt vmcnt + raw s_barrier, guide
-// section 5 "Pipelining across barriers").  The 2-stage kernel above drains the DMA queue before every barrier
-// (hipcc's __syncthreads), which exposes the HBM/L2 latency of each 64-deep tile once per iteration; here a tile
-// is requested three iterations before it is consumed.  Same fragment layout, swizzle idea and epilogue.
-//   LDS tile image: rows of 32 k = 64 B = 4 chunks; one DMA instruction (1 KiB) covers 16 rows; chunk c of row r
-//   sits at slot c ^ ((-(r >> 2)) & 3), which spreads each ds_read_b128 service group over all 16 bank slots.
-template <int BM, int BN, int NS, int WM, int WN>
-__device__ __forceinline__ void gemm_bf16_pipe_body(const GemmParams& p, const int bid, const int by, char* smem) {
-    constexpr int BK = 32, AHEAD = NS - 2;   // tiles kept in flight beyond the one being consumed
-    constexpr int NW = WM * WN;
-    constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INST = BM / 16 / NW, B_INST = BN / 16 / NW;     // 16-row DMA instructions per wave
-    static_assert(A_INST >= 1 && B_INST >= 1, "tile too small for the wave count");
-    constexpr int LOADS = A_INST + B_INST;                        // per wave per tile
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int swz = xcd_remap(bid, tiles_m * tiles_n);
-    int tile_m, tile_n;
-    tile_coords(swz, tiles_m, tiles_n, (p.debug >> 8) ? (p.debug >> 8) : 4, tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int bz = by;
-    const bf16_t* __restrict__ A = p.A + (int64_t)bz * p.strideA;
-    const bf16_t* __restrict__ W = p.W + (int64_t)bz * p.strideW;
-
-    const int lrow = lane >> 2;                           // row inside the 16-row instruction
-    // chunk c of row r sits at slot c ^ h(r), h = (-(r >> 2)) & 3: with ds_read_b128's 16-lane service groups
-    // ({0-3,12-15,20-27}, ...) every group then touches 16 distinct 16-byte bank slots
-    const int schunk = (lane & 3) ^ ((0 - (lrow >> 2)) & 3);
-    const bf16_t* a_src[A_INST];
-    const bf16_t* b_src[B_INST];
-#pragma unroll
-    for (int it = 0; it < A_INST; ++it) {
-        int r = m0 + (wave + it * NW) * 16 + lrow;
-        r = r < p.M ? r : p.M - 1;
-        int64_t ar = r;
-        if (p.a_seg_rows > 0) {
-            const int bi = r / p.a_seg_rows;
-            ar = (int64_t)bi * p.a_seg_stride + p.a_seg_off + (r - bi * p.a_seg_rows);
-        }
-        a_src[it] = A + ar * p.lda + schunk * 8;
-    }
-#pragma unroll
-    for (int it = 0; it < B_INST; ++it) {
-        int r = n0 + (wave + it * NW) * 16 + lrow;
-        r = r < p.N ? r : p.N - 1;
-        b_src[it] = W + (int64_t)r * p.ldw + schunk * 8;
-    }
-    auto stage = [&](int slot, int kt) __attribute__((always_inline)) {
-        char* base = smem + slot * STAGE;
-#pragma unroll
-        for (int it = 0; it < A_INST; ++it)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[it] + kt * BK), (lds_ptr_t)(base + (wave + it * NW) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int it = 0; it < B_INST; ++it)
-            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[it] + kt * BK),
-                                             (lds_ptr_t)(base + A_BYTES + (wave + it * NW) * 1024), 16, 0, 0);
-    };
-    // fragment byte offset inside a tile: row (lane&15) * 64 B + swizzled chunk (lane>>4)
-    const int frow = lane & 15;
-    const int frag_off = frow * 64 + ((((lane >> 4)) ^ ((0 - (frow >> 2)) & 3)) << 4);
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
-    // prologue: NS-1 tiles in flight
-#pragma unroll
-    for (int t = 0; t < NS - 1; ++t)
-        if (t < nk) stage(t, t);
-    int slot = 0;                      // slot of tile kt
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt must have landed: allow the younger tiles (at most AHEAD) to stay in flight
-        const int ahead = min(nk - 1 - kt, AHEAD);
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // the slot of tile kt-1 is free now (every wave passed the barrier after reading it): refill it
-        const int fill = slot == 0 ? NS - 1 : slot - 1;
-        if (kt + NS - 1 < nk) stage(fill, kt + NS - 1);
-        const char* ta = smem + slot * STAGE + wm * TM * 64;
-        const char* tb = smem + slot * STAGE + A_BYTES + wn * TN * 64;
-        slot = slot == NS - 1 ? 0 : slot + 1;
-        bf16x8_t af[FM], bf[FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(ta + i * 1024 + frag_off);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(tb + j * 1024 + frag_off);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    gemm_epilogue<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane, smem, wave);
-}
-
-template <int BM, int BN, int NS, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_pipe_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_bf16_pipe_body<BM, BN, NS, WM, WN>(p, blockIdx.x, blockIdx.y, smem);
-}
-
-template <int BM, int BN, int NS, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_pipe_pair_kernel(const GemmPair pp) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int bid = blockIdx.x;
-    if (bid < pp.tiles_a) gemm_bf16_pipe_body<BM, BN, NS, WM, WN>(pp.a, bid, 0, smem);
-    else gemm_bf16_pipe_body<BM, BN, NS, WM, WN>(pp.b, bid - pp.tiles_a, 0, smem);
-}
-
-template <int BM, int BN, int NS, int WM, int WN>
-static int launch_pipe(const GemmParams& p, hipStream_t s) {
-    constexpr int lds = NS * (BM + BN) * 32 * 2;
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pipe_kernel<BM, BN, NS, WM, WN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, NS, WM, WN>), dim3(tiles, p.batch), dim3(WM * WN * 64), lds, s, p);
-    ADVGRPO_LAUNCH_CHECK();
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Ping-pong variant: 8 waves in two groups of four that run half a phase apart, so that while one group is in its
-// MFMA segment the other is in its LDS-read + DMA-issue segment (one wave of each group per SIMD: the matrix pipe
-// and the LDS/VMEM paths are busy at the same time instead of taking turns behind a common barrier).
-//   * BK = 32 tiles in a 4-slot LDS ring; the DMA for tile t+2 is issued in the load segment of tile t and waited
-//     for (counted s_waitcnt vmcnt) in the segment just before the barrier that precedes its first read, so a
-//     tile has two full compute segments to arrive and every LDS hazard (read-after-DMA, DMA-after-read) is
-//     separated by at least one workgroup barrier -- no placement or timing assumption.
-//   * segment structure per tile and wave:  [ds_read fragments of tile t, issue DMA of tile t+2] s_barrier
-//     [s_waitcnt lgkmcnt(0); MFMAs] s_barrier ; group 1 executes one extra barrier up front (stagger) and group 0
-//     one extra at the end, so both groups arrive at every barrier.
-template <int BM, int BN, int NS, int WM, int WN>
-__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
-    constexpr int BK = 32, NW = 8;
-    static_assert(NS == 3 || NS == 4, "ring depth");
-    static_assert(WM * WN == NW, "eight waves");
-    constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INST = BM / 16 / NW, B_INST = BN / 16 / NW;
-    constexpr int LOADS = A_INST + B_INST;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;                       // waves w and w+4 share a SIMD: one of each group per SIMD
-    const int wm = wave / WN, wn = wave % WN;
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int swz = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    int tile_m, tile_n;
-    tile_coords(swz, tiles_m, tiles_n, (p.debug >> 8) ? (p.debug >> 8) : 4, tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int bz = blockIdx.y;
-    const bf16_t* __restrict__ A = p.A + (int64_t)bz * p.strideA;
-    const bf16_t* __restrict__ W = p.W + (int64_t)bz * p.strideW;
-    const int lrow = lane >> 2;
-    const int schunk = (lane & 3) ^ ((0 - (lrow >> 2)) & 3);
-    const bf16_t* a_src[A_INST];
-    const bf16_t* b_src[B_INST];
-#pragma unroll
-    for (int it = 0; it < A_INST; ++it) {
-        int r = m0 + (wave + it * NW) * 16 + lrow;
-        r = r < p.M ? r : p.M - 1;
-        int64_t ar = r;
-        if (p.a_seg_rows > 0) {
-            const int bi = r / p.a_seg_rows;
-            ar = (int64_t)bi * p.a_seg_stride + p.a_seg_off + (r - bi * p.a_seg_rows);
-        }
-        a_src[it] = A + ar * p.lda + schunk * 8;
-    }
-#pragma unroll
-    for (int it = 0; it < B_INST; ++it) {
-        int r = n0 + (wave + it * NW) * 16 + lrow;
-        r = r < p.N ? r : p.N - 1;
-        b_src[it] = W + (int64_t)r * p.ldw + schunk * 8;
-    }
-    auto stage = [&](int slot, int kt) __attribute__((always_inline)) {
-        char* base = smem + slot * STAGE;
-#pragma unroll
-        for (int it = 0; it < A_INST; ++it)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[it] + kt * BK), (lds_ptr_t)(base + (wave + it * NW) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int it = 0; it < B_INST; ++it)
-            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[it] + kt * BK),
-                                             (lds_ptr_t)(base + A_BYTES + (wave + it * NW) * 1024), 16, 0, 0);
-    };
-    const int frow = lane & 15;
-    const int frag_off = frow * 64 + ((((lane >> 4)) ^ ((0 - (frow >> 2)) & 3)) << 4);
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (p.debug & 8) ? 2 : p.K / BK;
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                     // tile 0 is complete for everybody
-    if (grp == 1) __builtin_amdgcn_s_barrier();       // stagger: group 1 runs one segment behind
-    int slot = 0, slot2 = 2;                          // ring slots of tile kt and tile kt+2
-    for (int kt = 0; kt < nk; ++kt) {
-        // ---- load segment: fragments of tile kt, DMA of tile kt+2
-        const char* ta = smem + slot * STAGE + wm * TM * 64;
-        const char* tb = smem + slot * STAGE + A_BYTES + wn * TN * 64;
-        bf16x8_t af[FM], bf[FN];
-        if (!(p.debug & 2) || kt == 0) {
-#pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(ta + i * 1024 + frag_off);
-#pragma unroll
-            for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(tb + j * 1024 + frag_off);
-        }
-        if (kt + 2 < nk && !(p.debug & 1)) stage(slot2, kt + 2);
-        slot = slot + 1 == NS ? 0 : slot + 1;
-        slot2 = slot2 + 1 == NS ? 0 : slot2 + 1;
-        if (grp == 1) {   // tile kt+1 is first read right after the next barrier (by group 0)
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // with a 3-slot ring group 0 refills the slot of tile kt (= slot of tile kt+3) right after the next
-            // barrier: this group's fragment reads of it must have completed, not just been issued
-            if (NS == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- compute segment
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        if (grp == 0) {
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();       // matches group 1's stagger barrier
-    if (p.debug & 4) { if (acc[0][0][0] != 12345.678f) return; }
-    gemm_epilogue<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, bz, lane, smem, wave);
-}
-
-template <int BM, int BN, int NS, int WM, int WN>
-static int launch_pp(const GemmParams& p, hipStream_t s) {
-    constexpr int lds = NS * (BM + BN) * 32 * 2;
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<BM, BN, NS, WM, WN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, NS, WM, WN>), dim3(tiles, p.batch), dim3(512), lds, s, p);
-    ADVGRPO_LAUNCH_CHECK();
-    return 0;
-}
+#ifdef ADVGRPO_EXPERIMENTS
+#include "experiments/gemm_variants.inc"
+#endif
 
 template <int BM, int BN, int WM, int WN, bool CONV>
 static int launch(const GemmParams& p, hipStream_t s) {
@@ -502,78 +234,53 @@ static int launch_pair(const GemmParams& a, const GemmParams& b, hipStream_t s) 
     return 0;
 }
 
-template <int BM, int BN, int NS, int WM, int WN>
-static int launch_pipe_pair(const GemmParams& a, const GemmParams& b, hipStream_t s) {
-    constexpr int lds = NS * (BM + BN) * 32 * 2;
-    GemmPair pp{a, b, ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN)};
-    const int tiles_b = ((b.M + BM - 1) / BM) * ((b.N + BN - 1) / BN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pipe_pair_kernel<BM, BN, NS, WM, WN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+// ---- tile variants (ids returned by advgrpo_gemm_variant):
+//   two-stage BK=64 kernel: 0 = 128x128 (4 waves), 1 = 128x64, 2 = 64x128, 15 = 128x128 (8 waves 4x2), 26 = 192x128;
+//   conv: 5 = 128x64, 18 = 128x128 (8 waves); 30 = the 256x256 eight-phase persistent kernel of gemm8p.hip.
+//   An experiments build (make EXPERIMENTS=1 -> libadvgrpo_experiments.so, never the product library) adds 14 / 27 (other
+//   wave grids), 4 (conv, 4 waves), 11 / 17 (BK=32 ring kernel), 20 / 21 / 23 (ping-pong kernel), 31 (experiments/gemm4w.hip)
+//   and the ADVGRPO_GEMM_* environment overrides used for in-situ A/B runs; the product library reads no environment.
+#ifdef ADVGRPO_EXPERIMENTS
+struct ExperimentKnobs {
+    int force = -1, no8p = 0, use4w = 0, debug = 0, fn = -1, fk = 0, fv = 0;
+    ExperimentKnobs() {
+        if (const char* e = getenv("ADVGRPO_GEMM_FORCE")) force = atoi(e);
+        if (const char* e = getenv("ADVGRPO_GEMM_NO8P")) no8p = atoi(e) ? 1 : 0;
+        if (const char* e = getenv("ADVGRPO_GEMM_4W")) use4w = atoi(e);
+        if (const char* e = getenv("ADVGRPO_GEMM_DEBUG")) debug = atoi(e);
+        if (const char* e = getenv("ADVGRPO_GEMM_FORCE_NK")) sscanf(e, "%d:%d:%d", &fn, &fk, &fv);
     }
-    hipLaunchKernelGGL((gemm_bf16_pipe_pair_kernel<BM, BN, NS, WM, WN>), dim3(pp.tiles_a + tiles_b), dim3(WM * WN * 64), lds,
-                       s, pp);
-    ADVGRPO_LAUNCH_CHECK();
-    return 0;
-}
+};
+static const ExperimentKnobs& knobs() { static ExperimentKnobs k; return k; }
+#endif
 
-// ---- tile variants (ids as accepted by ADVGRPO_GEMM_FORCE / advgrpo_gemm_variant):
-//   two-stage BK=64 kernel: 0 = 128x128 (4 waves), 1 = 128x64, 2 = 64x128, 14 = 128x128 (8 waves 2x4), 15 = 128x128 (8 waves
-//   4x2), 26 = 192x128, 27 = 128x192 (8 waves 2x4, 48-wide wave tiles); conv: 4 = 128x128 (4 waves), 5 = 128x64, 18 = 128x128
-//   (8 waves); BK=32 ring kernel: 11 = 128x128 (8 waves), 17 = 256x128; ping-pong kernel: 20 = 256x256, 21 / 23 = 256x128
-//   with a 4- / 3-slot ring; 30 = the 256x256 eight-phase persistent kernel of gemm8p.hip.  Variants that lost every comparison (256x256 two-stage, 4-wave ring tiles, ...) were dropped.
-static int g_force_variant = -2;
 static int gemm_variant(int M, int N, int K, int batch, int conv, int plain) {   // batch includes the split-K factor
-    if (g_force_variant == -2) {
-        const char* e = getenv("ADVGRPO_GEMM_FORCE");   // experiments only
-        g_force_variant = e ? atoi(e) : -1;
-    }
-    auto rounds_eff = [&](int bm, int bn, int capacity) {
-        const double tiles = (double)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
-        const double rounds = (double)(int64_t)((tiles + capacity - 1) / capacity);
-        // useful fraction of the launched tile area x fullness of the rounds
-        const double area = (double)M * N * batch / (tiles * bm * bn);
-        return area * tiles / (rounds * capacity);
-    };
     if (N <= 64) return conv ? 5 : 1;
-    if (g_force_variant >= 0) {
-        const int f = g_force_variant;
-        if (conv) return f == 18 ? 18 : 4;
-        return f;
-    }
-    if (g_force_variant == -3) return conv ? 4 : 0;   // (experiments: ADVGRPO_GEMM_FORCE=-3 = always 128x128 2-stage)
-    (void)rounds_eff;
+#ifdef ADVGRPO_EXPERIMENTS
+    if (knobs().force >= 0) return conv ? (knobs().force == 18 ? 18 : 4) : knobs().force;
+    if (knobs().force == -3) return conv ? 4 : 0;
+    if (plain && M >= 8192 && N >= 1024 && batch == 1 && !knobs().no8p && N % 256 == 0 &&
+        (knobs().use4w == 1 || (knobs().use4w == 2 && K <= 2048)))
+        return 31;
+    if (knobs().no8p && plain && M >= 8192 && N >= 1024) return 26;
+#endif
     if (conv) return 18;
     if (M <= 64) return 2;
-    // measured (scripts/bench_gemm.py): 8 waves per workgroup (16 waves per CU) beat 4 on every MMDiT / ViT shape;
-    // image-stream Linears (M = 16384 rows): the 192x128 tile (80 KB of LDS: still two workgroups per CU, 17 % fewer
-    // L2->LDS bytes per flop than 128x128).  Chosen from in-situ runs of the whole rollout step with one shape forced to
-    // each candidate (ADVGRPO_GEMM_FORCE_NK): it beat 128x128, 128x192 and the 256x128 ring kernel on all four shapes
-    // (QKV 891 vs 784-798, FF1 850 vs 704-768, FF2 1004 vs 821-923, out-proj 741 vs 588-648 TFLOP/s on the same box),
-    // although 128x192 is the fastest in the isolated micro-benchmark.
+    // measured (scripts/bench_gemm.py): 8 waves per workgroup (16 waves per CU) beat 4 on every MMDiT / ViT shape.
+    // Wide Linears (M >= 8192 rows, N >= 1024): the 256x256 eight-phase kernel; where its preconditions fail
+    // (gemm8p_ok), the 192x128 two-stage tile (80 KB of LDS: still two workgroups per CU, 17 % fewer L2->LDS bytes per
+    // flop than 128x128), chosen from in-situ runs of the whole rollout step with one shape forced to each candidate.
     (void)K;
-    {   // the 256x256 eight-phase kernel for the wide image-stream Linears (ADVGRPO_GEMM_NO8P=1: the 192x128 tile, A/B runs)
-        static int no8p = -1;
-        if (no8p < 0) { const char* e = getenv("ADVGRPO_GEMM_NO8P"); no8p = (e && atoi(e)) ? 1 : 0; }
-        static int use4w = -1;      // experiment (gemm4w.hip): 1 = every eligible Linear, 2 = only the short-K ones (K <= 2048)
-        if (use4w < 0) { const char* e = getenv("ADVGRPO_GEMM_4W"); use4w = e ? atoi(e) : 0; }
-        if (plain && M >= 8192 && N >= 1024 && batch == 1 && !no8p && N % 256 == 0 && (use4w == 1 || (use4w == 2 && K <= 2048)))
-            return 31;
-        if (plain && M >= 8192 && N >= 1024 && batch == 1 && !no8p) return 30;
-    }
+    if (plain && M >= 8192 && N >= 1024 && batch == 1) return 30;
     if (plain && M >= 8192 && N >= 1024) return 26;
     return plain ? 15 : 0;
 }
 
 // validation shared by the single and the paired launch; returns the tile variant or -1
 static int gemm_prepare(GemmParams& p) {
-    {
-        static int dbg = -1;
-        if (dbg < 0) { const char* e = getenv("ADVGRPO_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
-        p.debug = dbg;
-    }
+#ifdef ADVGRPO_EXPERIMENTS
+    p.debug = knobs().debug;
+#endif
     ADVGRPO_CHECK(p.A && p.W && p.C, "gemm: null operand");
     ADVGRPO_CHECK(p.M > 0 && p.N > 0 && p.K > 0 && p.K % 64 == 0, "gemm: need M,N>0 and K %% 64 == 0 (M=%d N=%d K=%d)",
                   p.M, p.N, p.K);
@@ -586,15 +293,9 @@ static int gemm_prepare(GemmParams& p) {
     ADVGRPO_CHECK(p.act < ACT_DGELU_TANH || p.aux_in, "gemm: d-activation epilogue needs aux_in");
     ADVGRPO_CHECK(!(p.aux_out || p.aux_in) || ((p.ld_aux & 3) == 0 && (p.N & 3) == 0), "gemm: aux needs N, ld_aux %% 4 == 0");
     int variant = gemm_variant(p.M, p.N, p.K, p.batch * p.splitk, p.conv, p.splitk == 1 && !p.conv);
-    {   // experiments: ADVGRPO_GEMM_FORCE_NK=N:K:variant overrides the tile variant of one Linear shape
-        static int fn = -2, fk = 0, fv = 0;
-        if (fn == -2) {
-            const char* e = getenv("ADVGRPO_GEMM_FORCE_NK");
-            fn = -1;
-            if (e) sscanf(e, "%d:%d:%d", &fn, &fk, &fv);
-        }
-        if (fn == p.N && fk == p.K && !p.conv && p.splitk == 1 && p.M >= 8192) variant = fv;
-    }
+#ifdef ADVGRPO_EXPERIMENTS   // ADVGRPO_GEMM_FORCE_NK=N:K:variant overrides the tile variant of one Linear shape
+    if (knobs().fn == p.N && knobs().fk == p.K && !p.conv && p.splitk == 1 && p.M >= 8192) variant = knobs().fv;
+#endif
     if (variant == 30 && !gemm8p_ok(p)) variant = p.M >= 8192 && p.N >= 1024 ? 26 : 15;
     if (p.rms_w && variant == 27) variant = 15;   // the fused QK-norm needs 64-wide wave tiles (one head per wave row)
     if (p.conv) {
@@ -622,12 +323,14 @@ int gemm_bf16_pair(const GemmParams& a_in, const GemmParams& b_in, hipStream_t s
     const bool pairable = a.batch == 1 && b.batch == 1 && a.splitk == 1 && b.splitk == 1 && !a.conv && !b.conv &&
                           !(a.debug & 32);
     if (pairable && va == 15) return launch_pair<128, 128, 4, 2>(a, b, s);
+#ifdef ADVGRPO_EXPERIMENTS
     if (pairable && va == 17) return launch_pipe_pair<256, 128, 3, 4, 2>(a, b, s);
-    if (pairable && va == 26) return launch_pair<192, 128, 4, 2>(a, b, s);
     if (pairable && va == 27) return launch_pair<128, 192, 2, 4>(a, b, s);
-    if (pairable && va == 30) return gemm8p_launch_pair(a, b, s);
     if (pairable && va == 31 && gemm8p_ok(a) && gemm8p_ok(b) && a.N % 256 == 0 && b.N % 256 == 0 && a.K % 64 == 0 && b.K % 64 == 0)
         return gemm4w_launch_pair(&a, &b, s);
+#endif
+    if (pairable && va == 26) return launch_pair<192, 128, 4, 2>(a, b, s);
+    if (pairable && va == 30) return gemm8p_launch_pair(a, b, s);
     const int rc = gemm_bf16(a_in, s);
     return rc ? rc : gemm_bf16(b_in, s);
 }
@@ -640,22 +343,24 @@ int gemm_bf16(const GemmParams& p_in, hipStream_t s) {
         case 0: return launch<128, 128, 2, 2, false>(p, s);
         case 1: return launch<128, 64, 2, 2, false>(p, s);
         case 2: return launch<64, 128, 2, 2, false>(p, s);
-        case 4: return launch<128, 128, 2, 2, true>(p, s);
         case 5: return launch<128, 64, 2, 2, true>(p, s);
+        case 18: return launch<128, 128, 4, 2, true>(p, s);
+        case 15: return launch<128, 128, 4, 2, false>(p, s);
+        case 26: return launch<192, 128, 4, 2, false>(p, s);
+        case 30: return gemm8p_launch(p, s);
+#ifdef ADVGRPO_EXPERIMENTS
+        case 4: return launch<128, 128, 2, 2, true>(p, s);
         case 11: return launch_pipe<128, 128, 3, 4, 2>(p, s);
         case 14: return launch<128, 128, 2, 4, false>(p, s);
-        case 18: return launch<128, 128, 4, 2, true>(p, s);
+        case 17: return launch_pipe<256, 128, 3, 4, 2>(p, s);
         case 20: return launch_pp<256, 256, 4, 2, 4>(p, s);
         case 21: return launch_pp<256, 128, 4, 4, 2>(p, s);
         case 23: return launch_pp<256, 128, 3, 4, 2>(p, s);
-        case 15: return launch<128, 128, 4, 2, false>(p, s);
-        case 26: return launch<192, 128, 4, 2, false>(p, s);
         case 27: return launch<128, 192, 2, 4, false>(p, s);
-        case 17: return launch_pipe<256, 128, 3, 4, 2>(p, s);
-        case 30: return gemm8p_launch(p, s);
         case 31:
             if (gemm8p_ok(p) && p.N % 256 == 0 && p.K % 64 == 0) return gemm4w_launch_pair(&p, nullptr, s);
             return launch<128, 128, 4, 2, false>(p, s);
+#endif
     }
     set_error("gemm: bad variant %d", variant);
     return -1;

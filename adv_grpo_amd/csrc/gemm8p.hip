@@ -128,8 +128,10 @@ int gemm8p_launch_pair(const GemmParams& a, const GemmParams& b, hipStream_t s) 
 
 }  // namespace advgrpo
 
+#ifdef ADVGRPO_EXPERIMENTS
 /* experiment only (not in include/advgrpo.h): copy the s_memtime stamps of the last gemm8p launch to the host */
 extern "C" int advgrpo_dbg_p8_stamps(unsigned long long* host, int count) {
     if (!advgrpo::g_p8_stamps) return -1;
     return hipMemcpy(host, advgrpo::g_p8_stamps, (size_t)count * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
+#endif

@@ -451,12 +451,16 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
     };
 
     // experiment: s_memtime at the tile milestones, wave 0 of every workgroup, 8 stamps per tile
-    int stamp_i = 0;
+    [[maybe_unused]] int stamp_i = 0;
     auto stamp = [&](int k) __attribute__((always_inline)) {
+#ifdef ADVGRPO_EXPERIMENTS
         if (sc.stamps && wave == 0 && stamp_i < 8) {
             const unsigned long long tm = __builtin_readcyclecounter();
             if (p8_lane() == 0) sc.stamps[((size_t)blockIdx.x * 8 + stamp_i) * 8 + k] = tm;
         }
+#else
+        (void)k;
+#endif
     };
     P8Tile t;
     locate(blockIdx.x, t);
@@ -612,6 +616,7 @@ int launch8p(const GemmPair& pp, const P8Sched& sc, hipStream_t s) {
     }
     const int grid = sc.tiles_total < cus ? sc.tiles_total : cus;
     P8Sched sc2 = sc;
+#ifdef ADVGRPO_EXPERIMENTS
     {
         static unsigned long long* stamps = nullptr;
         static int want = -1;
@@ -620,6 +625,7 @@ int launch8p(const GemmPair& pp, const P8Sched& sc, hipStream_t s) {
         if (want) { (void)hipMemsetAsync(stamps, 0, 256 * 8 * 8 * 8, s); g_p8_stamps = stamps; }
         sc2.stamps = want ? stamps : nullptr;
     }
+#endif
     hipLaunchKernelGGL((gemm8p_kernel<true, EPI>), dim3(grid), dim3(512), P8_LDS, s, pp, sc2);   // a single problem is a pair with an empty second half
     ADVGRPO_LAUNCH_CHECK();
     return 0;

@@ -66,8 +66,7 @@ class ClipLastLayerTrainable:
         bf16, f32 = torch.bfloat16, torch.float32
         M = Bt * S
         # ---- frozen part: embeddings, pre-LN, layers[:-1]
-        if Bt not in m._pos_cache:
-            m._pos_cache[Bt] = m.v_pos.repeat(Bt, 1).contiguous()
+        ops.cached(m._pos_cache, Bt, lambda: m.v_pos.repeat(Bt, 1).contiguous())
         x = torch.empty(M, D, dtype=bf16, device=dev)
         ops.gemm(pixel_patches, m.patch_w, out=x, seg=(P, S, 1), residual=m._pos_cache[Bt])
         x.view(Bt, S, D)[:, 0] = m.v_cls

@@ -61,10 +61,12 @@ def pipeline_with_logprob_random(self, prompt=None, prompt_2=None, prompt_3=None
         latents = self.prepare_latents(B, self.transformer.config.in_channels, height, width, dtype, device, seed)
     latents = latents.to(device=device, dtype=dtype)
     timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device)   # PF:574
-    random.seed(process_index)                                                 # PF:585
-    if random_timestep is None:
-        random_timestep = random.randint(0, sample_num_steps // 2)
-    self.last_random_timestep = random_timestep    # host int: scheduler index of the first recorded step (for the G-step)
+    # rollout-local view of the schedule: rollouts of other prompt groups run at the same time on other streams / host
+    # threads (trainer.sample_epoch) and re-install the scheduler's tables; this call keeps the objects it started with
+    sigma_table = self.scheduler.sigmas
+    if random_timestep is None:                                                # PF:585-586: random.seed(process_index); randint
+        random_timestep = random.Random(process_index).randint(0, sample_num_steps // 2)   # same draw, no global reseed
+    self.last_random_timestep = random_timestep    # host int, per calling thread (pipeline.py): first recorded scheduler index
     all_latents, all_log_probs, all_timesteps = [], [], []
     n_per = latents[0].numel()
     # One Philox key per rollout call, disjoint counter ranges per draw: the initial latents use counters [0, ctr), the
@@ -89,7 +91,7 @@ def pipeline_with_logprob_random(self, prompt=None, prompt_2=None, prompt_3=None
         nxt, cast, log_prob, _, _ = sde_step_cfg(                              # PF:640-655 fused
             self.scheduler, vu, vt, guidance_scale, None, latents, cur,
             noise=None if noises is None else noises[i], seed=seed, offset=(1 + i) * ctr,
-            out_dtype=None if want_f32 else dtype, want_mean=False, step_index=i)
+            out_dtype=None if want_f32 else dtype, want_mean=False, step_index=i, sigmas=sigma_table)
         latents = nxt if want_f32 else cast
         if random_timestep <= i < random_timestep + train_num_steps:           # PF:657-660
             all_latents.append(latents)

@@ -26,7 +26,7 @@ def _sigma_tables(scheduler, timestep, B, device):
 
 def sde_step_cfg(scheduler, v_uncond, v_text, guidance_scale, timestep, sample, noise_level=0.7,
                  prev_sample=None, noise=None, seed=None, offset=0, out_dtype=None, want_mean=True,
-                 step_index=None):
+                 step_index=None, sigmas=None):
     """Returns (prev_sample_f32_or_None, prev_sample_cast_or_None, log_prob, prev_sample_mean_or_None, std_dev_t).
 
     v_text=None => no CFG.  Exactly one of prev_sample (replay), noise (injected epsilon) or seed
@@ -36,7 +36,8 @@ def sde_step_cfg(scheduler, v_uncond, v_text, guidance_scale, timestep, sample, 
     n = sample[0].numel()
     dev = sample.device
     if step_index is not None:
-        sig, sigp, stride = scheduler.sigmas[step_index:step_index + 1], scheduler.sigmas[step_index + 1:step_index + 2], 0
+        tab = scheduler.sigmas if sigmas is None else sigmas       # `sigmas`: the caller's rollout-local table
+        sig, sigp, stride = tab[step_index:step_index + 1], tab[step_index + 1:step_index + 2], 0
     else:
         sig, sigp, stride = _sigma_tables(scheduler, timestep, B, dev)
     v_uncond = v_uncond.contiguous()

@@ -52,7 +52,12 @@ class EMAModuleWrapper:
 
     def load_state_dict(self, state_dict):
         self.decay = self.decay if self.decay else state_dict.get("decay", self.decay)
-        self.ema_parameters = [p.to(self.device) if self.device is not None else p for p in state_dict.get("ema_parameters")]
+        loaded = list(state_dict.get("ema_parameters"))
+        if len(loaded) == len(self.ema_parameters) and all(a.shape == b.shape for a, b in zip(loaded, self.ema_parameters)):
+            for e, p in zip(self.ema_parameters, loaded):      # in place: callers alias these tensors (model.ema)
+                e.copy_(p.to(e.device))
+        else:
+            self.ema_parameters = [p.to(self.device) if self.device is not None else p for p in loaded]
 
     def state_dict(self):
         return {"decay": self.decay, "ema_parameters": self.ema_parameters}

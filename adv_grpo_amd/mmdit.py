@@ -108,13 +108,12 @@ class SD3Transformer2DModel:
         return outs
 
     def _pos(self, B, hh, ww):
-        key = (B, hh, ww)
-        if key not in self._pos_cache:
+        def make():
             m = self.cfg.pos_embed_max_size
             top, left = (m - hh) // 2, (m - ww) // 2
             pe = self.pos_embed.reshape(m, m, -1)[top:top + hh, left:left + ww].reshape(hh * ww, -1)
-            self._pos_cache[key] = pe.to(torch.bfloat16).repeat(B, 1).contiguous()
-        return self._pos_cache[key]
+            return pe.to(torch.bfloat16).repeat(B, 1).contiguous()
+        return ops.cached(self._pos_cache, (B, hh, ww), make)
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()

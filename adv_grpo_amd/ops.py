@@ -276,14 +276,24 @@ def unpatchify(tokens, B, C, H, W, out_dtype=torch.bfloat16):
     return out
 
 
+def cached(cache, key, make):
+    """Fill-once device-tensor caches that are read from several HIP streams (rollouts of two prompt groups, the scoring
+    stream): the tensor is built on the first caller's stream and that stream is drained ONCE before the entry is
+    published, so a reader on another stream never sees it half written.  Entries are never evicted."""
+    t = cache.get(key)
+    if t is None:
+        t = make()
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+        cache[key] = t
+    return t
+
+
 _ZERO_PAGE = {}
 
 
 def zero_page(device):
-    key = str(device)
-    if key not in _ZERO_PAGE:
-        _ZERO_PAGE[key] = torch.zeros(256, dtype=torch.bfloat16, device=device)
-    return _ZERO_PAGE[key]
+    return cached(_ZERO_PAGE, str(device), lambda: torch.zeros(256, dtype=torch.bfloat16, device=device))
 
 
 def conv3x3(x, w, bias=None, upsample=False, act=None, residual=None, out_dtype=torch.bfloat16):
@@ -445,18 +455,19 @@ def gemm_tn(P, Q, out, alpha=1.0, M=None, p_seg=None, q_seg=None, transpose_out=
     M = P.shape[0] if M is None else M
     ps = p_seg if p_seg is not None else (0, 0, 0)
     qs = q_seg if q_seg is not None else (0, 0, 0)
-    global _TN_WS
     need = lib.advgrpo_gemm_tn_workspace_bytes(M, P.shape[1])
-    if _TN_WS is None or _TN_WS.numel() < need or _TN_WS.device != P.device:
-        _TN_WS = torch.empty(need, dtype=torch.uint8, device=P.device)      # stream-ordered reuse across calls
+    wkey = (str(P.device), _lib.stream_ptr())         # one workspace per launch stream (the adapter gradients run on a side
+    ws = _TN_WS.get(wkey)                             # stream): allocated, reused and re-grown in that stream's order only
+    if ws is None or ws.numel() < need:
+        ws = _TN_WS[wkey] = torch.empty(need, dtype=torch.uint8, device=P.device)
     _lib.check(lib.advgrpo_gemm_tn_f32acc(P.data_ptr(), P.stride(0), int(ps[0]), int(ps[1]), int(ps[2]), Q.data_ptr(),
                                           Q.stride(0), int(qs[0]), int(qs[1]), int(qs[2]), out.data_ptr(), out.stride(0),
-                                          int(transpose_out), M, P.shape[1], Q.shape[1], float(alpha), _TN_WS.data_ptr(),
+                                          int(transpose_out), M, P.shape[1], Q.shape[1], float(alpha), ws.data_ptr(),
                                           _lib.stream_ptr()))
     return out
 
 
-_TN_WS = None
+_TN_WS = {}
 
 
 def transpose(x, R=None, seg=None, pad_to=64, out=None):

@@ -1,5 +1,7 @@
 """The pipeline object the rollout function takes as ``self`` (what StableDiffusion3Pipeline is to the
 reference, scripts/train_sd3_fast_pickscore.py:447-486): transformer + scheduler + VAE decoder."""
+import threading
+
 import torch
 
 from . import _lib
@@ -16,6 +18,17 @@ class SD3Pipeline:
         self.device = torch.device(device)
         self.scheduler = FlowMatchEulerDiscreteScheduler(device=self.device)
         self._guidance_scale = 1.0
+        self._tls = threading.local()
+
+    @property
+    def last_random_timestep(self):
+        """First recorded scheduler index of the calling thread's latest rollout (prompt groups are rolled out from
+        several host threads at once; each reads back its own draw)."""
+        return getattr(self._tls, "last_random_timestep", None)
+
+    @last_random_timestep.setter
+    def last_random_timestep(self, v):
+        self._tls.last_random_timestep = v
 
     @property
     def _execution_device(self):

@@ -183,10 +183,19 @@ def multi_score(device, score_dict):
             details[name] = scores
             if isinstance(scores, torch.Tensor):
                 weighted = weight * scores            # stays on the device; same arithmetic as the list version
-                total = weighted if isinstance(total, list) and not total else total + weighted
             else:
                 weighted = [weight * s for s in scores]
-                total = weighted if isinstance(total, list) and not total else [a + b for a, b in zip(total, weighted)]
+            if isinstance(total, list) and not total:                               # RW:1086-1087
+                total = weighted
+            elif isinstance(total, torch.Tensor) or isinstance(weighted, torch.Tensor):
+                # RW:1088-1089 adds element by element, so a list-returning scorer (ocr) and a tensor-returning one
+                # (pickscore) mix in either order: python float + f32 element = f32 element
+                ref = total if isinstance(total, torch.Tensor) else weighted
+                a = total if isinstance(total, torch.Tensor) else torch.as_tensor(total, dtype=torch.float64, device=ref.device).to(ref.dtype)
+                b = weighted if isinstance(weighted, torch.Tensor) else torch.as_tensor(weighted, dtype=torch.float64, device=ref.device).to(ref.dtype)
+                total = a + b
+            else:
+                total = [a + b for a, b in zip(total, weighted)]
         details["avg"] = total
         return details, {}
     return _fn

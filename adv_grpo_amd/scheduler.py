@@ -23,6 +23,7 @@ class FlowMatchEulerDiscreteScheduler:
         sig = (np.float32(shift) * sig / (1 + (np.float32(shift) - 1) * sig)).astype(np.float32)
         self.sigma_max = float(sig[0])
         self.sigma_min = float(sig[-1])
+        self._tables = {}          # (n_steps, device) -> (sigmas_host, timesteps_host, sigmas, timesteps): immutable, never freed
         self._install(sig, append_zero=False)
 
     def _install(self, sig, append_zero):
@@ -36,13 +37,24 @@ class FlowMatchEulerDiscreteScheduler:
         self.timesteps = torch.from_numpy(ts.copy()).to(self.device) if self.device else torch.from_numpy(ts.copy())
 
     def set_timesteps(self, num_inference_steps, device=None):
+        """Installs the n-step table.  The device tensors of a given (n, device) are built ONCE and kept for the life of the
+        scheduler: concurrent rollouts (two prompt groups in flight on two streams, trainer.sample_epoch) each re-install the
+        same objects, so no kernel queued on another stream can find its sigma table freed and recycled under it."""
         if device is not None:
             self.device = device
+        key = (int(num_inference_steps), str(self.device))
+        hit = self._tables.get(key)
+        if hit is not None:
+            self._sigmas_host, self._timesteps_host, self.sigmas, self.timesteps = hit
+            return
         t = np.linspace(self.sigma_max * self.num_train_timesteps, self.sigma_min * self.num_train_timesteps,
                         num_inference_steps)
         sig = t / self.num_train_timesteps
         sig = self.shift * sig / (1 + (self.shift - 1) * sig)
         self._install(sig.astype(np.float32), append_zero=True)
+        if self.sigmas.is_cuda:
+            torch.cuda.current_stream(self.sigmas.device).synchronize()     # one-time: the tables are complete before any stream reads them
+        self._tables[key] = (self._sigmas_host, self._timesteps_host, self.sigmas, self.timesteps)
 
     def index_for_timestep(self, timestep):
         t = float(timestep)

@@ -152,8 +152,11 @@ class Trainer:
             if hasattr(pipeline.transformer, "refresh"):
                 pipeline.transformer.ema.copy_(pipeline.transformer.params)
                 pipeline.transformer.refresh()
-            if head is not None and hasattr(head, "p16"):
-                head.p16.copy_(head.params)
+            for obj in (head, self.clip_trainable):            # bf16 shadows / installed weights follow the broadcast masters
+                if obj is not None and hasattr(obj, "p16"):
+                    obj.p16.copy_(obj.params)
+                if obj is not None and hasattr(obj, "sync_model"):
+                    obj.sync_model()
         # reference rewards only feed the PickScore D/G gate and the D-steps (TP:1008-1037, TD:1091-1097)
         self.needs_reference = bool(c.get("train_d", False)) or self.variant == "dino"
         self.async_reward = bool(c.get("async_reward", True))
@@ -277,8 +280,7 @@ class Trainer:
                 s["ref_images"] = ref
             return s, first
 
-        # a rollout that draws its SDE window start at random keeps that draw on the pipeline object: one group at a time
-        in_flight = int(c.sample.get("groups_in_flight", 2)) if c.sample.random_timestep is not None else 1
+        in_flight = int(c.sample.get("groups_in_flight", 2))   # (the random SDE-window draw is per calling thread: pipeline.py)
         in_flight = max(1, min(in_flight, nb))
         t0 = time.perf_counter()
         if in_flight == 1:
@@ -290,11 +292,18 @@ class Trainer:
                 d = torch.device(self.device)
                 self._rollout_dev = d.index if d.index is not None else torch.cuda.current_device()
                 self._rollout_streams = [torch.cuda.Stream(device=self._rollout_dev) for _ in range(in_flight)]
+                import threading
+                self._rollout_tls, self._rollout_lock = threading.local(), threading.Lock()
             main = torch.cuda.current_stream()
 
             def work(i, args, ready):
                 torch.cuda.set_device(self._rollout_dev)
-                st = self._rollout_streams[i % in_flight]
+                # one stream per WORKER THREAD (tasks are taken in completion order: an index-derived stream could be
+                # shared by two running threads)
+                st = getattr(self._rollout_tls, "stream", None)
+                if st is None:
+                    with self._rollout_lock:
+                        st = self._rollout_tls.stream = self._rollout_streams.pop()
                 st.wait_event(ready)                       # the inputs were produced on the caller's stream
                 with torch.cuda.stream(st):
                     s, first = rollout(i, *args)
@@ -323,9 +332,11 @@ class Trainer:
             r, rr, done_ev = s.pop("_future").result()          # re-raises what the scorer raised
             if done_ev is not None:
                 torch.cuda.current_stream().wait_event(done_ev)
-            s["rewards"] = torch.as_tensor(r["avg"], device=self.device).float()
+            # produced on the scoring stream: copied on THIS stream (behind done_ev), so the scoring stream's allocator can
+            # recycle its blocks whenever it likes
+            s["rewards"] = torch.as_tensor(r["avg"], device=self.device).float().clone()
             if rr is not None:
-                s["reference_rewards"] = torch.as_tensor(rr["avg"], device=self.device).float()
+                s["reference_rewards"] = torch.as_tensor(rr["avg"], device=self.device).float().clone()
         self._tick("score", t0)
         samples = {k: torch.cat([s[k] for s in out], dim=0) for k in out[0]}
         samples["first_step_index"] = first_step        # host ints, one per prompt group: no device -> host copy in the G-step
@@ -418,7 +429,7 @@ class Trainer:
         return tensors, scalars
 
     def load_checkpoint(self, path):
-        """Restore a checkpoint written by save_checkpoint.  With the resume file: bit-exact continuation (live LoRA master
+        """Restore a checkpoint written by save_checkpoint.  With the resume file: the state is restored bit-exactly (live LoRA master
         weights, Adam moments and step counts, EMA, discriminator state, epoch / global_step -- the sampler and the noise
         streams are functions of those).  Without it (an adapter written upstream): PeftModel.from_pretrained semantics,
         TP:506-509."""

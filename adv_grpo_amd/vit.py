@@ -97,8 +97,7 @@ class CLIPModel:
         cfg = self.cfg
         P = (cfg.image_size // cfg.patch) ** 2
         S, D = P + 1, cfg.v_hidden
-        if B not in self._pos_cache:
-            self._pos_cache[B] = self.v_pos.repeat(B, 1).contiguous()
+        ops.cached(self._pos_cache, B, lambda: self.v_pos.repeat(B, 1).contiguous())
         x = torch.empty(B * S, D, dtype=torch.bfloat16, device=patches.device)
         ops.gemm(patches, self.patch_w, out=x, seg=(P, S, 1), residual=self._pos_cache[B])
         x.view(B, S, D)[:, 0] = self.v_cls
@@ -168,8 +167,7 @@ class DinoV2:
         P = (cfg.image_size // cfg.patch) ** 2
         B = pixel_patches.shape[0] // P
         S, D = P + 1, cfg.hidden
-        if B not in self._pos_cache:
-            self._pos_cache[B] = self.pos.repeat(B, 1).contiguous()
+        ops.cached(self._pos_cache, B, lambda: self.pos.repeat(B, 1).contiguous())
         x = torch.empty(B * S, D, dtype=torch.bfloat16, device=pixel_patches.device)
         ops.gemm(pixel_patches, self.patch_w, bias=self.patch_b, out=x, seg=(P, S, 1), residual=self._pos_cache[B])
         x.view(B, S, D)[:, 0] = self.cls

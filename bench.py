@@ -36,8 +36,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-epoch", action="store_true", help="skip the untimed-for-the-metric full-epoch leg")
-    ap.add_argument("--epoch", action="store_true", help="run the full-epoch leg for N > 1 too (adds the LoRA-gradient all-reduce "
-                                                         "of the G-step to what the scaling curve exercises)")
+    ap.add_argument("--epoch", action="store_true", help="(kept for compatibility: the full-epoch leg, with the LoRA-gradient "
+                                                         "all-reduce of the G-step, now runs by default at every N)")
+    ap.add_argument("--spawn", action="store_true", help="take the self-spawn path (torch.distributed.run, RCCL process group) at N = 1 "
+                                                         "as well: exercises the launcher on a one-GPU box")
     ap.add_argument("--config", default="c2", choices=["c2", "c4"],
                     help="c2 = the headline (BASELINE config 2); c4 = secondary line, SD3.5-large 1024^2 G=4 (BASELINE config 4 shapes)")
     ap.add_argument("--no-pricing", action="store_true",
@@ -123,9 +125,16 @@ def full_epoch(device, world=1, rank=0):
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
+    phases = dict(trainer.timers)
+    if world > 1:                              # slowest rank per phase (every rank walks the phases in the same order)
+        keys = sorted(phases)
+        pm = torch.tensor([phases[k] for k in keys], dtype=torch.float64, device=device)
+        dist.all_reduce(pm, op=dist.ReduceOp.MAX)
+        phases = dict(zip(keys, pm.tolist()))
     images = world * cfg.sample.num_batches_per_epoch * cfg.sample.mini_num_image_per_prompt
     return {"images": images, "seconds": round(dt, 3), "images_per_s_full_epoch": round(images / dt, 3),
-            "phases_s": {k: round(v, 4) for k, v in trainer.timers.items()},
+            "phases_s": {k: round(v, 4) for k, v in phases.items()}, "phases_are": "max over ranks" if world > 1 else "rank 0",
+            "exchanges": "reward all-gather once per epoch; all-reduce of the flat LoRA gradient before each optimizer step (TP:1165)",
             "note": "sample = rollout + VAE decode; score = PickScore of generated AND reference images; g_step = "
                     "2 groups x 2 SDE timesteps fwd+bwd at CFG batch 16 + 2 clip+AdamW steps + EMA (+ for N > 1 the all-reduce of "
                     "the 37.6 MB flat LoRA gradient before each optimizer step); reward scoring runs on the worker stream and "
@@ -190,11 +199,38 @@ def cpu_baseline():
                                      "pickscore": round(t_clip, 3)}}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_command(argv, gpus, port=None, script=None):
+    """The launch line of scripts/grpo_pickscore.sh:7-11 (one process per GPU of one node), for a plain
+    `python bench.py --gpus N` started without a launcher: the same script re-executed under torch.distributed.run."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), script or os.path.abspath(__file__)] + list(argv)
+
+
+def self_spawn(args):
+    """--gpus N > 1 without WORLD_SIZE in the environment: start the N ranks ourselves and pass rank 0's JSON line on."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus))))
+    raise SystemExit(subprocess.run(spawn_command(sys.argv[1:], args.gpus), env=env).returncode)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()))
         return
+    if (args.gpus > 1 or args.spawn) and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -203,11 +239,18 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.spawn:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)      # RCCL over xGMI
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    ranks_seen = 1
+    if dist is not None:                                       # RCCL sanity: every rank contributes a one
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        assert ranks_seen == world, f"all-reduce of ones saw {ranks_seen} ranks, expected {world}"
 
     from adv_grpo_amd import distributed as D
     from adv_grpo_amd import ops, stat_tracking, synthetic, vit
@@ -354,7 +397,7 @@ def main():
         res = {
             "metric": "sampled+scored images/sec (whole node), SD3.5-large 1024^2 10-step G=4 (secondary line, BASELINE config 4 shapes)"
             if c4 else "sampled+scored images/sec (whole node), SD3-med 512^2 10-step G=8 GRPO",
-            "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("BASELINE config 4 shapes: SD3.5-large (38 blocks, D=2432) LoRA-merged 1024x1024, 10 steps, CFG 4.5, "
@@ -385,7 +428,7 @@ def main():
                      "ms_per_step": lora_ms,
                      "value_if_side": round(world * G / (lora_ms["side"] * 1e-3), 3) if "side" in lora_ms else None},
         }
-    run_epoch = not c4 and not args.no_epoch and (world == 1 or args.epoch)
+    run_epoch = not c4 and not args.no_epoch       # at every N: for N > 1 this is the leg with the LoRA-gradient all-reduce (TP:1165)
     if run_epoch:                                   # every rank takes part (LoRA-gradient all-reduce, reward gather)
         del pipe, clip
         torch.cuda.empty_cache()

@@ -28,7 +28,9 @@ if len(sys.argv) > 1:
     torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[1])
     sys.exit(0)
 torch.save({k: v.cpu() for k, v in out.items()}, "/tmp/gemm_ref.pt")
-env = dict(os.environ, ADVGRPO_GEMM_FORCE="31")
+exp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adv_grpo_amd", "libadvgrpo_experiments.so")
+assert os.path.exists(exp), "build the experiments library first: make -C adv_grpo_amd/csrc EXPERIMENTS=1"
+env = dict(os.environ, ADVGRPO_GEMM_FORCE="31", ADVGRPO_LIB=exp)
 subprocess.check_call([sys.executable, os.path.abspath(__file__), "/tmp/gemm_4w.pt"], env=env)
 a, b = torch.load("/tmp/gemm_ref.pt"), torch.load("/tmp/gemm_4w.pt")
 ok = True

@@ -326,3 +326,17 @@ def test_groups_in_flight_do_not_change_the_samples():
         else:
             assert a[k] == b[k], k
     assert a["latents"].shape[0] == 3 * tr_.cfg.sample.mini_num_image_per_prompt
+
+
+def test_bench_self_spawn_path_at_world_1():
+    """`bench.py --spawn` takes the launcher path a plain `python bench.py --gpus N` takes for N > 1 (re-exec under
+    torch.distributed.run, RCCL process group, all-reduce of ones) on this one-GPU box."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--spawn", "--steps", "1", "--warmup", "1",
+                        "--no-epoch", "--no-cpu-baseline", "--no-pricing"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["value"] > 0
