@@ -21,27 +21,10 @@
 //     softmax rescale is a per-lane scalar and the epilogue is an 8-byte bf16x4 store per lane.
 #include <stdlib.h>
 
-#include "common.hpp"
-#include "gemm.hpp"
+#include "attention.hpp"
 
 namespace advgrpo {
 
-struct AttnParams {
-    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
-    int64_t ldq, ldk, ldv, ldo;   // row pitch (elements)
-    int64_t bsq, bsk, bsv, bso;   // batch pitch (elements)
-    int H, Sq, Skv;
-    float scale_log2e;            // softmax scale * log2(e)
-    int causal;
-    float* lse;                   // optional [B,H,Sq]: base-2 log-sum-exp of the scaled scores (for backward)
-    const float* bias;            // optional additive score bias [H,Sq,Skv] f32 (T5 relative position bias), head dim 64 only
-    int nqb, nwg, xcd_local;      // query blocks per (b,h); workgroups in the 1-D grid; XCD-local block order (common.hpp)
-};
-
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-
-constexpr int ATT_QB = 128;   // queries per workgroup
-constexpr int ATT_KB = 64;    // keys per tile
 
 // HD = 64 (MMDiT, DINOv2, CLIP text) or 80 (CLIP ViT-H vision: 1280 / 16 heads).  For HD = 80 the
 // QK^T contraction is padded to 96 with zero columns in LDS (K) and zero Q fragments.
@@ -263,32 +246,6 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
 //   K (ds_read_b128 fragments): 16-byte chunk c of row r sits at slot c ^ (r & 7)       (as in gemm.hip)
 //   V (ds_read_b64_tr_b16):     32-byte segment s of row r sits at slot s ^ ((r >> 1) & 3): the 8 rows a 32-lane
 //                               service group touches land on 8 disjoint 8-bank ranges.
-// xor-16 / xor-32 lane exchanges on the VALU (gfx950 v_permlane{16,32}_swap) instead of ds_bpermute: the softmax
-// row maximum no longer takes two LDS round trips per tile, nor shares lgkmcnt with the V fragment reads.
-// v_permlane32_swap d, s: d[32..63] <-> s[0..31]; with d = s = v the pair (d, s) afterwards holds, in every lane,
-// the lane's value and its xor-32 partner's (16: odd 16-lane rows of d <-> even rows of s).
-// (inline asm with two read-write operands: given the same value twice the builtin form is folded onto ONE
-// register and returns the swap of a register with itself -- checked with scripts/probes/permlane_probe.hip)
-#define ADVGRPO_SWAP16(a, b) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b))
-#define ADVGRPO_SWAP32(a, b) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b))
-__device__ __forceinline__ float xor16_max(float v) { float a = v, b = v; ADVGRPO_SWAP16(a, b); return fmaxf(a, b); }
-__device__ __forceinline__ float xor32_max(float v) { float a = v, b = v; ADVGRPO_SWAP32(a, b); return fmaxf(a, b); }
-__device__ __forceinline__ float xor16_add(float v) { float a = v, b = v; ADVGRPO_SWAP16(a, b); return a + b; }
-__device__ __forceinline__ float xor32_add(float v) { float a = v, b = v; ADVGRPO_SWAP32(a, b); return a + b; }
-
-typedef __attribute__((address_space(3))) void* att_lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* att_gptr_t;
-
-// One LDS-DMA instruction (64 lanes x 16 bytes -> LDS [lds, lds + 1 KiB)), hand-written: issued through the builtin the
-// compiler treats the DMA as a possible alias of every later ds_read and puts s_waitcnt vmcnt(0) in front of the first K
-// fragment read of the SAME iteration -- i.e. each wave waited for the tile it had just requested two iterations ahead,
-// and the three-slot ring hid nothing inside a wave.  The ring's hazards are covered by the counted wait + barrier at the
-// top of the loop (RAW) and by that same barrier coming after every read of the slot being refilled (WAR).
-__device__ __forceinline__ void att_dma16(const void* src, const char* lds) {
-    const uint32_t l = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)(lds));
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory");
-}
-
 #ifndef ATT_NS
 #define ATT_NS 3
 #define ATT_WGS 3
@@ -542,10 +499,11 @@ int attention_fwd(const AttnParams& p_in, int B, int head_dim, hipStream_t s) {
     ADVGRPO_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0,
                   "attention: row pitches must keep 16-byte (q,k,v) / 8-byte (o) alignment");
     ADVGRPO_CHECK(!p.bias || head_dim == 64, "attention: the score bias is implemented for head dim 64");
-    int use_glds = 1, xcd_local = 1;
+    int use_glds = 1, xcd_local = 1, use_pipe = 1;
 #ifdef ADVGRPO_EXPERIMENTS   // A/B knobs of the experiments build only (the product library reads no environment)
     { const char* e = getenv("ADVGRPO_ATTN_REGSTAGE"); if (e && atoi(e)) use_glds = 0; }
     { const char* e = getenv("ADVGRPO_ATTN_NO_XCD"); if (e && atoi(e)) xcd_local = 0; }
+    { const char* e = getenv("ADVGRPO_ATTN_NO_PIPE"); if (e && atoi(e)) use_pipe = 0; }
 #endif
     p.nqb = (p.Sq + ATT_QB - 1) / ATT_QB;
     const int64_t nwg = (int64_t)p.nqb * p.H * B;
@@ -555,6 +513,8 @@ int attention_fwd(const AttnParams& p_in, int B, int head_dim, hipStream_t s) {
     dim3 grid((unsigned)nwg);
     const bool o16 = p.ldo % 8 == 0 && p.bso % 8 == 0 && (reinterpret_cast<uintptr_t>(p.o) & 15) == 0;   // 16-byte row stores
     ADVGRPO_CHECK(!p.bias || (use_glds && o16), "attention: the score bias needs the LDS-DMA kernel (16-byte aligned output rows)");
+    // plain head-dim-64 attention (MMDiT joint / second attention, DINOv2): the software-pipelined kernel of attention_pipe.hip
+    if (head_dim == 64 && use_glds && o16 && !p.bias && !p.causal && use_pipe) return attention_fwd_pipe_launch(p, s);
     if (head_dim == 64 && use_glds && o16 && p.bias) hipLaunchKernelGGL(attention_fwd_glds_kernel<true>, grid, dim3(256), 0, s, p);
     else if (head_dim == 64 && use_glds && o16) hipLaunchKernelGGL(attention_fwd_glds_kernel<false>, grid, dim3(256), 0, s, p);
     else if (head_dim == 64) hipLaunchKernelGGL(attention_fwd_kernel<64>, grid, dim3(256), 0, s, p);

@@ -81,3 +81,29 @@ def test_attention_backward_matches_autograd(B, H, Sq, Skv):
     for name, got, want in (("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
         rel = ((got.float() - want).norm() / want.norm()).item()
         assert rel < 2e-2, (name, rel)
+
+
+@pytest.mark.parametrize("where", ["late", "early"])
+def test_attention_scores_far_outside_the_first_tiles_window(where):
+    """The pipelined head-dim-64 kernel takes every probability relative to the row maximum of the FIRST 64 keys and never
+    rescales on the way; a row sum that over- or underflows sends the workgroup through its running-maximum fallback.  Keys
+    scaled by 200 put logits hundreds of octaves above (late) or the first tile hundreds above the rest (early)."""
+    from adv_grpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, H, S, D = 1, 2, 640, 64
+    q = torch.randn(B, S, H * D, device="cuda", generator=g)
+    k = torch.randn(B, S, H * D, device="cuda", generator=g)
+    v = torch.randn(B, S, H * D, device="cuda", generator=g)
+    if where == "late":
+        k[:, 400:, :] *= 200.0
+    else:
+        k[:, :64, :] *= 200.0
+    q, k, v = (x.to(torch.bfloat16) for x in (q, k, v))
+    lse = torch.empty(B, H, S, dtype=torch.float32, device="cuda")
+    out = ops.attention(q, k, v, H, lse=lse)
+    ref = _ref(q, k, v, H)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    assert (out.float() - ref).abs().max().item() < 3e-2
+    sc = (q.float().view(B, S, H, D).transpose(1, 2) @ k.float().view(B, S, H, D).transpose(1, 2).transpose(-1, -2)) * D ** -0.5
+    want = torch.logsumexp(sc, -1) * 1.4426950408889634
+    assert ((lse - want).abs() / want.abs().clamp_min(1.0)).max().item() < 1e-3
