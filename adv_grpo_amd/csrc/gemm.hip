@@ -469,5 +469,8 @@ extern "C" int advgrpo_conv3x3_nhwc_x3(const void* x3, const void* w3, float* y,
     p.splitk = 1;
     p.f32_io = 1;
     ADVGRPO_CHECK(Cin3 % 192 == 0, "conv3x3_x3: Cin3 must be 3 x (a multiple of 64) (Cin3=%d)", Cin3);
+    // wide outputs: the dedicated kernel (conv_x3.hip: the four hi / lo pieces staged once per 64 channels, three MFMA
+    // products from them); the 3-channel conv_out keeps the 128x64 tile of the tripled-K path
+    if (Cout >= 128) return conv3x3_x3_launch(p, as_stream(stream));
     return gemm_bf16(p, as_stream(stream));
 }

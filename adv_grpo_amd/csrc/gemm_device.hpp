@@ -376,6 +376,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // instead of as a second, badly filled launch (M = 16 x 205 rows against 256 CUs x 2 workgroups).
 struct GemmPair { GemmParams a, b; int tiles_a; };
 
+// split-bf16 3x3 convolution of the fp32-equivalent VAE decode (conv_x3.hip)
+int conv3x3_x3_launch(const GemmParams& p, hipStream_t s);
+
 // 256x256 eight-phase kernel (gemm8p.hip)
 bool gemm8p_ok(const GemmParams& p);
 int gemm8p_launch(const GemmParams& p, hipStream_t s);

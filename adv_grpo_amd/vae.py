@@ -10,11 +10,13 @@ gather, residual adds and biases into the convolution epilogue.
 DEVIATION from the reference: it runs the VAE in fp32 (train_sd3_fast_pickscore.py:481); fp32 matrix
 math on MI355X is 1/16 of the bf16 MFMA rate (no TF32 on gfx950), which would make decode as long as the
 whole rollout.  Two modes:
-  mode="bf16"    (default) bf16 operands and activations, f32 accumulation, f32/f64 GroupNorm statistics.
-  mode="bf16x3"  split-bf16: every f32 operand is carried as hi + lo bf16 halves and each product runs as
-                 xh*wh + xh*wl + xl*wh on the bf16 MFMA (3x the flops, ~2^-16 relative error per product);
-                 everything between two matrix products -- bias, residual adds, GroupNorm / softmax inputs --
-                 stays f32.  This is the fp32-equivalent decode; bench.py prices it next to the default.
+  mode="bf16x3"  (default: the reference's arithmetic) split-bf16: every f32 operand is carried as hi + lo bf16 halves
+                 and each product runs as xh*wh + xh*wl + xl*wh on the bf16 MFMA (3x the flops, ~2^-16 relative error
+                 per product; csrc/conv_x3.hip stages the four pieces once per 64 channels); everything between two
+                 matrix products -- bias, residual adds, GroupNorm / softmax inputs -- stays f32.  Image within 3e-5 of
+                 the fp32 decode.
+  mode="bf16"    the fast opt-in: bf16 operands and activations, f32 accumulation, f32/f64 GroupNorm statistics (2.6x
+                 faster, image within 2.3e-2); bench.py prices it next to the default.
 Measured tolerances of both in tests/test_gpu_vae.py.
 """
 import torch
@@ -23,7 +25,7 @@ from . import ops
 
 
 class AutoencoderKLDecoder:
-    def __init__(self, state_dict, cfg, device="cuda", mode="bf16"):
+    def __init__(self, state_dict, cfg, device="cuda", mode="bf16x3"):
         if mode not in ("bf16", "bf16x3"):
             raise ValueError(f"AutoencoderKLDecoder: mode must be 'bf16' or 'bf16x3', got {mode!r}")
         self.mode = mode

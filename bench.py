@@ -45,13 +45,13 @@ def parse():
     ap.add_argument("--no-pricing", action="store_true",
                     help="skip the untimed legs that price the alternative modes (split-bf16 VAE, LoRA side path): profiling runs, "
                          "so that the rocprof summary holds the timed configuration only")
-    ap.add_argument("--vae-mode", default="bf16", choices=["bf16", "bf16x3"],
-                    help="decoder arithmetic inside the timed step: bf16 (default) or the fp32-equivalent split-bf16 mode; the "
-                         "'vae' object of the JSON line prices both either way")
+    ap.add_argument("--vae-mode", default="bf16x3", choices=["bf16", "bf16x3"],
+                    help="decoder arithmetic inside the timed step: the fp32-equivalent split-bf16 mode (default: the reference "
+                         "decodes in fp32, TP:481) or plain bf16; the 'vae' object of the JSON line prices both either way")
     return ap.parse_args()
 
 
-def build(device, large=False, vae_mode="bf16"):
+def build(device, large=False, vae_mode="bf16x3"):
     from adv_grpo_amd import synthetic, vit
     from adv_grpo_amd.mmdit import SD3Transformer2DModel
     from adv_grpo_amd.pipeline import SD3Pipeline
@@ -404,7 +404,7 @@ def main():
                                     "G=4, SDE window 2 @ noise 0.8, VAE decode, PickScore reward (the OCR half of the reward is a "
                                     "host plugin outside the timed path), reward all-gather + group advantage") if c4 else
                                    ("BASELINE config 2: SD3.5-medium LoRA-merged 512x512, 10 steps, CFG 4.5, G=8, "
-                                    "SDE window 2 @ noise 0.8, VAE decode, PickScore (CLIP ViT-H/14) reward, "
+                                    "SDE window 2 @ noise 0.8, VAE decode (" + pipe.vae.mode + "), PickScore (CLIP ViT-H/14) reward, "
                                     "reward all-gather + group advantage"), "global_batch": world * G,
                        "transformer_batch_per_gpu": 2 * G, "parallelism": f"dp{world} (prompt groups sharded)"},
             "effective_tflops_per_gpu": round(per_image_tflop * images / dt / world, 1),
@@ -418,7 +418,9 @@ def main():
                     "share_of_step_time": round(vae_ms[pipe.vae.mode] / step_ms, 4),
                     # what the headline would be with the other decoder swapped in (only the decode time changes)
                     "value_if_bf16x3": round(images / (dt + args.steps * (vae_ms["bf16x3"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)
-                    if "bf16x3" in vae_ms else None},
+                    if "bf16x3" in vae_ms else None,
+                    "value_if_bf16": round(images / (dt + args.steps * (vae_ms["bf16"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)
+                    if "bf16" in vae_ms else None},
             "overlap": overlap,
             "lora": {"mode": "merged",
                      "modes": {"merged": "W_eff = bf16(W + s B A) in the rollout and training forward (the timed configuration)",

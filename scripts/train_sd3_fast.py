@@ -30,7 +30,7 @@ def main():
                     help="override sample.groups_in_flight (prompt groups rolled out concurrently on separate HIP streams)")
     ap.add_argument("--lora-mode", default="merged", choices=["merged", "side"],
                     help="merged: LoRA folded into the bf16 weights (default); side: PEFT's side-path arithmetic (TP:490-511)")
-    ap.add_argument("--vae-mode", default="bf16", choices=["bf16", "bf16x3"],
+    ap.add_argument("--vae-mode", default="bf16x3", choices=["bf16", "bf16x3"],
                     help="decoder arithmetic: bf16 (default) or the fp32-equivalent split-bf16 mode (the reference decodes in fp32, TP:481)")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))

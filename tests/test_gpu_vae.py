@@ -60,7 +60,7 @@ def test_vae_decode_vs_fp32_oracle(B, hw):
     Wb = {k: v.to(torch.bfloat16) for k, v in W.items()}
     g = torch.Generator().manual_seed(hw)
     lat = torch.randn(B, 16, hw, hw, generator=g).to(torch.bfloat16)
-    dec = AutoencoderKLDecoder(Wb, cfg, "cuda")
+    dec = AutoencoderKLDecoder(Wb, cfg, "cuda", mode="bf16")
     img = dec.decode_to_image(lat.cuda())
     W32 = {k: v.float().cuda() for k, v in Wb.items()}
     z = lat.float().cuda() / cfg.scaling_factor + cfg.shift_factor
@@ -172,7 +172,7 @@ def test_bf16_vae_decode_reward_deltas_vs_fp32_decode_at_config2():
     g = torch.Generator().manual_seed(8)
     # a group of 8 related samples, as a rollout produces them: a shared component plus per-sample variation
     lat = (0.8 * torch.randn(1, 16, 64, 64, generator=g) + 0.6 * torch.randn(8, 16, 64, 64, generator=g)).to(torch.bfloat16)
-    img_b = AutoencoderKLDecoder(Wb, cfg, "cuda").decode_to_image(lat.cuda())
+    img_b = AutoencoderKLDecoder(Wb, cfg, "cuda", mode="bf16").decode_to_image(lat.cuda())
     img_x = AutoencoderKLDecoder({k: v.float() for k, v in Wb.items()}, cfg, "cuda", mode="bf16x3").decode_to_image(lat.cuda())
     W32 = {k: v.float().cuda() for k, v in Wb.items()}
     with torch.no_grad():
