@@ -36,7 +36,7 @@
 #include "attention.hpp"
 
 // timing-only ablations (scripts/ablate_attention.sh; results are WRONG with any bit set): 1 = no wait + barrier, 2 = v_exp ->
-// v_mul, 4 = no LDS fragment reads in the slots, 8 = no DMA, 16 = (unused), 32 = clock probe into lse[0..1], 64 = no row sums
+// v_mul, 4 = no LDS fragment reads in the slots, 8 = no DMA, 16 = (unused), 32 = clock probe into lse[0..1], 64 = no row sums, 128 = never take the fallback
 #ifndef ATT_ABL
 #define ATT_ABL 0
 #endif
@@ -47,11 +47,9 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float att_max3(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// (through the compiler, which fuses the pair into v_max3_f32: as an asm statement its reads of the score accumulators were
+// not padded against the MFMAs that had just written them, and the reference maximum came out of half-written registers)
+__device__ __forceinline__ float att_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 // two f32 -> packed bf16 (v_cvt_pk_bf16_f32).  Through the compiler, NOT inline asm: the packed probabilities are written
 // into registers that MFMAs issued a slot earlier may still be reading as their B operand, and the hazard recogniser only
 // pads instructions it knows (an asm statement here produced wrong probabilities for half of the query lanes).
@@ -79,6 +77,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 __global__ __launch_bounds__(256, 2) void attention_fwd_pipe_kernel(const AttnParams p) {
     constexpr int HD = 64, TILE_B = ATT_KB * 128;             // 8 KiB per K or V tile
     __shared__ __attribute__((aligned(1024))) char smem[6 * TILE_B];
+    __shared__ int wg_flag[4];
     char* const Kr = smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -384,7 +383,13 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_pipe_kernel(const AttnPa
     float l = xor32_add((lsum[0][0] + lsum[0][1]) + (lsum[1][0] + lsum[1][1]));       // both key halves of the query
     {
         const bool bad = !(l > 1e-30f && l < 1e30f);
-        if (__syncthreads_or(bad)) {
+        // workgroup-wide OR through four LDS words (__syncthreads_or came back non-zero at random here: workgroups then took the
+        // fallback, whose rounding differs in the last bit, and two launches on the same data were not bitwise equal)
+        const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+        if (lane == 0) wg_flag[wave] = wave_bad ? 1 : 0;
+        __syncthreads();
+        const int any_bad = wg_flag[0] | wg_flag[1] | wg_flag[2] | wg_flag[3];
+        if ((ATT_ABL & 128) == 0 && any_bad) {
             asm volatile("; fallback: running maximum per tile" ::: "memory");
             o[0] = zero16; o[1] = zero16;
             float m_run = -INFINITY, l_run = 0.f;

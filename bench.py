@@ -67,12 +67,14 @@ def build(device, large=False, vae_mode="bf16x3"):
     return SD3Pipeline(tr, vae, device), clip
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate runs of this same command, scripts/pmc_traffic.py: (2*FETCH_SIZE + WRITE_SIZE)*1024, the factor 2 being
-    the gfx950 correction of MI355X_MICROARCH.md)."""
+def pmc_traffic(kernel, config="c2"):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes OF THE SAME CONFIG (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs of this same command, scripts/pmc_traffic.py: (2*FETCH_SIZE + WRITE_SIZE)*1024, the factor 2
+    being the gfx950 correction of MI355X_MICROARCH.md); None when no pass of that config is committed."""
     root = os.path.dirname(os.path.abspath(__file__))
-    for rel in ("profiles/r2_pmc_traffic.json", "profiles/r1_pmc_traffic.json"):
+    files = (f"profiles/r3_pmc_traffic_{config}.json",) + (("profiles/r2_pmc_traffic.json", "profiles/r1_pmc_traffic.json")
+                                                          if config == "c2" else ())
+    for rel in files:
         path = os.path.join(root, rel)
         if not os.path.exists(path):
             continue
@@ -312,7 +314,7 @@ def main():
         dom = max(per, key=lambda k: per[k][2])
         n, fl, tsec = per[dom]
         achieved = fl / tsec / 1e12
-        traffic, traffic_src = pmc_traffic(dom)
+        traffic, traffic_src = pmc_traffic(dom, args.config)
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": BF16_DENSE_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,

@@ -107,3 +107,17 @@ def test_attention_scores_far_outside_the_first_tiles_window(where):
     sc = (q.float().view(B, S, H, D).transpose(1, 2) @ k.float().view(B, S, H, D).transpose(1, 2).transpose(-1, -2)) * D ** -0.5
     want = torch.logsumexp(sc, -1) * 1.4426950408889634
     assert ((lse - want).abs() / want.abs().clamp_min(1.0)).max().item() < 1e-3
+
+
+@pytest.mark.parametrize("B,H,S", [(8, 4, 77), (8, 4, 64), (2, 24, 1229)])
+def test_attention_is_bitwise_reproducible(B, H, S):
+    """Two launches on the same data give the same bits, with and without the log-sum-exp output (the training forward and the
+    rollout forward of the MMDiT must be identical for ratio = 1 at update 0)."""
+    from adv_grpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(S + B)
+    qkv = torch.randn(B, S, 3 * H * 64, device="cuda", generator=g).to(torch.bfloat16)
+    q, k, v = qkv[..., :H * 64], qkv[..., H * 64:2 * H * 64], qkv[..., 2 * H * 64:]
+    first = ops.attention(q, k, v, H).clone()
+    for i in range(5):
+        lse = torch.empty(B, H, S, dtype=torch.float32, device="cuda") if i % 2 else None
+        assert torch.equal(ops.attention(q, k, v, H, lse=lse), first)

@@ -14,12 +14,17 @@ def _rel(a, b):
     return ((a.float() - b.float()).norm() / b.float().norm()).item()
 
 
-def _run(cfg, B, hw, Nt, seed):
+def _run(cfg, B, hw, Nt, seed, on_device=False):
     from adv_grpo_amd import synthetic
     from adv_grpo_amd.mmdit import SD3Transformer2DModel
     from oracle import mmdit as o
-    W = synthetic.mmdit_weights(cfg, seed)
+    if on_device:      # multi-billion-parameter configs: draw the weights on the GPU, never hold an fp32 copy on the host
+        with synthetic.on_device("cuda"):
+            W = synthetic.mmdit_weights(cfg, seed)
+    else:
+        W = synthetic.mmdit_weights(cfg, seed)
     Wb = {k: v.to(torch.bfloat16) for k, v in W.items()}           # the weights every path sees
+    del W
     g = torch.Generator().manual_seed(seed + 1)
     lat = torch.randn(B, 16, hw, hw, generator=g).to(torch.bfloat16)
     t = torch.full((B,), 913.3488, dtype=torch.float32)
@@ -97,3 +102,18 @@ def test_mmdit_sd35_large_width_at_1024():
     print("SD3.5-large width @1024^2: rel err hip", e_hip, "torch-bf16", e_torch)
     assert e_hip < max(2 * e_torch, 2e-2), (e_hip, e_torch)
     assert _rel(inter["x3"], rinter["x3"]) < 3e-2
+
+
+def test_mmdit_sd35_large_full_depth_at_1024():
+    """BASELINE config 4's transformer at FULL size: SD3.5-large (38 joint blocks, D = 2432 = 38 heads x 64, no dual blocks,
+    8.0 B parameters) at 1024 x 1024 -- 4096 image + 205 text tokens per sample -- CFG pair, against the fp32 oracle.  The
+    bound is relative to what torch's own bf16 execution of the oracle does at this depth (factor 2), as for the other shapes."""
+    from oracle.mmdit import MMDiTConfig
+    cfg = MMDiTConfig(num_layers=38, num_heads=38, pos_embed_max_size=192, dual_attention_layers=())
+    out, ref, tb, inter, rinter = _run(cfg, B=2, hw=128, Nt=205, seed=79, on_device=True)
+    assert out.shape == (2, 16, 128, 128) and torch.isfinite(out.float()).all()
+    e_hip, e_torch = _rel(out, ref), _rel(tb, ref)
+    print("SD3.5-large, 38 blocks @1024^2: rel err hip", e_hip, "torch-bf16", e_torch)
+    assert e_hip < max(2 * e_torch, 2e-2), (e_hip, e_torch)
+    for k in ("x1", "x19", "x38"):
+        assert _rel(inter[k], rinter[k]) < 6e-2, (k, _rel(inter[k], rinter[k]))

@@ -146,6 +146,31 @@ def test_vae_decode_bf16x3_mode_vs_fp32_oracle(B, hw):
         AutoencoderKLDecoder(W, cfg, "cuda", mode="fp32")
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_vae_decode_at_1024_vs_fp32_oracle(mode):
+    """BASELINE config 4's decode size: one 128 x 128 latent -> 1024^2 image (the mid-block attention runs over 16384 keys,
+    the last up block over 1024^2 x 128 activations) in both modes, against the fp32 oracle decode; same bounds as at 512^2."""
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.vae import AutoencoderKLDecoder
+    from oracle import vae as o
+    cfg = o.VaeConfig()
+    W = synthetic.vae_decoder_weights(cfg, 99)
+    if mode == "bf16":
+        W = {k: v.to(torch.bfloat16) for k, v in W.items()}
+    lat = torch.randn(1, 16, 128, 128, generator=torch.Generator().manual_seed(128)).to(torch.bfloat16)
+    img = AutoencoderKLDecoder(W, cfg, "cuda", mode=mode).decode_to_image(lat.cuda())
+    W32 = {k: v.float().cuda() for k, v in W.items()}
+    with torch.no_grad():
+        ref = o.postprocess(o.vae_decode(W32, cfg, lat.float().cuda() / cfg.scaling_factor + cfg.shift_factor))
+    assert img.shape == (1, 3, 1024, 1024) and torch.isfinite(img).all()
+    err = (img - ref).abs()
+    print(f"vae {mode} @1024^2: image err mean {err.mean().item():.3e} max {err.max().item():.3e}")
+    if mode == "bf16x3":
+        assert err.mean().item() < 2e-5 and err.max().item() < 1e-3
+    else:
+        assert err.mean().item() < 4e-3 and err.max().item() < 6e-2
+
+
 def test_bf16_vae_decode_reward_deltas_vs_fp32_decode_at_config2():
     """The reference decodes in fp32 (TP:481, PF:667-670); the product's decoder runs bf16 MFMA / f32 accumulate with bf16
     activations (fp32 matrix math is 1/16 of the bf16 rate on gfx950).  What matters downstream is the REWARD of a decoded
