@@ -184,13 +184,23 @@ __global__ __launch_bounds__(256) void gate_mul_kernel(const bf16_t* __restrict_
     }
 }
 
-// ---- sum of squares of an f32 vector -> out[0] += (atomic, zero it first)
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+// ---- sum of squares of an f32 vector -> out[0] += ...; fixed summation order (the clipping factor of every optimizer step
+// hangs on it: with one atomicAdd per block the factor, and with it every LoRA weight, moved in the last bit from run to run).
+// Stage 1: SUMSQ_BLOCKS blocks, each a fixed grid-stride slice -> partial[block]; stage 2: one block adds the partials.
+constexpr int SUMSQ_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial) {
     __shared__ float red[4];
     float s = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += g[i] * g[i];
     s = block_sum<4>(s, red);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int nb, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) out[0] += s;
 }
 
 // ---- AdamW (torch semantics: decoupled weight decay, bias correction) with gradient clipping folded in:
@@ -285,9 +295,15 @@ extern "C" int advgrpo_gate_mul(const void* x, const void* gate, void* y, int M,
     return 0;
 }
 
-extern "C" int advgrpo_sumsq_f32(const float* g, int64_t n, float* out, void* stream) {
-    ADVGRPO_CHECK(g && out && n > 0, "sumsq: bad argument");
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, as_stream(stream), g, n, out);
+extern "C" int64_t advgrpo_sumsq_workspace_bytes(void) { return SUMSQ_BLOCKS * sizeof(float); }
+
+extern "C" int advgrpo_sumsq_f32(const float* g, int64_t n, float* out, float* workspace, void* stream) {
+    ADVGRPO_CHECK(g && out && workspace && n > 0, "sumsq: bad argument");
+    int64_t nb = (n + 1023) / 1024;
+    if (nb > SUMSQ_BLOCKS) nb = SUMSQ_BLOCKS;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), g, n, workspace);
+    ADVGRPO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), workspace, (int)nb, out);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

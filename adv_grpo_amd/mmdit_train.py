@@ -441,7 +441,8 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
         lib = _lib.load()
         self.opt_step += 1
         sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
-        _lib.check(lib.advgrpo_sumsq_f32(self.grads.data_ptr(), self.n_params, sumsq.data_ptr(), _lib.stream_ptr()))
+        ws = torch.empty(lib.advgrpo_sumsq_workspace_bytes() // 4, dtype=torch.float32, device=self.device)
+        _lib.check(lib.advgrpo_sumsq_f32(self.grads.data_ptr(), self.n_params, sumsq.data_ptr(), ws.data_ptr(), _lib.stream_ptr()))
         _lib.check(lib.advgrpo_adamw_step(self.params.data_ptr(), self.params_bf16.data_ptr(), self.grads.data_ptr(),
                                           self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.n_params, lr, betas[0],
                                           betas[1], eps, weight_decay, self.opt_step, sumsq.data_ptr(), max_grad_norm,

@@ -320,7 +320,10 @@ int advgrpo_rmsnorm_heads_bwd(void* dy, int64_t lddy, const void* y, int64_t ldy
                               int64_t seg_stride, int64_t seg_off, void* stream);
 int advgrpo_gate_mul(const void* x, const void* gate, void* y, int M, int D, int rows_per_batch,
                      int64_t gate_stride, void* stream);
-int advgrpo_sumsq_f32(const float* g, int64_t n, float* out /* += */, void* stream);
+/* workspace: advgrpo_sumsq_workspace_bytes() bytes of device memory (per-block partial sums, added in a fixed order: the result
+ * is bitwise repeatable) */
+int64_t advgrpo_sumsq_workspace_bytes(void);
+int advgrpo_sumsq_f32(const float* g, int64_t n, float* out /* += */, float* workspace, void* stream);
 /* torch.optim.AdamW step on a flat f32 vector (+ bf16 copy), with clip_grad_norm_ folded in
  * (grad_sumsq = device scalar sum of squares of the UNSCALED grads; grad_scale multiplies every grad, e.g.
  * 1/accumulation steps); grads are zeroed. */

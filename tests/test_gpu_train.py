@@ -235,27 +235,37 @@ def test_dino_d_step_full_size_runs_and_learns():
     assert all(math.isfinite(x) for x in losses) and losses[-1] < losses[0]
 
 
-def test_pickscore_d_step_vs_autograd():
+@pytest.mark.parametrize("size", ["toy", "vit_h"])
+def test_pickscore_d_step_vs_autograd(size):
     """train_pickscore / CLIPCriterion with only the last vision layer trainable (TP:151-183, 1016-1020): loss and
-    every parameter gradient of that layer against torch autograd on the fp32 oracle (pinned vs transformers)."""
+    every parameter gradient of that layer against torch autograd on the fp32 oracle (pinned vs transformers).
+    "vit_h": the width train_pickscore really runs at -- CLIP ViT-H/14 vision layers (1280 wide, 16 heads x 80, MLP 5120,
+    224^2 -> 257 tokens; two layers deep, the frozen ones below the trainable one do not change the arithmetic under test)."""
     from adv_grpo_amd import synthetic, vit
     from adv_grpo_amd.d_step_pickscore import ClipLastLayerTrainable
     from oracle import losses as o_l
     from oracle import vit as o
-    cfg = o.ClipConfig(v_hidden=320, v_layers=3, v_heads=4, v_mlp=640, image_size=56, t_hidden=128, t_layers=2, t_heads=2,
-                       t_mlp=256, vocab=1000, proj=128, eos_token_id=999)
+    if size == "toy":
+        cfg = o.ClipConfig(v_hidden=320, v_layers=3, v_heads=4, v_mlp=640, image_size=56, t_hidden=128, t_layers=2, t_heads=2,
+                           t_mlp=256, vocab=1000, proj=128, eos_token_id=999)
+        cos_min = 0.97
+    else:
+        cfg = o.ClipConfig(v_hidden=1280, v_layers=2, v_heads=16, v_mlp=5120, image_size=224, t_hidden=256, t_layers=2, t_heads=4,
+                           t_mlp=512, vocab=1000, proj=1024, eos_token_id=999)
+        cos_min = 0.995
     W = {k: v.to(torch.bfloat16) for k, v in synthetic.clip_weights(cfg, 12).items()}
     model = vit.CLIPModel(W, cfg, "cuda")
     tr = ClipLastLayerTrainable(model)
     g = torch.Generator().manual_seed(5)
     B = 6
-    px = torch.randn(2 * B, 3, 56, 56, generator=g).to(torch.bfloat16)
+    side, grid = cfg.image_size, cfg.image_size // 14
+    px = torch.randn(2 * B, 3, side, side, generator=g).to(torch.bfloat16)
     ids = torch.randint(1, 990, (B, 77), generator=g); ids[:, 20] = 999
-    patches = torch.zeros(2 * B * 16, 640, dtype=torch.bfloat16)
-    patches[:, :588] = px.view(2 * B, 3, 4, 14, 4, 14).permute(0, 2, 4, 1, 3, 5).reshape(2 * B * 16, 588)
+    patches = torch.zeros(2 * B * grid * grid, 640, dtype=torch.bfloat16)
+    patches[:, :588] = px.view(2 * B, 3, grid, 14, grid, 14).permute(0, 2, 4, 1, 3, 5).reshape(2 * B * grid * grid, 588)
     loss = tr.loss_and_grads(patches.cuda(), ids)
     W32 = {k: v.float().cuda() for k, v in W.items()}
-    p = "vision_model.encoder.layers.2"
+    p = f"vision_model.encoder.layers.{cfg.v_layers - 1}"
     names = {"ln1.w": f"{p}.layer_norm1.weight", "ln1.b": f"{p}.layer_norm1.bias", "out.w": f"{p}.self_attn.out_proj.weight",
              "out.b": f"{p}.self_attn.out_proj.bias", "ln2.w": f"{p}.layer_norm2.weight", "ln2.b": f"{p}.layer_norm2.bias",
              "fc1.w": f"{p}.mlp.fc1.weight", "fc1.b": f"{p}.mlp.fc1.bias", "fc2.w": f"{p}.mlp.fc2.weight",
@@ -268,17 +278,22 @@ def test_pickscore_d_step_vs_autograd():
     ref = o_l.clip_pair_loss(nrm(txt).cpu(), nrm(img[:B]).cpu(), nrm(img[B:]).cpu(), W32["logit_scale"].exp().cpu())
     ref.backward()
     assert abs(loss.item() - ref.item()) < 3e-2 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    worst = 1.0
     for k, n in names.items():
         c = _cos(tr.view(tr.grads, k), W32[n].grad)
-        assert c > 0.97, (k, c)
+        worst = min(worst, c)
+        assert c > cos_min, (k, c)
     for i, x in enumerate("qkv"):
         D = cfg.v_hidden
         cw = _cos(tr.view(tr.grads, "qkv.w")[i * D:(i + 1) * D], W32[f"{p}.self_attn.{x}_proj.weight"].grad)
         cb = _cos(tr.view(tr.grads, "qkv.b")[i * D:(i + 1) * D], W32[f"{p}.self_attn.{x}_proj.bias"].grad)
         if x == "k":      # softmax is invariant to a constant added to every score: d/d(k bias) is exactly zero
-            assert cw > 0.97 and W32[f"{p}.self_attn.k_proj.bias"].grad.abs().max().item() < 1e-5, (x, cw)
+            assert cw > cos_min and W32[f"{p}.self_attn.k_proj.bias"].grad.abs().max().item() < 1e-5, (x, cw)
+            worst = min(worst, cw)
         else:
-            assert cw > 0.97 and cb > 0.97, (x, cw, cb)
+            assert cw > cos_min and cb > cos_min, (x, cw, cb)
+            worst = min(worst, cw, cb)
+    print(f"pickscore D-step ({size}): loss {loss.item():.5f} vs {ref.item():.5f}; worst gradient cosine {worst:.5f}")
     before = model.v_enc.layers[-1]["fc1.w"].clone()
     tr.adam_step(1e-3)
     assert not torch.equal(model.v_enc.layers[-1]["fc1.w"], before)        # the scorer's weights alias the flat vector

@@ -151,6 +151,7 @@ def test_eval_matches_oracle_eval_on_reduced_stack():
         ids = torch.cat([data.clip_ids(i, 1) for i in idxs])
         ref = o_rw.pickscore_from_embeddings(o_t.clip_image_features(C32, ccfg, px), o_t.clip_text_features(C32, ccfg, ids),
                                              C32["logit_scale"]).mean().item()
+    print(f"eval reward: product {got['eval_reward_pickscore_cotrain']:.5f} oracle {ref:.5f} |diff| {abs(got['eval_reward_pickscore_cotrain'] - ref):.3e}")
     assert abs(got["eval_reward_pickscore_cotrain"] - ref) < 5e-2 * max(1.0, abs(ref)), (got, ref)
     assert got["eval_reward_avg"] == got["eval_reward_pickscore_cotrain"]
 
@@ -266,6 +267,7 @@ def test_image_similarity_scorer_on_the_kernels():
     eb = o.dino_forward_features(W32, dc, o_rw.dino_preprocess(b, cuda_semantics=True).float().cuda())[:, 0]
     ea, eb = ea / ea.norm(dim=-1, keepdim=True), eb / eb.norm(dim=-1, keepdim=True)
     ref = (ea @ eb.T).max(dim=1).values
+    print(f"image_similarity: max |diff| {(s - ref).abs().max().item():.3e}")
     assert s.shape == (3,) and (s - ref).abs().max().item() < 2e-2, (s, ref)
 
 
@@ -340,3 +342,49 @@ def test_bench_self_spawn_path_at_world_1():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["value"] > 0
+
+
+def test_full_size_epoch_config2(tmp_path):
+    """One whole sample -> score -> gather -> advantage -> G-step epoch at BASELINE config 2's FULL size (SD3.5-medium, 24
+    blocks, D = 1536, 512^2, 10 steps, CFG 4.5, G = 8, SDE window 2, fp32-equivalent VAE decode, full CLIP ViT-H PickScore)
+    through trainer.Trainer -- the loop bench.py's `epoch` leg times.  Properties of TP:709-1191: the metrics the reference
+    logs exist and are finite (TP:941-955,975-988,1132-1183), the gate takes the G branch with the discriminator off, every
+    sample is INSIDE the clip window at update 0 (old and new log-probs come from the same weights: ratio = 1 exactly, so
+    approx_kl = 0 and clipfrac = 0 for the first optimizer step), the LoRA moved, stayed finite, and the gradient vector
+    was zeroed."""
+    import json
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.config.experiments import get_config
+    from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
+    from adv_grpo_amd.model_configs import ClipConfig, MMDiTConfig, VaeConfig
+    from adv_grpo_amd.pickscore_scorer import PickScoreScorer
+    from adv_grpo_amd.pipeline import SD3Pipeline
+    from adv_grpo_amd.trainer import SyntheticData, Trainer
+    from adv_grpo_amd.vae import AutoencoderKLDecoder
+    cfg = get_config("pickscore_cotrain_sd3_fast", gpu_number=1)
+    cfg.sample.num_image_per_prompt = 8
+    cfg.sample.num_batches_per_epoch = 1
+    cfg.train.gradient_accumulation_steps = 1
+    cfg.train_d = False
+    mcfg = MMDiTConfig()
+    with synthetic.on_device("cuda"):
+        tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, "cuda", seed=cfg.seed)
+        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321), VaeConfig(), "cuda")
+        scorer = PickScoreScorer("cuda", model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
+    log = tmp_path / "metrics.jsonl"
+    trainer = Trainer(cfg, SD3Pipeline(tr, vae, "cuda"), SyntheticData(resolution=cfg.resolution, device="cuda"), scorer, None, 0, 1,
+                      log_path=str(log))
+    p0 = tr.params.clone()
+    out = trainer.run_epoch()
+    torch.cuda.synchronize()
+    assert out["phase"] == "G" and trainer.global_step == 1 and trainer.epoch == 1
+    assert torch.isfinite(tr.params).all() and not torch.equal(tr.params, p0) and (tr.grads == 0).all()
+    recs = [json.loads(l) for l in open(log)]
+    epoch_rec = next(r for r in recs if "reward_avg" in r)
+    for k in ("reward_avg", "zero_std_ratio", "reward_std_mean", "group_size", "trained_prompt_num"):
+        assert k in epoch_rec and torch.isfinite(torch.tensor(float(epoch_rec[k]))), (k, epoch_rec)
+    assert epoch_rec["group_size"] == 8 and epoch_rec["trained_prompt_num"] == 1
+    step_rec = next(r for r in recs if "approx_kl" in r)
+    for k in ("loss", "policy_loss", "approx_kl", "clipfrac", "clipfrac_gt_one", "clipfrac_lt_one"):
+        assert k in step_rec and torch.isfinite(torch.tensor(float(step_rec[k]))), (k, step_rec)
+    assert step_rec["approx_kl"] == 0.0 and step_rec["clipfrac"] == 0.0, step_rec       # ratio == 1 at update 0, bit for bit
