@@ -35,7 +35,8 @@ class EMAModuleWrapper:
         for e, p in zip(self.ema_parameters, parameters):
             if e.dtype != torch.float32 or p.dtype != torch.float32 or e.numel() != p.numel():
                 raise _lib.AdvGrpoError("EMA runs on f32 tensors of equal size")
-            _lib.check(lib.advgrpo_ema_step(_lib.ptr(e), _lib.ptr(p.contiguous()), e.numel(), float(one_minus_decay),
+            pc = p.contiguous()
+            _lib.check(lib.advgrpo_ema_step(_lib.ptr(e), _lib.ptr(pc), e.numel(), float(one_minus_decay),
                                             _lib.stream_ptr()))
 
     def copy_ema_to(self, parameters, store_temp=True):

@@ -386,7 +386,8 @@ def latents_to_nhwc_x3(z, cpad, scaling_factor, shift_factor):
     lib = _lib.load()
     B, C, H, W = z.shape
     out = torch.empty(B, H, W, 3 * cpad, dtype=torch.bfloat16, device=z.device)
-    _lib.check(lib.advgrpo_latents_to_nhwc_x3(_lib.ptr(z.contiguous()), _lib.dtype_code(z.dtype), out.data_ptr(), B, C, H, W,
+    z = z.contiguous()
+    _lib.check(lib.advgrpo_latents_to_nhwc_x3(_lib.ptr(z), _lib.dtype_code(z.dtype), out.data_ptr(), B, C, H, W,
                                               cpad, float(scaling_factor), float(shift_factor), _lib.stream_ptr()))
     return out
 
@@ -402,7 +403,8 @@ def latents_to_nhwc(z, cpad, scaling_factor, shift_factor):
     lib = _lib.load()
     B, C, H, W = z.shape
     out = torch.empty(B, H, W, cpad, dtype=torch.bfloat16, device=z.device)
-    _lib.check(lib.advgrpo_latents_to_nhwc(_lib.ptr(z.contiguous()), _lib.dtype_code(z.dtype), out.data_ptr(), B, C, H, W,
+    z = z.contiguous()
+    _lib.check(lib.advgrpo_latents_to_nhwc(_lib.ptr(z), _lib.dtype_code(z.dtype), out.data_ptr(), B, C, H, W,
                                            cpad, float(scaling_factor), float(shift_factor), _lib.stream_ptr()))
     return out
 

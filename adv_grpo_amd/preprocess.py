@@ -88,8 +88,9 @@ def pil_patches(images, size, mean, std, trunc=False):
     P = (size // 14) ** 2
     patches = torch.empty(B * P, 640, dtype=torch.bfloat16, device=dev)
     tmp = torch.empty(B * 3 * H * size, dtype=torch.uint8, device=dev)
+    images = images.contiguous()
     _lib.check(lib.advgrpo_clip_preprocess_patches(
-        _lib.ptr(images.contiguous()), _lib.dtype_code(images.dtype), patches.data_ptr(), tmp.data_ptr(), B, H, W, size,
+        _lib.ptr(images), _lib.dtype_code(images.dtype), patches.data_ptr(), tmp.data_ptr(), B, H, W, size,
         size, bh.data_ptr(), ch.data_ptr(), kh, bv.data_ptr(), cv.data_ptr(), kv, _f3(mean), _f3(std), int(trunc),
         _lib.stream_ptr()))
     return patches
@@ -100,7 +101,8 @@ def dino_patches(images, size=518):
     B, C, H, W = images.shape
     P = (size // 14) ** 2
     patches = torch.empty(B * P, 640, dtype=torch.bfloat16, device=images.device)
-    _lib.check(lib.advgrpo_dino_preprocess_patches(_lib.ptr(images.contiguous()), _lib.dtype_code(images.dtype),
+    images = images.contiguous()
+    _lib.check(lib.advgrpo_dino_preprocess_patches(_lib.ptr(images), _lib.dtype_code(images.dtype),
                                                    patches.data_ptr(), B, H, W, size, size, _f3(IMAGENET_MEAN),
                                                    _f3(IMAGENET_STD), _lib.stream_ptr()))
     return patches

@@ -191,7 +191,8 @@ class DinoHead:
         B, T, D = feats.shape
         n = idx.shape[1]
         rows = torch.empty(B * (1 + n), D, dtype=torch.bfloat16, device=feats.device)
-        _lib.check(lib.advgrpo_gather_l2norm_rows(_lib.ptr(feats.contiguous()), _lib.ptr(idx.to(torch.int64).contiguous()),
+        feats_c, idx_c = feats.contiguous(), idx.to(torch.int64).contiguous()      # (named: temporaries inside the argument list
+        _lib.check(lib.advgrpo_gather_l2norm_rows(_lib.ptr(feats_c), _lib.ptr(idx_c),  #  are freed before the launch)
                                                   rows.data_ptr(), B, T, D, n, 1e-6, _lib.stream_ptr()))
         hid = ops.gemm(rows, self.w1, bias=self.b1, act="gelu")
         hyb = torch.empty(B, dtype=torch.float32, device=feats.device)
@@ -209,6 +210,7 @@ def pickscore_scores(image_embs, text_embs, logit_scale):
     lib = _lib.load()
     B, P = image_embs.shape
     out = torch.empty(B, dtype=torch.float32, device=image_embs.device)
-    _lib.check(lib.advgrpo_pickscore_pairs(_lib.ptr(image_embs.contiguous()), _lib.ptr(text_embs.contiguous()), B, P,
+    image_c, text_c = image_embs.contiguous(), text_embs.contiguous()
+    _lib.check(lib.advgrpo_pickscore_pairs(_lib.ptr(image_c), _lib.ptr(text_c), B, P,
                                            float(torch.as_tensor(logit_scale).exp()), out.data_ptr(), _lib.stream_ptr()))
     return out

@@ -201,3 +201,22 @@ def test_grpo_loss_vs_reference_golden(dev, case):
         # give an absolute error of a few 1e-7; the clip fractions are exact counts
         np.testing.assert_allclose(scal[i], g[k], rtol=2e-6, atol=1e-6, err_msg=k)
     np.testing.assert_allclose(grad.cpu().numpy(), g["grad"], rtol=2e-6, atol=1e-9)
+
+
+def test_grpo_loss_takes_strided_views():
+    """losses.grpo_loss on column views of [G, T] tensors (what the G-step passes: log_probs[:, j], advantages[:, j]) equals the
+    call on contiguous copies.  Regression: the f32 / contiguous temporaries were created inside the argument list of the ctypes
+    call, freed as soon as their pointer had been taken, and the next temporary re-used the block -- the kernel then read the
+    advantages where the old log-probs should have been."""
+    from adv_grpo_amd import losses
+    g = torch.Generator(device="cuda").manual_seed(3)
+    lp = torch.randn(8, 2, device="cuda", generator=g) * 0.01 - 0.8
+    old = lp + torch.randn(8, 2, device="cuda", generator=g) * 1e-3
+    adv = torch.randn(8, 2, device="cuda", generator=g)
+    for j in range(2):
+        a, ga = losses.grpo_loss(lp[:, j].contiguous(), old[:, j].contiguous(), adv[:, j].contiguous(), 5.0, 1e-4)
+        b, gb = losses.grpo_loss(lp[:, j].contiguous(), old[:, j], adv[:, j], 5.0, 1e-4)
+        assert torch.equal(a, b) and torch.equal(ga, gb)
+        r = torch.exp(lp[:, j] - old[:, j])
+        want = torch.maximum(-adv[:, j] * r, -adv[:, j] * r.clamp(1 - 1e-4, 1 + 1e-4)).mean()
+        assert abs(a[0].item() - want.item()) < 1e-6 and abs(a[1].item() - 0.5 * ((lp[:, j] - old[:, j]) ** 2).mean().item()) < 1e-9

@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-E2E_SCORE_TOL = 5e-2     # end-to-end reward tolerance on the score scale (measured value in the test output)
+E2E_SCORE_TOL = 1.5e-3   # end-to-end reward tolerance on the score scale: measured 6.0e-4 (printed by the test) x 2.5
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 

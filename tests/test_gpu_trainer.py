@@ -152,7 +152,7 @@ def test_eval_matches_oracle_eval_on_reduced_stack():
         ref = o_rw.pickscore_from_embeddings(o_t.clip_image_features(C32, ccfg, px), o_t.clip_text_features(C32, ccfg, ids),
                                              C32["logit_scale"]).mean().item()
     print(f"eval reward: product {got['eval_reward_pickscore_cotrain']:.5f} oracle {ref:.5f} |diff| {abs(got['eval_reward_pickscore_cotrain'] - ref):.3e}")
-    assert abs(got["eval_reward_pickscore_cotrain"] - ref) < 5e-2 * max(1.0, abs(ref)), (got, ref)
+    assert abs(got["eval_reward_pickscore_cotrain"] - ref) < 1.5e-3 * max(1.0, abs(ref)), (got, ref)       # measured 6.3e-4
     assert got["eval_reward_avg"] == got["eval_reward_pickscore_cotrain"]
 
 
@@ -268,7 +268,7 @@ def test_image_similarity_scorer_on_the_kernels():
     ea, eb = ea / ea.norm(dim=-1, keepdim=True), eb / eb.norm(dim=-1, keepdim=True)
     ref = (ea @ eb.T).max(dim=1).values
     print(f"image_similarity: max |diff| {(s - ref).abs().max().item():.3e}")
-    assert s.shape == (3,) and (s - ref).abs().max().item() < 2e-2, (s, ref)
+    assert s.shape == (3,) and (s - ref).abs().max().item() < 8e-3, (s, ref)       # measured 3.4e-3 (bf16 tower vs fp32)
 
 
 def test_checkpoint_resume_restores_state_bit_exactly(tmp_path):
@@ -349,9 +349,11 @@ def test_full_size_epoch_config2(tmp_path):
     blocks, D = 1536, 512^2, 10 steps, CFG 4.5, G = 8, SDE window 2, fp32-equivalent VAE decode, full CLIP ViT-H PickScore)
     through trainer.Trainer -- the loop bench.py's `epoch` leg times.  Properties of TP:709-1191: the metrics the reference
     logs exist and are finite (TP:941-955,975-988,1132-1183), the gate takes the G branch with the discriminator off, every
-    sample is INSIDE the clip window at update 0 (old and new log-probs come from the same weights: ratio = 1 exactly, so
-    approx_kl = 0 and clipfrac = 0 for the first optimizer step), the LoRA moved, stayed finite, and the gradient vector
-    was zeroed."""
+    new log-prob equals the rollout's at update 0 up to the bf16 cast of the stored next latents (the rollout takes its log-prob
+    from the f32 sample BEFORE the cast, PF:646-660, the replay from the stored bf16 one, TP:258: |d log p| ~ 5e-5, approx_kl
+    ~ 1e-9 -- with clip_range = 1e-5 that already counts as clipped, in the reference too), the LoRA moved, stayed finite, and
+    the gradient vector was zeroed.  (This test found the G-step differentiating exp(log_prob - ADVANTAGE): losses.grpo_loss
+    passed pointers of temporaries that were freed and re-used inside its own argument list.)"""
     import json
     from adv_grpo_amd import synthetic
     from adv_grpo_amd.config.experiments import get_config
@@ -387,4 +389,4 @@ def test_full_size_epoch_config2(tmp_path):
     step_rec = next(r for r in recs if "approx_kl" in r)
     for k in ("loss", "policy_loss", "approx_kl", "clipfrac", "clipfrac_gt_one", "clipfrac_lt_one"):
         assert k in step_rec and torch.isfinite(torch.tensor(float(step_rec[k]))), (k, step_rec)
-    assert step_rec["approx_kl"] == 0.0 and step_rec["clipfrac"] == 0.0, step_rec       # ratio == 1 at update 0, bit for bit
+    assert 0.0 <= step_rec["approx_kl"] < 1e-8, step_rec                                 # ratio == 1 at update 0 up to the bf16 cast
