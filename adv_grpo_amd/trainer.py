@@ -518,6 +518,10 @@ class Trainer:
         G, T, nb = c.sample.mini_num_image_per_prompt, c.sample.train_num_steps, c.sample.num_batches_per_epoch
         GA = max(1, c.train.gradient_accumulation_steps)
         neg_pe, neg_ppe = self.data.neg
+        # the sampling schedule (upstream: whatever the last rollout left on the pipeline's scheduler, PF:574): installed here as
+        # well so that a trainer restored from a checkpoint, or one whose last rollout was an eval with another step count,
+        # replays against the same sigma table (the tables are cached per step count: no allocation after the first time)
+        self.pipe.scheduler.set_timesteps(c.sample.num_steps, device=self.device)
         agg = {}
         n_acc = 0
         for inner in range(c.train.num_inner_epochs):

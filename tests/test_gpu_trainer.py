@@ -294,9 +294,9 @@ def test_checkpoint_resume_restores_state_bit_exactly(tmp_path):
     state, _ = checkpoint.load_lora(path)
     assert torch.equal(state["transformer_blocks.0.attn.to_q.lora_A.weight"].cuda(),
                        model_a.A_view(model_a.adapters["transformer_blocks.0.attn.to_q"], model_a.ema)[:32])
-    # and the restored trainer trains on: one more G-step from the same samples moves both models, by at most one lr per
-    # optimizer step (a G-step repeats only up to the summation order of the f32-atomic normalisation-layer gradients, and
-    # Adam turns last-bit differences of near-zero gradients into +-lr, so the two are not compared element for element)
+    # and the restored trainer trains on: one more G-step from the same samples takes both models to the SAME bits (every
+    # reduction on the path sums in a fixed order; the gradient-norm reduction behind clip_grad_norm_ used one atomicAdd per
+    # block until round 3, and Adam turned its last-bit wobble into +-lr on near-zero gradients)
     samples = tr_a.sample_epoch()
     samples["advantages"] = torch.randn(samples["rewards"].shape[0], tr_a.cfg.sample.train_num_steps, device="cuda")
     before = model_b.params.clone()
@@ -307,6 +307,8 @@ def test_checkpoint_resume_restores_state_bit_exactly(tmp_path):
         assert torch.isfinite(m.params).all() and not torch.equal(m.params, before)
         assert (m.params - before).abs().max().item() <= 4 * n_opt * tr_a.cfg.train.learning_rate   # |Adam step| <= (1-b1)/sqrt(1-b2) lr
     assert tr_a.global_step == tr_b.global_step and model_a.opt_step == model_b.opt_step
+    for f in ("params", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(getattr(model_a, f), getattr(model_b, f)), f
 
 
 def test_groups_in_flight_do_not_change_the_samples():
