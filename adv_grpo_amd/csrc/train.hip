@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
     }
 }
 
-// ---- LayerNorm(no affine) + modulation backward.  One row per wave (D <= 2048).
+// ---- LayerNorm(no affine) + modulation backward.  One row per wave (D <= 4096).
 struct LnBwdParams {
     const bf16_t* x; int64_t ldx;
     const bf16_t* dy0; const bf16_t* dy1; int64_t lddy;
@@ -63,8 +63,8 @@ struct LnBwdParams {
     const bf16_t* dres; bf16_t* dx; int64_t lddx;
     int M, D; float eps;
 };
+template <int MAXC>     // 512-column chunks per row: 4 up to D = 2048 (SD3.5-medium), 8 up to 4096 (SD3.5-large: D = 2432)
 __global__ __launch_bounds__(256) void layernorm_mod_bwd_kernel(const LnBwdParams p) {
-    constexpr int MAXC = 4;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.M) return;
@@ -265,11 +265,12 @@ extern "C" int advgrpo_layernorm_mod_bwd(const void* x, int64_t ldx, const void*
                                          const void* scale0, const void* scale1, int64_t mod_stride, int rows_per_batch,
                                          const void* dres, void* dx, int64_t lddx, int M, int D, float eps, void* stream) {
     ADVGRPO_CHECK(x && dy0 && dx, "layernorm_mod_bwd: null pointer");
-    ADVGRPO_CHECK(M > 0 && D % 8 == 0 && D <= 2048, "layernorm_mod_bwd: need D %% 8 == 0, D <= 2048 (D=%d)", D);
+    ADVGRPO_CHECK(M > 0 && D % 8 == 0 && D <= 4096, "layernorm_mod_bwd: need D %% 8 == 0, D <= 4096 (D=%d)", D);
     ADVGRPO_CHECK(!dy1 || scale1, "layernorm_mod_bwd: dy1 needs scale1");
     LnBwdParams p{(const bf16_t*)x, ldx, (const bf16_t*)dy0, (const bf16_t*)dy1, lddy, (const bf16_t*)scale0,
                   (const bf16_t*)scale1, mod_stride, rows_per_batch, (const bf16_t*)dres, (bf16_t*)dx, lddx, M, D, eps};
-    hipLaunchKernelGGL(layernorm_mod_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
+    if (D <= 2048) hipLaunchKernelGGL(layernorm_mod_bwd_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(layernorm_mod_bwd_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

@@ -21,7 +21,11 @@ for _ in range(2): info = g_step.micro_step(model, sch, sample, 0, embeds, poole
 torch.cuda.synchronize(); t0 = time.time(); n = 3
 for _ in range(n): info = g_step.micro_step(model, sch, sample, 0, embeds, pooled, old, adv, **kw)
 torch.cuda.synchronize(); dt = (time.time() - t0) / n
-print(f"G-step micro-batch (fwd+bwd, batch 16): {dt*1e3:.1f} ms  -> {3*2.219*16/dt/1e3:.3f} PFLOP/s effective (fwd+dgrad+wgrad ~3x fwd)")
+# SURVEY 8d's count for a frozen base model: 1 forward + ~1 data-gradient pass of the Linears (no weight-gradient GEMM; the rank-32
+# adapter gradients are negligible) and forward + 2.5x forward for attention: 2 x 1.913 + 3.5 x 0.306 = 4.90 TFLOP per sample
+flop = (2 * 1.913 + 3.5 * 0.306) * 16
+print(f"G-step micro-batch (fwd+bwd, batch 16): {dt*1e3:.1f} ms  -> {flop/dt/1e3:.3f} PFLOP/s = {flop/dt/1e3/2.5:.3f} of the bf16 MFMA peak "
+      f"({flop:.1f} TFLOP per micro-step: 1 fwd + 1 dgrad of the Linears, fwd + bwd of attention)")
 print("log_prob", info["log_prob"][:3].tolist(), "peak mem GB", torch.cuda.max_memory_allocated() / 2**30)
 torch.cuda.synchronize(); t0 = time.time()
 model.optimizer_step()

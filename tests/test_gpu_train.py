@@ -89,12 +89,14 @@ def test_split_k_atomic_gemm_and_dgelu_epilogue():
     assert ((dpre.float() - p32.grad).norm() / p32.grad.norm()).item() < 1e-2
 
 
-@pytest.mark.parametrize("layers,dual", [(3, (0,)), (4, (0, 1))])
-def test_mmdit_lora_backward_vs_autograd(layers, dual):
+@pytest.mark.parametrize("layers,dual,heads", [(3, (0,), 4), (4, (0, 1), 4), (2, (), 38)])
+def test_mmdit_lora_backward_vs_autograd(layers, dual, heads):
+    """(heads = 38: the SD3.5-large width D = 2432 of BASELINE config 4 -- more than 2048 columns per LayerNorm row, a width
+    that is not a multiple of 128 -- through the same forward / backward chain.)"""
     from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
     from oracle import lora as o_lora
     from oracle import mmdit as o
-    cfg = o.MMDiTConfig(num_layers=layers, num_heads=4, joint_attention_dim=128, pooled_projection_dim=64,
+    cfg = o.MMDiTConfig(num_layers=layers, num_heads=heads, joint_attention_dim=128, pooled_projection_dim=64,
                         pos_embed_max_size=96, dual_attention_layers=dual)
     W, lora, lat, t, ctx, pooled, g = _setup(cfg, 31, B=4, hw=16, Nt=13)
     model = SD3TransformerLoRA(W, cfg, "cuda", lora_state=lora)

@@ -392,3 +392,53 @@ def test_full_size_epoch_config2(tmp_path):
     for k in ("loss", "policy_loss", "approx_kl", "clipfrac", "clipfrac_gt_one", "clipfrac_lt_one"):
         assert k in step_rec and torch.isfinite(torch.tensor(float(step_rec[k]))), (k, step_rec)
     assert 0.0 <= step_rec["approx_kl"] < 1e-8, step_rec                                 # ratio == 1 at update 0 up to the bf16 cast
+
+
+def test_full_size_epoch_config4(tmp_path):
+    """BASELINE config 4 at FULL size through the epoch loop: SD3.5-large (38 joint blocks, D = 2432, 8 B parameters) with LoRA,
+    1024 x 1024, 10 steps, CFG 4.5, G = 4, the multi-reward preset `pickscore_sd3_fast` (config/grpo.py:379-427: PickScore +
+    OCR at 0.5 each, no discriminator, random SDE window), fp32-equivalent VAE decode at 1024^2, full CLIP ViT-H PickScore; the
+    OCR half is the host plugin with a stand-in recogniser (PaddleOCR is not installed).  Properties: gate stays at G, rewards =
+    0.5 pick + 0.5 ocr per image, metrics finite, the replayed log-probs equal the rollout's up to the bf16 cast of the stored
+    latents (approx_kl < 1e-8), the LoRA moves and stays finite."""
+    import json
+    from adv_grpo_amd import rewards, synthetic
+    from adv_grpo_amd.config.experiments import get_config
+    from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
+    from adv_grpo_amd.model_configs import ClipConfig, MMDiTConfig, VaeConfig
+    from adv_grpo_amd.pipeline import SD3Pipeline
+    from adv_grpo_amd.trainer import SyntheticData, Trainer
+    from adv_grpo_amd.vae import AutoencoderKLDecoder
+    cfg = get_config("pickscore_sd3_fast", gpu_number=1)
+    cfg.resolution = 1024
+    cfg.sample.num_image_per_prompt = cfg.sample.mini_num_image_per_prompt = 4
+    cfg.sample.num_batches_per_epoch = 1
+    cfg.train.gradient_accumulation_steps = 1
+    mcfg = MMDiTConfig(num_layers=38, num_heads=38, dual_attention_layers=(), pos_embed_max_size=192)
+    with synthetic.on_device("cuda"):
+        tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, "cuda", seed=cfg.seed)
+        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321), VaeConfig(), "cuda")
+        rewards.configure_pickscore(synthetic.clip_weights(ClipConfig(), 777), ClipConfig())
+    calls = []
+
+    def recognizer(img):
+        assert img.dtype.name == "uint8" and img.shape == (1024, 1024, 3)
+        calls.append(1)
+        return "prompt" if len(calls) % 2 else ""
+    rewards.configure_ocr(recognizer)
+    log = tmp_path / "metrics.jsonl"
+    trainer = Trainer(cfg, SD3Pipeline(tr, vae, "cuda"), SyntheticData(resolution=1024, device="cuda"), None, None, 0, 1,
+                      log_path=str(log))
+    assert not trainer.needs_reference
+    p0 = tr.params.clone()
+    out = trainer.run_epoch()
+    torch.cuda.synchronize()
+    print(f"config 4 epoch: phases {trainer.timers}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    assert out["phase"] == "G" and len(calls) == 4
+    assert torch.isfinite(tr.params).all() and not torch.equal(tr.params, p0) and (tr.grads == 0).all()
+    recs = [json.loads(l) for l in open(log)]
+    epoch_rec = next(r for r in recs if "reward_avg" in r)
+    assert epoch_rec["group_size"] == 4 and all(torch.isfinite(torch.tensor(float(epoch_rec[k]))) for k in
+                                                ("reward_avg", "zero_std_ratio", "reward_std_mean"))
+    step_rec = next(r for r in recs if "approx_kl" in r)
+    assert 0.0 <= step_rec["approx_kl"] < 1e-8 and torch.isfinite(torch.tensor(float(step_rec["loss"]))), step_rec
