@@ -33,6 +33,11 @@ class GemmDesc(ctypes.Structure):
                 ("rms_rs_out", _P)]
 
 
+class Fp8Scales(ctypes.Structure):
+    """advgrpo_fp8_scales (include/advgrpo.h)."""
+    _fields_ = [("a_scale", _P), ("w_scale", _P)]
+
+
 # name -> (restype, argtypes); must list every function include/advgrpo.h declares
 SIGNATURES = {
     "advgrpo_abi_version": (c_int, []),
@@ -51,6 +56,8 @@ SIGNATURES = {
                                   c_int64, c_int, c_int64, c_int64, c_int64, _P]),
     "advgrpo_gemm_variant": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "advgrpo_gemm_grouped": (c_int, [POINTER(GemmDesc), c_int, _P]),
+    "advgrpo_gemm_fp8_grouped": (c_int, [POINTER(GemmDesc), POINTER(Fp8Scales), c_int, _P]),
+    "advgrpo_quant_fp8_rows": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int, c_int, c_int, _P]),
     "advgrpo_layernorm_mod": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int,
                                       c_int, c_float, _P]),
     "advgrpo_rmsnorm_heads": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int, c_float, c_int, c_int64, c_int64,

@@ -417,6 +417,19 @@ extern "C" int advgrpo_gemm_grouped(const advgrpo_gemm_desc* descs, int count, v
     return gemm_bf16_pair(from_desc(descs[0]), from_desc(descs[1]), as_stream(stream));
 }
 
+/* fp8 operands (gemm8p_fp8.hip): always the eight-phase kernel, no other tile variant takes them */
+extern "C" int advgrpo_gemm_fp8_grouped(const advgrpo_gemm_desc* descs, const advgrpo_fp8_scales* scales, int count, void* stream) {
+    ADVGRPO_CHECK(descs && scales && (count == 1 || count == 2), "gemm_fp8_grouped: need 1 or 2 descriptors with their scales");
+    GemmParams p[2];
+    for (int i = 0; i < count; ++i) {
+        p[i] = from_desc(descs[i]);
+        p[i].fp8 = 1; p[i].a_scale = scales[i].a_scale; p[i].w_scale = scales[i].w_scale;
+        ADVGRPO_CHECK(p[i].out_dtype == ADVGRPO_BF16 && !p[i].aux_out && !p[i].aux_in, "gemm_fp8_grouped: bf16 output, no aux operands");
+    }
+    if (count == 1) return gemm8p_launch(p[0], as_stream(stream));
+    return gemm8p_launch_pair(p[0], p[1], as_stream(stream));
+}
+
 /* training variant: + aux pre-activation output / d-activation input, split-K atomic accumulation */
 extern "C" int advgrpo_gemm_bf16_train(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                                        int out_dtype, int M, int N, int K, const void* bias, int act, float alpha,

@@ -34,6 +34,9 @@ struct GemmParams {
     // projection: q heads then k heads, V untouched): y = bf16(bf16(x) * rsqrt(mean(x^2) + eps)) * w[(head / hpw), :];
     // rms_rs_out[orow, head] (f32, optional) keeps 1/rms for the backward.  Needs a 64-wide wave tile.
     const bf16_t* rms_w; int rms_nheads; int rms_hpw; float rms_eps; float* rms_rs_out;
+    // fp8 (OCP e4m3) operands on the eight-phase kernel: A [M, K] and W [N, K] one BYTE per element (lda / ldw in elements =
+    // bytes), a_scale [M] / w_scale [N] f32 multiply the accumulators in the epilogue (per-token x per-output-channel scaling)
+    int fp8; const float* a_scale; const float* w_scale;
     int f32_io;  // convolutions only: bias / residual / C are f32 (the split-bf16 VAE mode keeps f32 between kernels)
     int debug;   // experiments only (ADVGRPO_GEMM_DEBUG): bit0 = skip steady-state DMA, bit1 = skip LDS fragment reads
 };

@@ -35,6 +35,7 @@ namespace advgrpo {
 
 unsigned long long* g_p8_stamps = nullptr;
 int gemm8p_launch_train_class(int epi, const GemmPair& pp, const P8Sched& sc, hipStream_t s);   // gemm8p_train.hip
+int gemm8p_launch_fp8_class(int epi, const GemmPair& pp, const P8Sched& sc, hipStream_t s);     // gemm8p_fp8.hip
 
 // every operand of the fused epilogue can be accessed as aligned 16-byte row segments (the dispatcher asks before choosing)
 bool gemm8p_ok(const GemmParams& p) {
@@ -51,13 +52,16 @@ namespace {
 
 int prepare(GemmParams& p) {
     ADVGRPO_CHECK(p.A && p.W && p.C, "gemm8p: null operand");
-    ADVGRPO_CHECK(p.M > 0 && p.N > 0 && p.K > 0 && p.K % 64 == 0, "gemm8p: need M,N>0 and K %% 64 == 0 (M=%d N=%d K=%d)", p.M,
-                  p.N, p.K);
-    ADVGRPO_CHECK(p.lda % 8 == 0 && p.ldw % 8 == 0, "gemm8p: lda/ldw must be multiples of 8 elements");
+    const int es = p.fp8 ? 1 : 2;                 // bytes per operand element; a k-tile is 128 bytes of a row
+    ADVGRPO_CHECK(p.M > 0 && p.N > 0 && p.K > 0 && (p.K * es) % 128 == 0, "gemm8p: need M,N>0 and K %% %d == 0 (M=%d N=%d K=%d)",
+                  128 / es, p.M, p.N, p.K);
+    ADVGRPO_CHECK((p.lda * es) % 16 == 0 && (p.ldw * es) % 16 == 0, "gemm8p: operand rows must be multiples of 16 bytes");
+    ADVGRPO_CHECK(!p.fp8 || (p.a_scale && p.w_scale && p.a_seg_rows == 0 && (reinterpret_cast<uintptr_t>(p.w_scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.a_scale) & 3) == 0),
+                  "gemm8p: fp8 operands need a_scale [M], a 16-byte aligned w_scale [N] and a contiguous row range of A");
     ADVGRPO_CHECK(p.batch == 1 && p.splitk == 1 && !p.conv, "gemm8p: plain (unbatched, unsplit) problems only");
     {
         const int64_t a_rows = p.a_seg_rows > 0 ? ((int64_t)((p.M - 1) / p.a_seg_rows) * p.a_seg_stride + p.a_seg_off + p.a_seg_rows) : p.M;
-        ADVGRPO_CHECK(a_rows * p.lda * 2 < (1ll << 32) && (int64_t)p.N * p.ldw * 2 < (1ll << 32),
+        ADVGRPO_CHECK(a_rows * p.lda * es < (1ll << 32) && (int64_t)p.N * p.ldw * es < (1ll << 32),
                       "gemm8p: operands must span less than 4 GiB (32-bit DMA offsets)");
     }
     {   // the epilogue addresses its operands with 24-bit row x 24-bit pitch multiplies and 32-bit byte offsets
@@ -86,6 +90,12 @@ int epi_class(const GemmParams& p) {
     if (p.gate && p.residual) f |= F_GATE_RES;
     else if (p.gate || p.residual) return EPI_GENERIC;
     if (p.aux_out) f |= F_AUX_OUT;
+    if (p.fp8) {     // fp8 operands: the four rollout classes, each with the scale step
+        switch (f) {
+            case EPI_BIAS: case EPI_BIAS_RMS: case EPI_BIAS_GELU: case EPI_BIAS_GATE_RES: return f | F_SCALE;
+        }
+        return -2;   // (no generic fp8 class)
+    }
     switch (f) {     // the instantiated classes
         case EPI_PLAIN: case EPI_BIAS: case EPI_BIAS_RMS: case EPI_BIAS_GELU: case EPI_BIAS_GATE_RES: case EPI_BIAS_GELU_AUX: case EPI_DGELU:
             return f;
@@ -94,6 +104,8 @@ int epi_class(const GemmParams& p) {
 }
 
 int launch8p_any(int epi, const GemmPair& pp, const P8Sched& sc, hipStream_t s) {
+    if (epi == -2) { set_error("gemm8p: fp8 operands need a bf16 output and one of the epilogues bias / bias+QK-norm / bias+GELU / bias+gate+residual"); return -1; }
+    if (epi >= 0 && (epi & F_SCALE)) return gemm8p_launch_fp8_class(epi, pp, sc, s);
     switch (epi) {
         case EPI_BIAS: return launch8p<EPI_BIAS>(pp, sc, s);
         case EPI_BIAS_RMS: return launch8p<EPI_BIAS_RMS>(pp, sc, s);
@@ -123,6 +135,7 @@ int gemm8p_launch_pair(const GemmParams& a, const GemmParams& b, hipStream_t s) 
     if (prepare(pp.a) || prepare(pp.b)) return -1;
     pp.tiles_a = tiles_of(pp.a);
     const int ea = epi_class(pp.a), eb = epi_class(pp.b);
+    ADVGRPO_CHECK(pp.a.fp8 == pp.b.fp8 && (!pp.a.fp8 || ea == eb), "gemm8p: a paired fp8 launch needs two fp8 problems with the same epilogue");
     return launch8p_any(ea == eb ? ea : (int)EPI_GENERIC, pp, P8Sched{pp.tiles_a, pp.tiles_a + tiles_of(pp.b), nullptr}, s);
 }
 

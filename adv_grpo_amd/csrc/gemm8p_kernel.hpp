@@ -68,7 +68,8 @@ __device__ __forceinline__ void p8_setup(P8Tile& t, const GemmParams& pr, int id
     t.w_bytes = reinterpret_cast<const char*>(p->W);
     t.m0 = tile_m * P8_BM;
     t.n0 = tile_n * P8_BN;
-    t.nk = p->K / P8_BK;
+    const int es = p->fp8 ? 1 : 2;                 // operand element size: a k-tile is 128 BYTES per row either way (64 bf16 / 128 fp8)
+    t.nk = p->K * es / (P8_BK * 2);
     const int lrow = lane >> 3;                   // row inside an 8-row DMA instruction
     const int schunk = (lane & 7) ^ lrow;         // pre-swizzled source chunk of this lane's LDS slot
 #pragma unroll
@@ -83,10 +84,10 @@ __device__ __forceinline__ void p8_setup(P8Tile& t, const GemmParams& pr, int id
                 const int bi = r / p->a_seg_rows;
                 ar = (int64_t)bi * p->a_seg_stride + p->a_seg_off + (r - bi * p->a_seg_rows);
             }
-            t.a_off[sub][it] = (uint32_t)((ar * p->lda + schunk * 8) * 2);
+            t.a_off[sub][it] = (uint32_t)(ar * p->lda * es + schunk * 16);
             int n = t.n0 + (sr >> 5) * 64 + sub * 32 + (sr & 31);
             n = n < p->N ? n : p->N - 1;
-            t.b_off[sub][it] = (uint32_t)(((int64_t)n * p->ldw + schunk * 8) * 2);
+            t.b_off[sub][it] = (uint32_t)((int64_t)n * p->ldw * es + schunk * 16);
         }
 }
 
@@ -127,7 +128,8 @@ __device__ __forceinline__ void p8_stage(const P8Tile& t, char* smem, int wave, 
 //     code took 22-28k cycles per tile, 55k being the k loop).
 // A class is a set of features fixed at compile time (EPI_GENERIC: everything decided at run time).
 enum { EPI_GENERIC = -1, F_BIAS = 1, F_RMS = 2 /* per-head QK RMSNorm */, F_GELU = 4 /* gelu_tanh */, F_GATE_RES = 8 /* * gate + residual */,
-       F_AUX_OUT = 16 /* keep the pre-activation (training forward) */, F_DGELU = 32 /* y *= gelu_tanh'(aux_in) (training backward) */ };
+       F_AUX_OUT = 16 /* keep the pre-activation (training forward) */, F_DGELU = 32 /* y *= gelu_tanh'(aux_in) (training backward) */,
+       F_SCALE = 64 /* acc *= a_scale[m] * w_scale[n]: the per-token / per-channel scales of fp8 operands */ };
 enum { EPI_PLAIN = 0, EPI_BIAS = F_BIAS, EPI_BIAS_RMS = F_BIAS | F_RMS, EPI_BIAS_GELU = F_BIAS | F_GELU, EPI_BIAS_GATE_RES = F_BIAS | F_GATE_RES,
        EPI_BIAS_GELU_AUX = F_BIAS | F_GELU | F_AUX_OUT, EPI_DGELU = F_DGELU };
 
@@ -168,7 +170,7 @@ struct P8EpiArgs {
     float alpha, rms_eps;
     // (explicitly GLOBAL pointers: a pointer that went through the register pin has lost the address space the compiler
     // infers for kernel arguments and would be accessed with flat_load / flat_store)
-    p8_gcptr bias, gate, residual, rms_w, aux_in;
+    p8_gcptr bias, gate, residual, rms_w, aux_in, a_scale, w_scale;
     p8_gptr aux_out, C, rms_rs_out;
     int rms_nheads, rms_hpw, gate_rows, seg_rows, seg_stride, seg_off;
     uint32_t gate_stride, ldc, ldr, ld_aux;
@@ -196,6 +198,7 @@ __device__ __forceinline__ P8EpiArgs p8_epi_args(const GemmParams& g) {
     if constexpr (AUXO) e.aux_out = (p8_gptr)p8_sgpr((uintptr_t)g.aux_out);
     if constexpr (AUXI) e.aux_in = (p8_gcptr)p8_sgpr((uintptr_t)g.aux_in);
     if constexpr (AUXO || AUXI) e.ld_aux = p8_sgpr((uint32_t)g.ld_aux);
+    if constexpr (!G && (EPI & F_SCALE)) { e.a_scale = (p8_gcptr)p8_sgpr((uintptr_t)g.a_scale); e.w_scale = (p8_gcptr)p8_sgpr((uintptr_t)g.w_scale); }
     return e;
 }
 
@@ -210,6 +213,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
     const bool has_gate = G ? p.gate != nullptr : (EPI & F_GATE_RES) != 0;
     const bool has_res = G ? p.residual != nullptr : (EPI & F_GATE_RES) != 0;
     const bool has_aux_out = G ? p.aux_out != nullptr : (EPI & F_AUX_OUT) != 0;
+    const bool has_scale = G ? false : (EPI & F_SCALE) != 0;   // (fp8 operands run on specialised classes only)
     const bool out_bf16 = G ? p.out_dtype == ADVGRPO_BF16 : true;
     const int mrow = lane & 15, q = lane >> 4;
     const int orow_l = lane >> 3, c8 = (lane & 7) * 8;
@@ -245,6 +249,14 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
     }
     f32x2 bias2[4];
     if (has_bias && n_ok) unpack4(ld16(p.bias, (uint32_t)n), bias2);
+    f32x2 wsc2[4];                               // fp8 operands: the eight per-output-channel scales of this lane's columns (f32)
+    if (has_scale && n_ok) {
+        const uint4 s0 = p8_gld16(p.w_scale, (uint32_t)n * 4u), s1 = p8_gld16(p.w_scale, (uint32_t)n * 4u + 16u);
+        wsc2[0] = f32x2{__builtin_bit_cast(float, s0.x), __builtin_bit_cast(float, s0.y)};
+        wsc2[1] = f32x2{__builtin_bit_cast(float, s0.z), __builtin_bit_cast(float, s0.w)};
+        wsc2[2] = f32x2{__builtin_bit_cast(float, s1.x), __builtin_bit_cast(float, s1.y)};
+        wsc2[3] = f32x2{__builtin_bit_cast(float, s1.z), __builtin_bit_cast(float, s1.w)};
+    }
     // wave-uniform bookkeeping of the slab's first row m_s: output row = seg_b * seg_stride + seg_off + seg_r (identity map:
     // seg_rows = 0 -> one segment as long as M), gate vector = gate_b
     const int seg_rows = p.seg_rows > 0 ? p.seg_rows : 0x7fffffff;
@@ -280,7 +292,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
     // compiler can no longer count the younger memory operations and waits with vmcnt(0) -- which also waits for the
     // prefetch it has just issued for the slab after next, so every slab paid a full memory latency (measured: 32 k
     // cycles for the gate + residual epilogue against 15 k for bias + GELU).
-    struct Pre { uint4 r[2]; uint4 g[2]; };     // (g[ps]: the gate vector of THIS lane's row in pass ps -- no reload branch)
+    struct Pre { uint4 r[2]; uint4 g[2]; float sa[2]; };     // (g[ps]: the gate vector of THIS lane's row in pass ps -- no reload branch; sa: its fp8 row scale)
     auto prefetch = [&](const Cur& c, int i, Pre& f) __attribute__((always_inline)) {
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
@@ -289,6 +301,14 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
             if (has_res) {
                 const bool ok = mw0 + i * 16 + row < p.M && n_ok;
                 f.r[ps] = ld16(p.residual, (__umul24(out_row(c, row), (uint32_t)p.ldr) + n) & (0u - (uint32_t)ok));
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {         // per-token scale of the INPUT row (unconditional: rows past the end read row M - 1)
+            f.sa[ps] = 1.0f;
+            if (has_scale) {
+                const int m_in = min(mw0 + i * 16 + ps * 8 + orow_l, p.M - 1);
+                f.sa[ps] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(p.a_scale + (uint32_t)m_in * 4u);
             }
         }
 #pragma unroll
@@ -346,6 +366,10 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
                 f32x2 v[4] = {f32x2{lo[0], lo[1]}, f32x2{lo[2], lo[3]}, f32x2{hi[0], hi[1]}, f32x2{hi[2], hi[3]}};
                 {
 #pragma clang fp contract(off)
+                    if (has_scale) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = (v[k] * f0.sa[ps]) * wsc2[k];
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = v[k] * alpha;
                     if (has_bias) {
@@ -420,7 +444,18 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
 
 struct P8Sched { int tiles_a, tiles_total; unsigned long long* stamps; };   // stamps: experiment (ADVGRPO_P8_STAMPS)
 
-template <bool PAIR, int EPI>
+typedef int p8_v4i __attribute__((ext_vector_type(4)));
+typedef int p8_v8i __attribute__((ext_vector_type(8)));
+// fp8 operands: the two 16-byte fragments a lane reads per row and k-tile (chunks kgrp and 4 + kgrp of the 128-byte row) are
+// the 32 fp8 of ONE v_mfma_scale_f32_16x16x128_f8f6f4 operand.  Which 32 of the row's 128 k positions a lane holds does not
+// matter for a dot product as long as both operands agree, and they do (same fragment reads for A and W), so the LDS image,
+// the DMA and the reads are the bf16 kernel's, byte for byte.  Block scales: all 2^0 (E8M0 127) -- the per-token /
+// per-channel scales are applied in the epilogue (F_SCALE); the scaled instruction is used for its K = 128 rate (2x bf16).
+__device__ __forceinline__ p8_v8i p8_cat(const bf16x8_t& lo, const bf16x8_t& hi) {
+    return __builtin_shufflevector(__builtin_bit_cast(p8_v4i, lo), __builtin_bit_cast(p8_v4i, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <bool PAIR, int EPI, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const P8Sched sc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -518,11 +553,19 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
 #define P8_COMPUTE(MH, NH, AF, BF)                                                                                      \
         do {                                                                                                            \
             __builtin_amdgcn_s_setprio(1);                                                                              \
+            if constexpr (FP8) {                                                                                        \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+                        acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(            \
+                            p8_cat(BF[0][j], BF[1][j]), p8_cat(AF[0][i], AF[1][i]), acc[(MH) * 4 + i][(NH) * 2 + j],    \
+                            0, 0, 0, 0, 0, 0);                                                                          \
+            } else {                                                                                                    \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                            \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
                     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
                         acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
                             BF[ks][j], AF[ks][i], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0);                            \
+            }                                                                                                           \
             __builtin_amdgcn_s_setprio(0);                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
             __builtin_amdgcn_s_barrier();                                                                               \
@@ -597,7 +640,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
 // experiment only: device buffer of the s_memtime stamps of the last launch (ADVGRPO_P8_STAMPS=1)
 extern unsigned long long* g_p8_stamps;
 
-template <int EPI>
+template <int EPI, bool FP8 = false>
 int launch8p(const GemmPair& pp, const P8Sched& sc, hipStream_t s) {
     static int cus = 0;
     if (!cus) {
@@ -611,7 +654,7 @@ int launch8p(const GemmPair& pp, const P8Sched& sc, hipStream_t s) {
     }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<true, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<true, EPI, FP8>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
         attr_set = true;
     }
     const int grid = sc.tiles_total < cus ? sc.tiles_total : cus;
@@ -626,7 +669,7 @@ int launch8p(const GemmPair& pp, const P8Sched& sc, hipStream_t s) {
         sc2.stamps = want ? stamps : nullptr;
     }
 #endif
-    hipLaunchKernelGGL((gemm8p_kernel<true, EPI>), dim3(grid), dim3(512), P8_LDS, s, pp, sc2);   // a single problem is a pair with an empty second half
+    hipLaunchKernelGGL((gemm8p_kernel<true, EPI, FP8>), dim3(grid), dim3(512), P8_LDS, s, pp, sc2);   // a single problem is a pair with an empty second half
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

@@ -30,6 +30,7 @@ class SD3Transformer2DModel:
         self.config = type("Cfg", (), {"in_channels": cfg.in_channels})()
         self._prepare({k: v for k, v in state_dict.items()})
         self._pos_cache = {}
+        self.fp8 = None          # {(block, Linear): ops.Fp8Rows} once enable_fp8() has been called
 
     # ------------------------------------------------------------------ weight preparation
     def _prepare(self, sd):
@@ -83,6 +84,29 @@ class SD3Transformer2DModel:
         w["mod.w"], w["mod.b"] = bf(torch.cat(mod_w)), bf(torch.cat(mod_b))
         self.n_mod = off
         self.w = w
+
+    # ------------------------------------------------------------------ fp8 Linears (BASELINE config 5)
+    FP8_LINEARS = ("qkv", "cqkv", "out", "cout", "qkv2", "out2", "ff1", "cff1", "ff2", "cff2")
+
+    def enable_fp8(self):
+        """Run the block Linears (QKV / out-projection / feed-forward of both streams) on fp8 e4m3 operands: weights quantised
+        per output channel here, activations per token row on the fly (quantize.hip), f32 accumulation, scales applied in the
+        GEMM epilogue (gemm8p_fp8.hip).  Embedders, modulation, norms, attention and the output projection stay bf16.  The
+        reference has no fp8 path (config 5 only swaps the model / resolution); the scheme is stated in
+        include/advgrpo.h.  Call requantize() after changing a weight (SD3TransformerLoRA.refresh does)."""
+        if self.lora_ext != (0, 0):
+            raise ValueError("fp8 Linears need the LoRA adapters merged into the weights (lora_mode='merged')")
+        if self.cfg.dim % 128:
+            raise ValueError(f"fp8 Linears need dim % 128 == 0 (dim = {self.cfg.dim})")
+        self.fp8 = {}
+        self.requantize()
+
+    @torch.no_grad()
+    def requantize(self):
+        for i, b in enumerate(self.blocks):
+            for key in self.FP8_LINEARS:
+                if key + ".w" in b:
+                    self.fp8[(i, key)] = ops.quant_fp8_rows(b[key + ".w"], out=self.fp8.get((i, key)))
 
     lora_ext = (0, 0)          # side columns of the (QKV, out-projection) inputs; set by SD3TransformerLoRA(lora_mode="side")
 
@@ -157,6 +181,23 @@ class SD3Transformer2DModel:
         att2d = att_ext.view(B * S, D + Eo)
         nx_buf = torch.empty(B * Ni, D + Eq, dtype=bf16, device=dev)
         nc_buf = torch.empty(B * Nt, D + Eq, dtype=bf16, device=dev)
+        f8 = self.fp8
+        if f8 is not None:
+            # one buffer for the image rows and the text rows of every Linear input: ONE quantiser launch per Linear pair, the
+            # two Linears read its two row ranges
+            Mi, Mt = B * Ni, B * Nt
+            n_all = torch.empty(Mi + Mt, D, dtype=bf16, device=dev)
+            nx_buf, nc_buf = n_all[:Mi], n_all[Mi:]
+            q_n = ops.Fp8Rows(torch.empty(Mi + Mt, D, dtype=torch.uint8, device=dev), torch.empty(Mi + Mt, dtype=torch.float32, device=dev))
+            q_h = ops.Fp8Rows(torch.empty(Mi + Mt, 4 * D, dtype=torch.uint8, device=dev), torch.empty(Mi + Mt, dtype=torch.float32, device=dev))
+            h_all = torch.empty(Mi + Mt, 4 * D, dtype=bf16, device=dev)
+
+        def linears(i, b, items):
+            """One grouped launch: items = (input, Linear key, epilogue kwargs); input = bf16 rows, or Fp8Rows in fp8 mode."""
+            if f8 is not None:
+                return ops.gemm_grouped_fp8([ops.gemm_desc_fp8(a, f8[(i, key)], bias=b[key + ".b"], **kw) for a, key, kw in items])
+            return ops.gemm_grouped([ops.gemm_desc(a, b[key + ".w"], bias=b[key + ".b"], **kw) for a, key, kw in items])
+
         for i, b in enumerate(self.blocks):
             kx, kc = ("x", i), ("c", i)
             # --- norms + modulation (chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
@@ -170,42 +211,62 @@ class SD3Transformer2DModel:
                 ops.layernorm_mod(c, out=nc_buf[:, :D], scale=mod(kc, 0), shift=mod(kc, 1), rows_per_batch=Nt)
             else:
                 ops.layernorm_mod(c, out=nc_buf[:, :D], scale=mod(kc, 1), shift=mod(kc, 0), rows_per_batch=Nt)
-            nx, nc = self._lora_side_pair(b, [("qkv", nx_buf, None, None), ("cqkv", nc_buf, None, None)], D)
+            if f8 is not None:
+                ops.quant_fp8_rows(n_all, out=q_n)
+                nx, nc = q_n.rows(0, Mi), q_n.rows(Mi, Mi + Mt)
+            else:
+                nx, nc = self._lora_side_pair(b, [("qkv", nx_buf, None, None), ("cqkv", nc_buf, None, None)], D)
             # --- joint attention.  Each text-stream Linear rides in the launch of its image-stream twin
             #     (ops.gemm_grouped) and the QK RMSNorm is the epilogue of the fused QKV projection.
             rms_x = (b["rms_x"], 2 * H, H, 1e-6, None) if cfg.qk_norm else None
             rms_c = (b["rms_c"], 2 * H, H, 1e-6, None) if cfg.qk_norm else None
-            ops.gemm_grouped([ops.gemm_desc(nx, b["qkv.w"], bias=b["qkv.b"], out=qkv, seg=(Ni, S, 0), rms=rms_x),
-                              ops.gemm_desc(nc, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni), rms=rms_c)])
+            linears(i, b, [(nx, "qkv", dict(out=qkv, seg=(Ni, S, 0), rms=rms_x)),
+                           (nc, "cqkv", dict(out=qkv, seg=(Nt, S, Ni), rms=rms_c))])
             ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att)
-            if Eo:
-                self._lora_side_pair(b, [("out", att2d, (Ni, S, 0), B * Ni)] +
-                                     ([] if b["last"] else [("cout", att2d, (Nt, S, Ni), B * Nt)]), D)
-            outs = [ops.gemm_desc(att2d, b["out.w"], bias=b["out.b"], gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x,
-                                  a_seg=(Ni, S, 0), M=B * Ni)]
-            if not b["last"]:
-                outs.append(ops.gemm_desc(att2d, b["cout.w"], bias=b["cout.b"], gate=mod(kc, 2), gate_rows=Nt, residual=c,
-                                          out=c, a_seg=(Nt, S, Ni), M=B * Nt))
-            ops.gemm_grouped(outs)
+            if f8 is not None:      # the joint attention output, image rows first: the two out-projections read its row ranges
+                ops.quant_fp8_rows(att2d, out=q_n, split=(Ni, S))
+                outs = [(q_n.rows(0, Mi), "out", dict(gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x))]
+                if not b["last"]:
+                    outs.append((q_n.rows(Mi, Mi + Mt), "cout", dict(gate=mod(kc, 2), gate_rows=Nt, residual=c, out=c)))
+            else:
+                if Eo:
+                    self._lora_side_pair(b, [("out", att2d, (Ni, S, 0), B * Ni)] +
+                                         ([] if b["last"] else [("cout", att2d, (Nt, S, Ni), B * Nt)]), D)
+                outs = [(att2d, "out", dict(gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x, a_seg=(Ni, S, 0), M=B * Ni))]
+                if not b["last"]:
+                    outs.append((att2d, "cout", dict(gate=mod(kc, 2), gate_rows=Nt, residual=c, out=c, a_seg=(Nt, S, Ni),
+                                                     M=B * Nt)))
+            linears(i, b, outs)
             if b["dual"]:
                 rms_2 = (b["rms_2"], 2 * H, H, 1e-6, None) if cfg.qk_norm else None
-                (qkv2,) = ops.gemm_grouped([ops.gemm_desc(nx2, b["qkv2.w"], bias=b["qkv2.b"], rms=rms_2)])
+                (qkv2,) = linears(i, b, [(ops.quant_fp8_rows(nx2) if f8 is not None else nx2, "qkv2", dict(rms=rms_2))])
                 q3 = qkv2.view(B, Ni, 3 * D)
-                o2 = ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], H)
-                ops.gemm(o2.view(B * Ni, D), b["out2.w"], bias=b["out2.b"], gate=mod(kx, 8), gate_rows=Ni, residual=x,
-                         out=x)
+                o2 = ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], H).view(B * Ni, D)
+                linears(i, b, [(ops.quant_fp8_rows(o2) if f8 is not None else o2, "out2",
+                                dict(gate=mod(kx, 8), gate_rows=Ni, residual=x, out=x))])
             # --- MLPs
-            nx = ops.layernorm_mod(x, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
-            ff1 = [ops.gemm_desc(nx, b["ff1.w"], bias=b["ff1.b"], act="gelu_tanh")]
+            if f8 is not None:
+                ops.layernorm_mod(x, out=nx_buf, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
+                if not b["last"]:
+                    ops.layernorm_mod(c, out=nc_buf, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
+                ops.quant_fp8_rows(n_all, out=q_n)      # (last block: the text rows are stale and unused)
+                ff1 = [(q_n.rows(0, Mi), "ff1", dict(act="gelu_tanh", out=h_all[:Mi]))]
+                if not b["last"]:
+                    ff1.append((q_n.rows(Mi, Mi + Mt), "cff1", dict(act="gelu_tanh", out=h_all[Mi:])))
+                linears(i, b, ff1)
+                ops.quant_fp8_rows(h_all, out=q_h)
+                hm = [q_h.rows(0, Mi), q_h.rows(Mi, Mi + Mt)]
+            else:
+                nx = ops.layernorm_mod(x, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
+                ff1 = [(nx, "ff1", dict(act="gelu_tanh"))]
+                if not b["last"]:
+                    nc = ops.layernorm_mod(c, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
+                    ff1.append((nc, "cff1", dict(act="gelu_tanh")))
+                hm = linears(i, b, ff1)
+            ff2 = [(hm[0], "ff2", dict(gate=mod(kx, 5), gate_rows=Ni, residual=x, out=x))]
             if not b["last"]:
-                nc = ops.layernorm_mod(c, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
-                ff1.append(ops.gemm_desc(nc, b["cff1.w"], bias=b["cff1.b"], act="gelu_tanh"))
-            hm = ops.gemm_grouped(ff1)
-            ff2 = [ops.gemm_desc(hm[0], b["ff2.w"], bias=b["ff2.b"], gate=mod(kx, 5), gate_rows=Ni, residual=x, out=x)]
-            if not b["last"]:
-                ff2.append(ops.gemm_desc(hm[1], b["cff2.w"], bias=b["cff2.b"], gate=mod(kc, 5), gate_rows=Nt, residual=c,
-                                         out=c))
-            ops.gemm_grouped(ff2)
+                ff2.append((hm[1], "cff2", dict(gate=mod(kc, 5), gate_rows=Nt, residual=c, out=c)))
+            linears(i, b, ff2)
             if return_intermediates:
                 inter[f"x{i + 1}"] = x.view(B, Ni, D).clone()
         nx = ops.layernorm_mod(x, scale=mod(("out",), 0), shift=mod(("out",), 1), rows_per_batch=Ni)

@@ -133,6 +133,76 @@ def gemm_grouped(descs):
     return [o for _, o in descs]
 
 
+class Fp8Rows:
+    """A matrix quantised row by row to fp8 e4m3 (quantize.hip): q [M, K] uint8 codes, scale [M] f32, x ~= scale[:, None] * q."""
+    __slots__ = ("q", "scale")
+
+    def __init__(self, q, scale):
+        self.q, self.scale = q, scale
+
+    def rows(self, start, stop):
+        return Fp8Rows(self.q[start:stop], self.scale[start:stop])
+
+    def dequant(self):
+        return self.q.view(torch.float8_e4m3fn).float() * self.scale[:, None]
+
+
+def quant_fp8_rows(x, out=None, split=None):
+    """Per-row symmetric e4m3 quantisation of a bf16 matrix x [M, K] (row pitch free).  split = (first, period): the rows of a
+    joint [B, period] layout are compacted, the `first` leading rows of every period to the front (advgrpo.h)."""
+    lib = _lib.load()
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    M, K = x.shape
+    if out is None:
+        out = Fp8Rows(torch.empty(M, K, dtype=torch.uint8, device=x.device), torch.empty(M, dtype=torch.float32, device=x.device))
+    assert out.q.shape == (M, K) and out.q.stride(1) == 1 and out.scale.is_contiguous() and out.scale.numel() == M
+    sf, sp = (int(v) for v in split) if split is not None else (0, 0)
+    _lib.check(lib.advgrpo_quant_fp8_rows(x.data_ptr(), x.stride(0), out.q.data_ptr(), out.q.stride(0), out.scale.data_ptr(),
+                                          M, K, sf, sp, _lib.stream_ptr()))
+    return out
+
+
+def gemm_desc_fp8(a, w, **kw):
+    """gemm_desc for fp8 operands: a, w are Fp8Rows (activation rows / weight output channels).  Returns
+    (descriptor, out, scales): the triple gemm_grouped_fp8 takes."""
+    assert a.q.dtype == torch.uint8 and w.q.dtype == torch.uint8 and a.q.shape[1] == w.q.shape[1]
+    assert "a_seg" not in kw and "aux_out" not in kw and "aux_in" not in kw
+    d, out = gemm_desc(_As16(a.q), _As16(w.q), **kw)
+    sc = _lib.Fp8Scales()
+    sc.a_scale, sc.w_scale = a.scale.data_ptr(), w.scale.data_ptr()
+    assert a.scale.numel() >= d.M and w.scale.numel() == d.N
+    return d, out, sc
+
+
+class _As16:
+    """Presents a uint8 code matrix to gemm_desc (which checks for bf16 operands and takes pointers / pitches in elements)."""
+    dtype = torch.bfloat16
+
+    def __init__(self, t):
+        self.t, self.shape, self.device = t, t.shape, t.device
+
+    def stride(self, i):
+        return self.t.stride(i)
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+
+def gemm_grouped_fp8(descs):
+    """One launch of the eight-phase kernel on fp8 operands for one or two Linears (triples from gemm_desc_fp8)."""
+    lib = _lib.load()
+    arr = (_lib.GemmDesc * len(descs))(*[d for d, _, _ in descs])
+    scs = (_lib.Fp8Scales * len(descs))(*[s for _, _, s in descs])
+    d0 = descs[0][0]
+    prof = _Prof(d0.M, d0.N, d0.K, 1, 0)
+    if prof.on:
+        prof.flops += sum(2.0 * d.M * d.N * d.K for d, _, _ in descs[1:])
+        prof.name = "gemm8p_kernel_fp8"
+    with prof:
+        _lib.check(lib.advgrpo_gemm_fp8_grouped(arr, scs, len(descs), _lib.stream_ptr()))
+    return [o for _, o, _ in descs]
+
+
 def bmm_nt(a, w, out=None, out_dtype=torch.bfloat16, alpha=1.0):
     """Batched out[b] = alpha * a[b] @ w[b]^T; a [B,M,K], w [B,N,K] bf16."""
     lib = _lib.load()

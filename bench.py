@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+FP8_DENSE_PEAK_TFLOPS = 5000.0    # MI355X_MICROARCH.md: ~5 PF dense fp8 MFMA
 
 
 def parse():
@@ -364,6 +365,29 @@ def main():
             torch.cuda.synchronize()
             lora_ms["side"] = round((time.perf_counter() - tl) / 2 * 1e3, 2)
             pipe.transformer = merged_tr
+        # the same step with the block Linears of the MMDiT on fp8 e4m3 operands (BASELINE config 5's "fp8 MFMA path";
+        # quantize.hip + gemm8p_fp8.hip).  Priced, not the headline: the reference has no fp8 arithmetic to match.
+        fp8 = None
+        if world == 1 and not args.no_pricing:
+            pipe.transformer.enable_fp8()
+            step(0)
+            torch.cuda.synchronize()
+            ops.PROFILE = []
+            t8 = time.perf_counter()
+            for it in range(2):
+                step(1 + it)
+            torch.cuda.synchronize()
+            fp8_ms = (time.perf_counter() - t8) / 2 * 1e3
+            prof8, ops.PROFILE = ops.PROFILE, None
+            k8 = [(fl, s_.elapsed_time(e_) * 1e-3) for name, fl, s_, e_, _ in prof8 if name == "gemm8p_kernel_fp8"]
+            fl8, t8s = sum(f for f, _ in k8), sum(t for _, t in k8)
+            pipe.transformer.fp8 = None
+            fp8 = {"ms_per_step": round(fp8_ms, 2), "value": round(G / (fp8_ms * 1e-3), 3), "speedup_vs_bf16_step": round(step_ms / fp8_ms, 3),
+                   "gemm8p_kernel_fp8": {"launches": len(k8), "achieved_tflops": round(fl8 / t8s / 1e12, 1), "peak_tflops": FP8_DENSE_PEAK_TFLOPS,
+                                         "frac": round(fl8 / t8s / 1e12 / FP8_DENSE_PEAK_TFLOPS, 4), "share_of_step_time": round(t8s / 2 / (fp8_ms * 1e-3), 3)},
+                   "note": "block Linears (QKV / out-projection / feed-forward, both streams) on e4m3 operands: per-token x per-channel f32 "
+                           "scales, f32 accumulation, v_mfma_f32_16x16x128_f8f6f4; activations quantised on the fly; everything else bf16. "
+                           "Velocity within 7e-2 of the fp32 oracle (measured 4.3e-2; bf16 path 1.3e-2) (tests/test_gpu_fp8.py); no reference arithmetic exists for this mode"}
         # two prompt groups in flight on two HIP streams (their rollouts are independent until the reward gather): kernels
         # of one group run in the GEMM tails / epilogue bursts of the other.  Priced, not the headline: with two streams a
         # launch's HIP-event duration includes the other stream's kernels, so the per-kernel roofline is only defined for
@@ -424,6 +448,7 @@ def main():
                     "value_if_bf16": round(images / (dt + args.steps * (vae_ms["bf16"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)
                     if "bf16" in vae_ms else None},
             "overlap": overlap,
+            "fp8_linears": fp8,
             "lora": {"mode": "merged",
                      "modes": {"merged": "W_eff = bf16(W + s B A) in the rollout and training forward (the timed configuration)",
                                "side": "PEFT's y = W x + s B (A x) as K + 192 / K + 64 extra columns of the adapted Linears: the "

@@ -286,6 +286,22 @@ typedef struct advgrpo_gemm_desc {
 } advgrpo_gemm_desc;
 int advgrpo_gemm_grouped(const advgrpo_gemm_desc* descs, int count /* 1 or 2 */, void* stream);
 
+/* ------------------------------------------------------------------ fp8 Linears (BASELINE config 5: "fp8 MFMA path")
+ * The reference has no fp8 code (config 5 changes pretrained.model / resolution only); the scheme is this
+ * library's: OCP e4m3 codes, one f32 scale per token row of the activation and per output channel of the weight,
+ *     x[r,k] ~= scale[r] * q[r,k],   scale[r] = max_k |x[r,k]| / 448  (1 for an all-zero row),  q = RNE(clamp(x / scale)).
+ * advgrpo_quant_fp8_rows: x [M, K] bf16 (pitch ldx) -> q [M, K] one byte per element (pitch ldq) + scale [M].
+ * split_period > 0: rows of a joint [B, period, K] buffer are compacted, the first split_first rows of every period (image
+ * tokens) to output rows b * split_first + s, the others behind ALL of them (B * split_first + b * (period - split_first) + ..).
+ * advgrpo_gemm_fp8_grouped: descriptors as for advgrpo_gemm_grouped with A / W pointing at fp8 codes (lda / ldw in bytes),
+ *     C = epilogue( a_scale[m] * w_scale[n] * sum_k A[m,k] W[n,k] ),
+ * f32 accumulation on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales), bf16 output, K % 128 == 0, no A row map, and one
+ * of the epilogues bias | bias + QK-norm | bias + GELU-tanh | bias + gate + residual. */
+typedef struct advgrpo_fp8_scales { const float* a_scale; const float* w_scale; } advgrpo_fp8_scales;
+int advgrpo_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int M, int K,
+                           int split_first, int split_period, void* stream);
+int advgrpo_gemm_fp8_grouped(const advgrpo_gemm_desc* descs, const advgrpo_fp8_scales* scales, int count /* 1 or 2 */, void* stream);
+
 /* ------------------------------------------------------------------ G-step (training) kernels
  * The update half of the path: loss.backward() / clip_grad_norm_ / AdamW / EMA at
  * scripts/train_sd3_fast_pickscore.py:1165-1171,1186-1187 and adv_grpo/ema.py:39-52; the backward of the

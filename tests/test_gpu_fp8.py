@@ -1,0 +1,208 @@
+"""GPU parity of the fp8 Linears (BASELINE config 5's "fp8 MFMA path": quantize.hip + gemm8p_fp8.hip through the C ABI).
+
+The reference has no fp8 code, so there is no reference output to match; what is pinned here:
+  * the quantiser against its stated definition (include/advgrpo.h), bit for bit: scale = amax / 448 per row, RNE e4m3 codes;
+  * the fp8 GEMM against an fp32 torch evaluation of the SAME quantised operands (products of two e4m3 values are exact in
+    f32, so only the summation order differs: the bound is the bf16 rounding of the output, 2^-8 relative, plus 1e-5);
+  * the quantisation error itself against the bf16 Linear, reported and bounded (e4m3 has a 3-bit mantissa: ~2^-4 relative
+    per element, a few percent on a 1536-deep contraction of random operands)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+bf16 = torch.bfloat16
+
+
+def _quant_ref(x):
+    """The definition in include/advgrpo.h, in torch: same f32 operations in the same order."""
+    xf = x.float()
+    amax = xf.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax * torch.tensor(1.0 / 448.0, dtype=torch.float32, device=x.device), torch.ones_like(amax))
+    inv = 1.0 / scale
+    q = (xf * inv[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), scale
+
+
+@pytest.mark.parametrize("M,K,pitch", [(37, 1536, 1536), (1024, 2432, 2432), (5, 6144, 6144), (64, 128, 256), (9, 8192, 8192)])
+def test_quant_rows_matches_definition(M, K, pitch):
+    from adv_grpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + K)
+    buf = torch.randn(M, pitch, device="cuda", generator=g) * torch.logspace(-3, 2, M, device="cuda")[:, None]
+    buf[M // 2, : K // 2] = 0.0
+    x = buf.to(bf16)[:, :K]
+    if M > 4:
+        x[3] = 0                                     # an all-zero row: scale 1, codes 0
+    r = ops.quant_fp8_rows(x)
+    q_ref, s_ref = _quant_ref(x)
+    assert torch.equal(r.scale, s_ref)
+    assert torch.equal(r.q, q_ref), (r.q != q_ref).sum().item()
+    # and the round trip is within half an e4m3 step of the row maximum (2^-4 relative to amax at worst)
+    err = (r.dequant() - x.float()).abs().amax(dim=1)
+    assert (err <= x.float().abs().amax(dim=1) * (2.0 ** -4) + 1e-30).all()
+
+
+def test_quant_rows_split_map():
+    """Joint [B, S] rows -> image rows first, then the text rows (what the two out-projections read)."""
+    from adv_grpo_amd import ops
+    B, Ni, Nt, K = 3, 40, 13, 256
+    S = Ni + Nt
+    x = torch.randn(B * S, K, device="cuda").to(bf16)
+    r = ops.quant_fp8_rows(x, split=(Ni, S))
+    x3 = x.view(B, S, K)
+    ref = torch.cat([x3[:, :Ni].reshape(B * Ni, K), x3[:, Ni:].reshape(B * Nt, K)])
+    q_ref, s_ref = _quant_ref(ref)
+    assert torch.equal(r.scale, s_ref) and torch.equal(r.q, q_ref)
+
+
+def _gelu_tanh(x):
+    return torch.nn.functional.gelu(x, approximate="tanh")
+
+
+def _ref_linear(a, w, bias, act=None, gate=None, gate_rows=0, residual=None, rms=None):
+    """fp32 evaluation of the epilogue order of gemm8p_kernel.hpp on dequantised operands."""
+    y = (a.dequant().double() @ w.dequant().double().t()).float()
+    y = y + bias.float()
+    if rms is not None:
+        rw, nheads, hpw, eps = rms
+        y = y.to(bf16).float()
+        M, N = y.shape
+        h = y.view(M, N // 64, 64)
+        rs = torch.rsqrt((h * h).mean(dim=-1, keepdim=True) + eps)
+        wsel = rw.float()[(torch.arange(N // 64, device=y.device) // hpw).clamp(max=rw.shape[0] - 1)]
+        hn = (h * rs).to(bf16).float() * wsel[None]
+        keep = (torch.arange(N // 64, device=y.device) < nheads)[None, :, None]
+        y = torch.where(keep, hn, h).reshape(M, N)
+    if act == "gelu_tanh":
+        y = _gelu_tanh(y)
+    if gate is not None:
+        idx = torch.arange(y.shape[0], device=y.device) // gate_rows
+        y = y * gate.float()[idx] + residual.float()
+    return y
+
+
+def _close(out, ref, what, roundings=1):
+    # bf16 output: half an ulp = 2^-9 relative; the gate/residual epilogue rounds once more on the way.  The QK-norm
+    # epilogue rounds to bf16 three times (Linear output, normalised value, weighted value): a summation-order difference
+    # that flips the first rounding moves the result by a whole ulp, and a flipped first rounding is itself up to 2^-7 relative: four times the bound (2^-6).
+    err = (out.float() - ref).abs()
+    bound = ref.abs() * (2.0 ** -8 * roundings) + 2e-3 * ref.abs().mean()
+    assert (err <= bound).all(), (what, (err - bound).max().item(), err.max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 1536, 1536), (1000, 2432, 2432), (16, 256, 128), (300, 4608, 1536), (4101, 1536, 6144)])
+def test_gemm_fp8_bias_and_gelu(M, N, K):
+    from adv_grpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = ops.quant_fp8_rows((torch.randn(M, K, device="cuda", generator=g) * 2).to(bf16))
+    w = ops.quant_fp8_rows((torch.randn(N, K, device="cuda", generator=g) * 0.05).to(bf16))
+    bias = torch.randn(N, device="cuda", generator=g).to(bf16)
+    (out,) = ops.gemm_grouped_fp8([ops.gemm_desc_fp8(a, w, bias=bias)])
+    _close(out, _ref_linear(a, w, bias), "bias")
+    (out,) = ops.gemm_grouped_fp8([ops.gemm_desc_fp8(a, w, bias=bias, act="gelu_tanh")])
+    _close(out, _ref_linear(a, w, bias, act="gelu_tanh"), "gelu")
+
+
+def test_gemm_fp8_pair_gate_residual_and_qk_norm():
+    """The grouped (image + text) launches of a joint block: QKV with the fused QK-norm scattered into the joint buffer, and
+    the gated residual out-projection reading the two row ranges of one quantised buffer."""
+    from adv_grpo_amd import ops
+    B, Ni, Nt, D, H = 2, 256, 77, 512, 8
+    S = Ni + Nt
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rnd = lambda *s, k=1.0: (torch.randn(*s, device="cuda", generator=g) * k).to(bf16)
+    nx, nc = ops.quant_fp8_rows(rnd(B * Ni, D)), ops.quant_fp8_rows(rnd(B * Nt, D))
+    wq, wc = ops.quant_fp8_rows(rnd(3 * D, D, k=0.05)), ops.quant_fp8_rows(rnd(3 * D, D, k=0.05))
+    bq, bc = rnd(3 * D), rnd(3 * D)
+    rms_x, rms_c = rnd(2, 64).abs() + 0.5, rnd(2, 64).abs() + 0.5
+    qkv = torch.zeros(B * S, 3 * D, dtype=bf16, device="cuda")
+    ops.gemm_grouped_fp8([ops.gemm_desc_fp8(nx, wq, bias=bq, out=qkv, seg=(Ni, S, 0), rms=(rms_x, 2 * H, H, 1e-6, None)),
+                          ops.gemm_desc_fp8(nc, wc, bias=bc, out=qkv, seg=(Nt, S, Ni), rms=(rms_c, 2 * H, H, 1e-6, None))])
+    q3 = qkv.view(B, S, 3 * D)
+    _close(q3[:, :Ni].reshape(B * Ni, -1), _ref_linear(nx, wq, bq, rms=(rms_x, 2 * H, H, 1e-6)), "qkv image", roundings=4)
+    _close(q3[:, Ni:].reshape(B * Nt, -1), _ref_linear(nc, wc, bc, rms=(rms_c, 2 * H, H, 1e-6)), "qkv text", roundings=4)
+    # out-projection: joint attention output -> split quantisation -> x += gate * (att W^T + b), c likewise
+    att = rnd(B * S, D)
+    a8 = ops.quant_fp8_rows(att, split=(Ni, S))
+    wo, wco = ops.quant_fp8_rows(rnd(D, D, k=0.05)), ops.quant_fp8_rows(rnd(D, D, k=0.05))
+    bo, bco = rnd(D), rnd(D)
+    gate_x, gate_c = rnd(B, D), rnd(B, D)
+    x, c = rnd(B * Ni, D), rnd(B * Nt, D)
+    x0, c0 = x.clone(), c.clone()
+    ai, at = a8.rows(0, B * Ni), a8.rows(B * Ni, B * S)
+    ops.gemm_grouped_fp8([ops.gemm_desc_fp8(ai, wo, bias=bo, gate=gate_x, gate_rows=Ni, residual=x, out=x),
+                          ops.gemm_desc_fp8(at, wco, bias=bco, gate=gate_c, gate_rows=Nt, residual=c, out=c)])
+    _close(x, _ref_linear(ai, wo, bo, gate=gate_x, gate_rows=Ni, residual=x0), "out image")
+    _close(c, _ref_linear(at, wco, bco, gate=gate_c, gate_rows=Nt, residual=c0), "out text")
+
+
+def test_gemm_fp8_vs_bf16_linear():
+    """What the quantisation costs on an SD3.5-medium Linear shape, against the bf16 kernel on the unquantised operands."""
+    from adv_grpo_amd import ops
+    M, N, K = 2048, 4608, 1536
+    g = torch.Generator(device="cuda").manual_seed(9)
+    a = (torch.randn(M, K, device="cuda", generator=g)).to(bf16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.03).to(bf16)
+    bias = torch.zeros(N, dtype=bf16, device="cuda")
+    ref = ops.gemm(a, w, bias=bias).float()
+    (out,) = ops.gemm_grouped_fp8([ops.gemm_desc_fp8(ops.quant_fp8_rows(a), ops.quant_fp8_rows(w), bias=bias)])
+    rel = ((out.float() - ref).norm() / ref.norm()).item()
+    print("fp8 vs bf16 Linear, relative error", rel)
+    assert rel < 5e-2
+
+
+def test_gemm_fp8_rejects_what_it_cannot_run():
+    from adv_grpo_amd import ops
+    a = ops.quant_fp8_rows(torch.randn(64, 192, device="cuda").to(bf16))      # K % 128 != 0
+    w = ops.quant_fp8_rows(torch.randn(256, 192, device="cuda").to(bf16))
+    with pytest.raises(RuntimeError):
+        ops.gemm_grouped_fp8([ops.gemm_desc_fp8(a, w, bias=torch.zeros(256, dtype=bf16, device="cuda"))])
+    a = ops.quant_fp8_rows(torch.randn(64, 256, device="cuda").to(bf16))
+    w = ops.quant_fp8_rows(torch.randn(256, 256, device="cuda").to(bf16))
+    with pytest.raises(RuntimeError):                                        # no bias: not one of the fp8 classes
+        ops.gemm_grouped_fp8([ops.gemm_desc_fp8(a, w)])
+
+
+def _mmdit_pair(cfg, B, hw, Nt, seed):
+    """The same weights and inputs through the bf16 model, the fp8 model and the fp32 oracle."""
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.mmdit import SD3Transformer2DModel
+    from oracle import mmdit as o
+    with synthetic.on_device("cuda"):
+        W = synthetic.mmdit_weights(cfg, seed)
+    Wb = {k: v.to(bf16) for k, v in W.items()}
+    del W
+    g = torch.Generator(device="cuda").manual_seed(seed + 1)
+    lat = torch.randn(B, 16, hw, hw, generator=g, device="cuda").to(bf16)
+    t = torch.full((B,), 913.3488, dtype=torch.float32, device="cuda")
+    ctx = torch.randn(B, Nt, cfg.joint_attention_dim, generator=g, device="cuda").to(bf16)
+    pooled = torch.randn(B, cfg.pooled_projection_dim, generator=g, device="cuda").to(bf16)
+    m16 = SD3Transformer2DModel(Wb, cfg, "cuda")
+    m8 = SD3Transformer2DModel(Wb, cfg, "cuda")
+    m8.enable_fp8()
+    (o16,) = m16(lat, t, ctx, pooled)
+    (o8,) = m8(lat, t, ctx, pooled)
+    (o8b,) = m8(lat, t, ctx, pooled)
+    assert torch.equal(o8, o8b)                     # bitwise repeatable
+    ref = o.mmdit_forward({k: v.float() for k, v in Wb.items()}, cfg, lat.float(), t, ctx.float(), pooled.float())
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    return rel(o16, ref), rel(o8, ref), rel(o8, o16)
+
+
+def test_mmdit_fp8_small_config():
+    from oracle.mmdit import MMDiTConfig
+    cfg = MMDiTConfig(num_layers=4, num_heads=4, joint_attention_dim=128, pooled_projection_dim=64,
+                      pos_embed_max_size=96, dual_attention_layers=(0, 1))
+    e16, e8, d = _mmdit_pair(cfg, B=3, hw=16, Nt=19, seed=11)   # (the eight-phase epilogue needs >= 16 rows per segment)
+    print("small MMDiT: bf16 vs oracle", e16, "fp8 vs oracle", e8, "fp8 vs bf16", d)
+    assert e8 < 8e-2 and e16 < 3e-2
+
+
+def test_mmdit_fp8_sd35_medium_512():
+    """Full SD3.5-medium at 512^2 with every block Linear on fp8 operands, against the fp32 oracle.  Tolerance: e4m3 carries a
+    3-bit mantissa -- per-Linear error ~3e-2 (test_gemm_fp8_vs_bf16_linear) -- so the velocity is held to 7e-2 relative to the
+    fp32 oracle (the bf16 path is held to 2e-2), and both errors are printed."""
+    from oracle.mmdit import MMDiTConfig
+    e16, e8, d = _mmdit_pair(MMDiTConfig(), B=2, hw=64, Nt=205, seed=5)
+    print("SD3.5-medium 512^2: bf16 vs oracle", e16, "fp8 vs oracle", e8, "fp8 vs bf16", d)
+    assert e16 < 2e-2 and e8 < 7e-2
