@@ -56,7 +56,6 @@ SIGNATURES = {
                                   c_int64, c_int, c_int64, c_int64, c_int64, _P]),
     "advgrpo_gemm_variant": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "advgrpo_gemm_grouped": (c_int, [POINTER(GemmDesc), c_int, _P]),
-    "advgrpo_gemm_stream_k": (c_int, [c_int]),
     "advgrpo_gemm_fp8_grouped": (c_int, [POINTER(GemmDesc), POINTER(Fp8Scales), c_int, _P]),
     "advgrpo_quant_fp8_rows": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int, c_int, c_int, _P]),
     "advgrpo_layernorm_mod": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int,

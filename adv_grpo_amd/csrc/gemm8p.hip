@@ -29,11 +29,6 @@
 //     gemm.hip (each XCD works on a near-square patch of C per round); two problems can share the launch (GemmPair).
 //     The next tile's first k-tile is requested BEFORE the epilogue of the current one (the epilogue bounces its slabs
 //     through the other k-tile buffer), so a tile boundary costs the epilogue but no pipeline refill.
-#include <atomic>
-#include <map>
-#include <mutex>
-#include <utility>
-
 #include "gemm8p_kernel.hpp"
 
 namespace advgrpo {
@@ -50,45 +45,6 @@ bool gemm8p_ok(const GemmParams& p) {
     return p.batch == 1 && p.splitk == 1 && !p.conv && (p.N & 7) == 0 &&
            ((p.ldc | p.ldr | p.gate_stride | p.ld_aux) & 7) == 0 && a16(p.C) && a16(p.bias) && a16(p.gate) &&
            a16(p.residual) && a16(p.aux_out) && a16(p.aux_in) && a16(p.rms_w);
-}
-
-// Stream-K for the ragged tail (P8Sched): used when the launch has more tiles than workgroups, the last round would be less
-// than 80 % full, and every tile has the same number of k-tiles (the two problems of a pair share K).  Splitting a tile's
-// contraction changes the order of its f32 sums: results differ in the last bit from the unsplit schedule, and are the same
-// from run to run (fixed shares, fixed order of the two partial sums).
-// Workspace: one per stream (launches on one stream are serial; two streams may run two of these kernels at once), kept
-// for the life of the process: 256 KiB per workgroup + the flags, which every launch leaves zeroed.
-static std::atomic<int> g_stream_k{1};
-
-int p8_sk_plan(const GemmPair& pp, P8Sched& sc, int grid, hipStream_t s) {
-    sc.sk_tiles = 0; sc.sk_nk = 0; sc.sk_ws = nullptr; sc.sk_flags = nullptr;
-    const int T = sc.tiles_total;
-    if (!g_stream_k.load(std::memory_order_relaxed) || T <= grid || T % grid == 0 || (T % grid) * 5 >= grid * 4) return 0;
-    const int nk_a = pp.a.K * (pp.a.fp8 ? 1 : 2) / (P8_BK * 2);
-    if (sc.tiles_total > sc.tiles_a && pp.b.K * (pp.b.fp8 ? 1 : 2) / (P8_BK * 2) != nk_a) return 0;
-    if (nk_a < 4) return 0;
-    struct Ws { char* ws; int* flags; int slots; };
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, Ws> all;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { set_error("gemm8p: cannot query the device"); return -2; }
-    std::lock_guard<std::mutex> lock(mu);
-    Ws& w = all[{dev, s}];
-    if (w.slots < grid) {
-        // (hipMalloc / hipMemset synchronise the device: first launch on a stream only)
-        char* ws = nullptr; int* flags = nullptr;
-        if (hipMalloc((void**)&ws, (size_t)grid * P8_SK_SLOT) != hipSuccess || hipMalloc((void**)&flags, (size_t)grid * 8 * sizeof(int)) != hipSuccess ||
-            hipMemset(flags, 0, (size_t)grid * 8 * sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-            set_error("gemm8p: cannot allocate the stream-K workspace (%zu bytes)", (size_t)grid * P8_SK_SLOT);
-            return -2;
-        }
-        w = Ws{ws, flags, grid};     // (an older, smaller workspace of this stream is left allocated: a launch may still be using it)
-    }
-    sc.sk_tiles = grid + T % grid;
-    sc.sk_nk = nk_a;
-    sc.sk_ws = w.ws;
-    sc.sk_flags = w.flags;
-    return 0;
 }
 
 namespace {
@@ -184,8 +140,6 @@ int gemm8p_launch_pair(const GemmParams& a, const GemmParams& b, hipStream_t s) 
 }
 
 }  // namespace advgrpo
-
-extern "C" int advgrpo_gemm_stream_k(int enable) { return advgrpo::g_stream_k.exchange(enable ? 1 : 0); }
 
 #ifdef ADVGRPO_EXPERIMENTS
 /* experiment only (not in include/advgrpo.h): copy the s_memtime stamps of the last gemm8p launch to the host */

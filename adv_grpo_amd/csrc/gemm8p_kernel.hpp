@@ -442,87 +442,15 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
 
 }  // namespace
 
-// Schedule of a launch.  sk_tiles = 0: every workgroup walks whole tiles id, id + grid, ... (data parallel).  sk_tiles = S > 0
-// (stream-K for the ragged tail, S = grid + tiles % grid): the S x sk_nk k-tile iterations of tiles [0, S) are dealt out in
-// EQUAL contiguous shares (between one and two tiles' worth each) and worked off first, the other tiles -- a whole number of
-// rounds -- follow data parallel.  A share that starts inside a tile delivers its accumulators to the workgroup that began the
-// tile, through sk_ws / sk_flags (p8_sk_* below).  Without it a launch of T tiles takes ceil(T / grid) rounds however few
-// tiles the last one holds: 540 tiles (out-projection / FF2 of the SD3.5-medium rollout) are 3 rounds for 2.1 rounds of work.
-struct P8Sched {
-    int tiles_a, tiles_total;
-    unsigned long long* stamps;          // experiment (ADVGRPO_P8_STAMPS)
-    int sk_tiles, sk_nk;
-    char* sk_ws;                         // grid slots x 8 waves x 32 KiB of f32 accumulators
-    int* sk_flags;                       // grid x 8, zero between launches (set by the producer, cleared by the consumer)
-};
-enum { P8_FULL = 0, P8_HEAD = 1 /* k-tiles [0, k1) on top of the delivered rest; runs the epilogue */, P8_TAIL = 2 /* [k0, nk): delivers */ };
-constexpr int P8_SK_SLOT = 8 * 32 * 1024;      // bytes of one workgroup's accumulators (8 waves x 128 VGPRs x 64 lanes x 4)
-
-// Partial accumulators travel through memory between two workgroups that are, in general, on different XCDs, whose L2s
-// are not coherent with each other.  Every access is made at AGENT scope (sc1: stores write through, loads do not hit a
-// possibly stale line), the flag is written after the stores have completed (vmcnt) and read before the loads are issued:
-// no L2 write-back / invalidate (buffer_wbl2 / buffer_inv), which would also drop the operand tiles the other workgroups
-// of the XCD are streaming.
-// (Relaxed agent-scope atomics on 64-bit halves ARE such accesses -- global_load / global_store_dwordx2 sc1 -- and, unlike
-// inline-asm loads, the compiler counts them: a first version with asm 128-bit loads and a separate asm wait produced a
-// few thousand wrong elements per launch, a different set every time, because the compiler may copy an asm output
-// register as soon as the statement ends, before the data has landed.)
-typedef unsigned long long p8_u64;
-__device__ __forceinline__ void p8_st16_sc1(char* base, uint32_t off, const f32x4& v) {
-    p8_u64* p = reinterpret_cast<p8_u64*>(base + off);
-    const f32x2 lo{v[0], v[1]}, hi{v[2], v[3]};
-    __hip_atomic_store(p, __builtin_bit_cast(p8_u64, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(p + 1, __builtin_bit_cast(p8_u64, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ f32x4 p8_ld16_sc1(const char* base, uint32_t off) {
-    p8_u64* p = reinterpret_cast<p8_u64*>(const_cast<char*>(base) + off);
-    const f32x2 lo = __builtin_bit_cast(f32x2, __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const f32x2 hi = __builtin_bit_cast(f32x2, __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    return f32x4{lo[0], lo[1], hi[0], hi[1]};
-}
-// a TAIL share: this wave's 128 accumulator registers to slot `slot`, then the wave's flag
-__device__ __forceinline__ void p8_sk_deliver(const P8Sched& sc, int slot, int wave, f32x4 (&acc)[8][4]) {
-    char* base = sc.sk_ws + ((size_t)slot * 8 + wave) * (32 * 1024);
-    const uint32_t off = (uint32_t)p8_lane() * 16u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) p8_st16_sc1(base, off + (uint32_t)(i * 4 + j) * 1024u, acc[i][j]);
-#ifdef P8_SK_FENCE
-    asm volatile("buffer_wbl2 sc1" ::: "memory");
-#endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have completed before the flag is written
-    if (p8_lane() == 0) __hip_atomic_store(sc.sk_flags + slot * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// a HEAD share STARTS from the accumulators of the workgroup that ran the rest of the tile (its first share, delivered long
-// before this one's last share begins): the sum is "later k range first, then k-tiles 0 .. k1 on top", a fixed order.  The
-// loads land in the accumulator registers themselves (collecting at the end instead needs temporaries next to 128 live
-// accumulators and the next item's addresses, and spilled).  Clears the flag for the next launch.
-__device__ __forceinline__ void p8_sk_collect(const P8Sched& sc, int slot, int wave, f32x4 (&acc)[8][4]) {
-    int* flag = sc.sk_flags + slot * 8 + wave;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
-#ifdef P8_SK_FENCE
-    asm volatile("buffer_inv sc1" ::: "memory");
-#endif
-    const char* base = sc.sk_ws + ((size_t)slot * 8 + wave) * (32 * 1024);
-    const uint32_t off = (uint32_t)p8_lane() * 16u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = p8_ld16_sc1(base, off + (uint32_t)(i * 4 + j) * 1024u);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the loads have been consumed into registers before the flag is cleared)
-    if (p8_lane() == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+struct P8Sched { int tiles_a, tiles_total; unsigned long long* stamps; };   // stamps: experiment (ADVGRPO_P8_STAMPS)
 
 typedef int p8_v4i __attribute__((ext_vector_type(4)));
 typedef int p8_v8i __attribute__((ext_vector_type(8)));
 // fp8 operands: the two 16-byte fragments a lane reads per row and k-tile (chunks kgrp and 4 + kgrp of the 128-byte row) are
-// the 32 fp8 of ONE v_mfma_f32_16x16x128_f8f6f4 operand.  Which 32 of the row's 128 k positions a lane holds does not matter
-// for a dot product as long as both operands agree, and they do (same fragment reads for A and W), so the LDS image, the DMA
-// and the reads are the bf16 kernel's, byte for byte.  The UNSCALED form of the instruction (both scale operands the
-// constant 0: no v_mfma_ld_scale prefix, block scales 2^0; measured identical to unit scales in a register, and it needs
-// no scale VGPRs -- with them this kernel spilled inside the k loop): the per-token / per-channel scales are applied in
-// the epilogue (F_SCALE), the instruction is used for its K = 128 rate (2x bf16).
+// the 32 fp8 of ONE v_mfma_scale_f32_16x16x128_f8f6f4 operand.  Which 32 of the row's 128 k positions a lane holds does not
+// matter for a dot product as long as both operands agree, and they do (same fragment reads for A and W), so the LDS image,
+// the DMA and the reads are the bf16 kernel's, byte for byte.  Block scales: all 2^0 (E8M0 127) -- the per-token /
+// per-channel scales are applied in the epilogue (F_SCALE); the scaled instruction is used for its K = 128 rate (2x bf16).
 __device__ __forceinline__ p8_v8i p8_cat(const bf16x8_t& lo, const bf16x8_t& hi) {
     return __builtin_shufflevector(__builtin_bit_cast(p8_v4i, lo), __builtin_bit_cast(p8_v4i, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }
@@ -537,46 +465,16 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
     const int b_base = 2 * P8_HALF + wc * 32 * 128;       // + sub * P8_HALF + j * 16 * 128
     const int nwg = gridDim.x;
 
-    // a work item: k-tiles [k0, k1) of tile id (k1 < 0: all of it) of problem a or b
-    auto setup = [&](int id, int k0, int k1, P8Tile& t) __attribute__((always_inline)) {
+    // tile -> (problem, tile id): every round of nwg tiles is dealt XCD-contiguously
+    auto locate = [&](int tile, P8Tile& t) __attribute__((always_inline)) {
+        const int round0 = tile - (int)blockIdx.x;
+        const int in_round = min(nwg, sc.tiles_total - round0);
+        int id = round0 + xcd_remap(blockIdx.x, in_round);
         const bool second = PAIR && id >= sc.tiles_a;
         if (second) id -= sc.tiles_a;
         t.second = second;
         if (second) p8_setup(t, pp.b, id, wave);
         else p8_setup(t, pp.a, id, wave);
-        if (k1 >= 0) {
-            t.a_bytes += (size_t)k0 * (P8_BK * 2);
-            t.w_bytes += (size_t)k0 * (P8_BK * 2);
-            t.nk = k1 - k0;
-        }
-    };
-    // this workgroup's items in order: its stream-K share (ranks are XCD-contiguous: the two workgroups of a split tile
-    // usually share an L2), then its data-parallel tiles -- every round of nwg tiles is dealt XCD-contiguously
-    const int rank = xcd_remap(blockIdx.x, nwg);
-    int sk_it = 0, sk_end = 0;
-    if (sc.sk_tiles > 0) {
-        const int total = sc.sk_tiles * sc.sk_nk, base = total / nwg, extra = total - base * nwg;
-        sk_it = rank * base + min(rank, extra);
-        sk_end = sk_it + base + (rank < extra ? 1 : 0);
-    }
-    int dp_tile = sc.sk_tiles + (int)blockIdx.x;
-    auto next_item = [&](P8Tile& t, int& kind) __attribute__((always_inline)) -> bool {
-        if (sk_it < sk_end) {
-            const int tile = sk_it / sc.sk_nk, k0 = sk_it - tile * sc.sk_nk, k1 = min(sc.sk_nk, k0 + (sk_end - sk_it));
-            sk_it += k1 - k0;
-            setup(tile, k0, k1, t);
-            kind = k0 > 0 ? (int)P8_TAIL : (k1 < sc.sk_nk ? (int)P8_HEAD : (int)P8_FULL);
-            return true;
-        }
-        if (dp_tile < sc.tiles_total) {
-            const int round0 = dp_tile - (int)blockIdx.x;
-            const int in_round = min(nwg, sc.tiles_total - round0);
-            setup(round0 + xcd_remap(blockIdx.x, in_round), 0, -1, t);
-            kind = P8_FULL;
-            dp_tile += nwg;
-            return true;
-        }
-        return false;
     };
     // the seven items the steady state would have issued before phase 0 of k-tile 0, in its order: A0 W0 W1 A1 of
     // k-tile 0 (buffer 0), then A0 W0 W1 of k-tile 1 (buffer 1)
@@ -600,24 +498,17 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
 #endif
     };
     P8Tile t;
-    int kind = P8_FULL;
-    bool have = next_item(t, kind);
-    if (have) {
-        issue_first(t);
-        issue_second(t);
-    }
-    while (have) {
+    locate(blockIdx.x, t);
+    issue_first(t);
+    issue_second(t);
+    for (int tile = blockIdx.x; tile < sc.tiles_total; tile += nwg) {
         const int nk = t.nk;
         const int n_items = 4 * nk;                       // ring items of this output tile, in issue (= first-read) order
         f32x4 acc[8][4];
-        if (EPI != EPI_GENERIC && kind == P8_HEAD) {      // (no stream-K in the generic class: it has no registers to spare)
-            p8_sk_collect(sc, rank + 1, wave, acc);       // (the rest of the tile was the next rank's first share)
-        } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         // per-lane fragment offsets, recomputed per tile from an opaque copy of the lane id: kept live across the epilogue
         // they were spilled, and the reload's conservative s_waitcnt vmcnt(0) ended up INSIDE the k loop (draining the DMA)
@@ -725,13 +616,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
         // request the rest of the next tile's pipeline fill
         const bool cur_second = t.second;
         const int mw0 = t.m0 + wr * 128, nw0 = t.n0 + wc * 64;
-        const int cur_kind = kind;
-        const bool more = next_item(t, kind);
-        if (more) issue_first(t);
+        const bool more = tile + nwg < sc.tiles_total;
+        if (more) {
+            locate(tile + nwg, t);
+            issue_first(t);
+        }
         stamp(3);
-        if (EPI != EPI_GENERIC && cur_kind == P8_TAIL) {                        // the tile was begun by the previous rank: it runs the epilogue
-            p8_sk_deliver(sc, rank, wave, acc);
-        } else {
+        {
             const GemmParams& p = (PAIR && cur_second) ? pp.b : pp.a;
             p8_epilogue<EPI>(p, acc, mw0, nw0, smem + P8_BUF + wave * P8_SCRATCH);
         }
@@ -742,16 +633,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
             stamp(5);
             issue_second(t);
         }
-        have = more;
         ++stamp_i;
     }
 }
 
 // experiment only: device buffer of the s_memtime stamps of the last launch (ADVGRPO_P8_STAMPS=1)
 extern unsigned long long* g_p8_stamps;
-
-// stream-K plan of a launch (fills sc.sk_*; gemm8p.hip owns the per-stream workspaces)
-int p8_sk_plan(const GemmPair& pp, P8Sched& sc, int grid, hipStream_t s);
 
 template <int EPI, bool FP8 = false>
 int launch8p(const GemmPair& pp, const P8Sched& sc, hipStream_t s) {
@@ -772,7 +659,6 @@ int launch8p(const GemmPair& pp, const P8Sched& sc, hipStream_t s) {
     }
     const int grid = sc.tiles_total < cus ? sc.tiles_total : cus;
     P8Sched sc2 = sc;
-    if (EPI != EPI_GENERIC && p8_sk_plan(pp, sc2, grid, s)) return -2;
 #ifdef ADVGRPO_EXPERIMENTS
     {
         static unsigned long long* stamps = nullptr;

@@ -112,19 +112,6 @@ def gemm_desc(a, w, bias=None, act=None, alpha=1.0, gate=None, gate_rows=0, resi
     return d, out
 
 
-class stream_k:
-    """Context manager: stream-K scheduling of the wide Linears on / off (advgrpo_gemm_stream_k, process-wide)."""
-
-    def __init__(self, enable):
-        self.enable = bool(enable)
-
-    def __enter__(self):
-        self.prev = _lib.load().advgrpo_gemm_stream_k(int(self.enable))
-
-    def __exit__(self, *a):
-        _lib.load().advgrpo_gemm_stream_k(self.prev)
-
-
 def gemm_grouped(descs):
     """One launch for one or two Linears ((descriptor, out) pairs from gemm_desc); returns the outputs."""
     lib = _lib.load()

@@ -285,12 +285,6 @@ typedef struct advgrpo_gemm_desc {
     const void* rms_weight; int32_t rms_nheads, rms_heads_per_weight; float rms_eps; float* rms_rs_out;
 } advgrpo_gemm_desc;
 int advgrpo_gemm_grouped(const advgrpo_gemm_desc* descs, int count /* 1 or 2 */, void* stream);
-/* Stream-K scheduling of the wide Linears (256x256 tiles, one workgroup per CU): when the last round of tiles would be less
- * than 80 % full, the contraction of grid + tiles % grid tiles is dealt out in equal shares, a split tile's two partial sums
- * meeting in a workspace (gemm8p.hip).  On (the default) a launch's results are reproducible run to run but the split
- * positions depend on M and N, so a row's last bit can differ between two batch sizes; off restores one summation order
- * for every shape (batch-invariant results, ragged last round).  Process-wide; returns the previous setting. */
-int advgrpo_gemm_stream_k(int enable);
 
 /* ------------------------------------------------------------------ fp8 Linears (BASELINE config 5: "fp8 MFMA path")
  * The reference has no fp8 code (config 5 changes pretrained.model / resolution only); the scheme is this

@@ -105,12 +105,7 @@ def test_gemm_grouped_pair_with_fused_qk_norm(shape):
     bt = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
     rw_i = (1 + 0.1 * torch.randn(2, 64, device="cuda", generator=g)).to(torch.bfloat16)
     rw_t = (1 + 0.1 * torch.randn(2, 64, device="cuda", generator=g)).to(torch.bfloat16)
-    # unfused: two launches + two norm kernels (one summation order for both schedules: stream-K off, see below)
-    with ops.stream_k(False):
-        _qk_norm_pair_body(ops, B, Ni, Nt, K, N, S, H, xi, xt, wi, wt, bi, bt, rw_i, rw_t)
-
-
-def _qk_norm_pair_body(ops, B, Ni, Nt, K, N, S, H, xi, xt, wi, wt, bi, bt, rw_i, rw_t):
+    # unfused: two launches + two norm kernels
     ref = torch.zeros(B * S, N, dtype=torch.bfloat16, device="cuda")
     rs_ref = torch.zeros(B * S, 2 * H, dtype=torch.float32, device="cuda")
     ops.gemm(xi, wi, bias=bi, out=ref, seg=(Ni, S, 0))
@@ -148,61 +143,8 @@ def test_gemm_grouped_pair_gate_residual_matches_two_launches():
     gt = torch.randn(B, N, device="cuda", generator=g).to(torch.bfloat16)
     ri = torch.randn(B * Ni, N, device="cuda", generator=g).to(torch.bfloat16)
     rt = torch.randn(B * Nt, N, device="cuda", generator=g).to(torch.bfloat16)
-    with ops.stream_k(False):       # (bit for bit needs one summation order: the two schedules split different tiles)
-        a = ops.gemm(xi, wi, bias=bi, gate=gi, gate_rows=Ni, residual=ri)
-        b = ops.gemm(xt, wt, act="gelu_tanh", gate=gt, gate_rows=Nt, residual=rt)
-        oa, ob = ops.gemm_grouped([ops.gemm_desc(xi, wi, bias=bi, gate=gi, gate_rows=Ni, residual=ri),
-                                   ops.gemm_desc(xt, wt, act="gelu_tanh", gate=gt, gate_rows=Nt, residual=rt)])
+    a = ops.gemm(xi, wi, bias=bi, gate=gi, gate_rows=Ni, residual=ri)
+    b = ops.gemm(xt, wt, act="gelu_tanh", gate=gt, gate_rows=Nt, residual=rt)
+    oa, ob = ops.gemm_grouped([ops.gemm_desc(xi, wi, bias=bi, gate=gi, gate_rows=Ni, residual=ri),
+                               ops.gemm_desc(xt, wt, act="gelu_tanh", gate=gt, gate_rows=Nt, residual=rt)])
     assert torch.equal(oa, a) and torch.equal(ob, b)
-
-
-@pytest.mark.parametrize("case", ["qkv", "ff2_pair", "ff1_pair_fp8", "large_width"])
-def test_gemm_stream_k_tail(case):
-    """Stream-K for the ragged last round of the 256x256 kernel (gemm8p.hip): the split tiles' two partial sums meet in a
-    workspace.  Against the unsplit schedule the result may differ where the f32 sum lands on the other side of a bf16
-    rounding boundary (one ulp, few elements); it is bitwise the same from launch to launch, also after the workspace
-    has been used by other shapes, and it matches the fp32 reference like the unsplit schedule does."""
-    from adv_grpo_amd import ops
-    g = torch.Generator(device="cuda").manual_seed(11)
-    rnd = lambda *s, k=1.0: (torch.randn(*s, device="cuda", generator=g) * k).to(torch.bfloat16)
-    B, Ni, Nt = 16, 1024, 205
-    if case == "qkv":                      # 77 x 18 = 1386 tiles: 5.4 rounds
-        x, w, b = rnd(19664, 1536), rnd(4608, 1536, k=0.05), rnd(4608)
-        run = lambda: ops.gemm(x, w, bias=b)
-        ref = lambda: x.float() @ w.float().t() + b.float()
-    elif case == "large_width":            # config 4's width: 135 x 10 = 1350 tiles (5.3 rounds), ragged last column tile, 38 k-tiles
-        x, w, b = rnd(34408, 2432), rnd(2432, 2432, k=0.05), rnd(2432)
-        run = lambda: ops.gemm(x, w, bias=b, act="gelu_tanh")
-        ref = lambda: torch.nn.functional.gelu(x.float() @ w.float().t() + b.float(), approximate="tanh")
-    elif case == "ff2_pair":               # (64 + 13) x 6 = 462 + 78 = 540 tiles: 2.1 rounds, K = 6144
-        xi, xt, wi, wt = rnd(B * Ni, 6144), rnd(B * Nt, 6144), rnd(1536, 6144, k=0.03), rnd(1536, 6144, k=0.03)
-        bi, bt, gi, gt = rnd(1536), rnd(1536), rnd(B, 1536), rnd(B, 1536)
-        ri, rt = rnd(B * Ni, 1536), rnd(B * Nt, 1536)
-        run = lambda: torch.cat(ops.gemm_grouped([ops.gemm_desc(xi, wi, bias=bi, gate=gi, gate_rows=Ni, residual=ri),
-                                                  ops.gemm_desc(xt, wt, bias=bt, gate=gt, gate_rows=Nt, residual=rt)]))
-        ref = lambda: torch.cat([(xi.float() @ wi.float().t() + bi.float()) * gi.float().repeat_interleave(Ni, 0) + ri.float(),
-                                 (xt.float() @ wt.float().t() + bt.float()) * gt.float().repeat_interleave(Nt, 0) + rt.float()])
-    else:                                  # fp8 operands: (64 + 13) x 24 = 1848 + 312 = 2160 tiles, 12 k-tiles of 128
-        xi, xt = ops.quant_fp8_rows(rnd(B * Ni, 1536)), ops.quant_fp8_rows(rnd(B * Nt, 1536))
-        wi, wt = ops.quant_fp8_rows(rnd(6144, 1536, k=0.05)), ops.quant_fp8_rows(rnd(6144, 1536, k=0.05))
-        bi, bt = rnd(6144), rnd(6144)
-        run = lambda: torch.cat(ops.gemm_grouped_fp8([ops.gemm_desc_fp8(xi, wi, bias=bi, act="gelu_tanh"),
-                                                      ops.gemm_desc_fp8(xt, wt, bias=bt, act="gelu_tanh")]))
-        gelu = lambda v: torch.nn.functional.gelu(v, approximate="tanh")
-        ref = lambda: torch.cat([gelu(xi.dequant() @ wi.dequant().t() + bi.float()), gelu(xt.dequant() @ wt.dequant().t() + bt.float())])
-    with ops.stream_k(False):
-        unsplit = run()
-    with ops.stream_k(True):
-        a = run()
-        ops.gemm(rnd(20000, 512), rnd(1024, 512))            # another split shape (316 tiles) through the same workspace
-        b2 = run()
-    assert torch.equal(a, b2)
-    want = ref()
-    scale = want.abs().mean().item()
-    d = (a.float() - unsplit.float()).abs()
-    assert (d <= unsplit.float().abs() * 2.0 ** -7 + 1e-3 * scale).all(), d.max().item()
-    frac = (d > 0).float().mean().item()
-    print(case, "elements that differ from the unsplit schedule:", frac)
-    assert frac < 0.02
-    ea, eu = (a.float() - want).abs().max().item(), (unsplit.float() - want).abs().max().item()
-    assert ea <= 1.5 * eu + 1e-3 * scale, (ea, eu)
