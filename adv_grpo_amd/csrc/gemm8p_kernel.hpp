@@ -400,11 +400,14 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
                 if ((G || (EPI & F_DGELU)) && act >= ACT_DGELU_TANH) {
                     f32x2 z[4];
                     unpack4(ld16(p.aux_in, o_aux), z);
+                    if (act == ACT_DGELU_TANH) {
+                        dgelu_tanh_mul_pk4(v, z);
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = f32x2{v[k].x * dact_fn(z[k].x, act), v[k].y * dact_fn(z[k].y, act)};
+                        for (int k = 0; k < 4; ++k) v[k] = f32x2{v[k].x * dact_fn(z[k].x, act), v[k].y * dact_fn(z[k].y, act)};
+                    }
                 } else if (act == ACT_GELU_TANH) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = gelu_tanh_pk(v[k]);
+                    gelu_tanh_pk4(v);
                 } else if (act != ACT_NONE) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = f32x2{act_fn(v[k].x, act), act_fn(v[k].y, act)};
@@ -447,10 +450,12 @@ struct P8Sched { int tiles_a, tiles_total; unsigned long long* stamps; };   // s
 typedef int p8_v4i __attribute__((ext_vector_type(4)));
 typedef int p8_v8i __attribute__((ext_vector_type(8)));
 // fp8 operands: the two 16-byte fragments a lane reads per row and k-tile (chunks kgrp and 4 + kgrp of the 128-byte row) are
-// the 32 fp8 of ONE v_mfma_scale_f32_16x16x128_f8f6f4 operand.  Which 32 of the row's 128 k positions a lane holds does not
-// matter for a dot product as long as both operands agree, and they do (same fragment reads for A and W), so the LDS image,
-// the DMA and the reads are the bf16 kernel's, byte for byte.  Block scales: all 2^0 (E8M0 127) -- the per-token /
-// per-channel scales are applied in the epilogue (F_SCALE); the scaled instruction is used for its K = 128 rate (2x bf16).
+// the 32 fp8 of ONE v_mfma_f32_16x16x128_f8f6f4 operand.  Which 32 of the row's 128 k positions a lane holds does not matter
+// for a dot product as long as both operands agree, and they do (same fragment reads for A and W), so the LDS image, the DMA
+// and the reads are the bf16 kernel's, byte for byte.  The UNSCALED form of the instruction (both scale operands the
+// constant 0: no v_mfma_ld_scale prefix, block scales 2^0; measured identical to unit scales in a register and at the same
+// rate, scripts/probes/mfma_fp8_probe.hip -- and with scale VGPRs this kernel spilled inside the k loop): the per-token /
+// per-channel scales are applied in the epilogue (F_SCALE), the instruction is used for its K = 128 rate (2x bf16).
 __device__ __forceinline__ p8_v8i p8_cat(const bf16x8_t& lo, const bf16x8_t& hi) {
     return __builtin_shufflevector(__builtin_bit_cast(p8_v4i, lo), __builtin_bit_cast(p8_v4i, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }

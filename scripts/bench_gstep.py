@@ -8,6 +8,12 @@ from adv_grpo_amd.scheduler import FlowMatchEulerDiscreteScheduler
 cfg = MMDiTConfig()
 with synthetic.on_device("cuda"):
     model = SD3TransformerLoRA(synthetic.mmdit_weights(cfg, 1234), cfg, "cuda")
+# what-if runs (results are wrong, timing only): "nowgrad" skips the adapter-gradient kernels, "serial" runs them in the chain
+mode = sys.argv[1] if len(sys.argv) > 1 else ""
+if mode == "nowgrad":
+    model._lora_wgrad = lambda *a, **k: None
+if mode == "serial":
+    model.overlap_wgrad = False
 G = 8
 sch = FlowMatchEulerDiscreteScheduler(device="cuda"); sch.set_timesteps(10)
 x = torch.randn(G, 1, 16, 64, 64, device="cuda").to(torch.bfloat16)
@@ -24,7 +30,7 @@ torch.cuda.synchronize(); dt = (time.time() - t0) / n
 # SURVEY 8d's count for a frozen base model: 1 forward + ~1 data-gradient pass of the Linears (no weight-gradient GEMM; the rank-32
 # adapter gradients are negligible) and forward + 2.5x forward for attention: 2 x 1.913 + 3.5 x 0.306 = 4.90 TFLOP per sample
 flop = (2 * 1.913 + 3.5 * 0.306) * 16
-print(f"G-step micro-batch (fwd+bwd, batch 16): {dt*1e3:.1f} ms  -> {flop/dt/1e3:.3f} PFLOP/s = {flop/dt/1e3/2.5:.3f} of the bf16 MFMA peak "
+print(f"[{mode or 'product'}] G-step micro-batch (fwd+bwd, batch 16): {dt*1e3:.1f} ms  -> {flop/dt/1e3:.3f} PFLOP/s = {flop/dt/1e3/2.5:.3f} of the bf16 MFMA peak "
       f"({flop:.1f} TFLOP per micro-step: 1 fwd + 1 dgrad of the Linears, fwd + bwd of attention)")
 print("log_prob", info["log_prob"][:3].tolist(), "peak mem GB", torch.cuda.max_memory_allocated() / 2**30)
 torch.cuda.synchronize(); t0 = time.time()
