@@ -48,6 +48,8 @@ SIGNATURES = {
                                  c_uint64, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int64, _P]),
     "advgrpo_sde_step_bwd": (c_int, [_P, _P, c_int, c_float, _P, c_int, _P, _P, c_int, c_float, _P, c_int, _P, _P,
                                      _P, c_int, c_int64, _P]),
+    "advgrpo_sde_step_bwd_kl": (c_int, [_P, _P, c_int, c_float, _P, c_int, _P, _P, c_int, c_float, _P, c_int, _P, _P, c_float,
+                                        _P, _P, _P, _P, c_int, c_int64, _P]),
     "advgrpo_group_advantage": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P]),
     "advgrpo_group_advantage_stats": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P]),
     "advgrpo_grpo_loss": (c_int, [_P, _P, _P, c_int, c_float, c_float, _P, _P, _P]),

@@ -125,12 +125,12 @@ __global__ __launch_bounds__(SDE_THREADS) void sde_step_kernel(
 
 // log_prob[b] = -(sum of block partials)/n ; partials summed in fixed order in f64
 __global__ void sde_finalize_kernel(const float* __restrict__ partial, int nblk, int64_t n,
-                                    float* __restrict__ out_log_prob, int B) {
+                                    float* __restrict__ out_log_prob, int B, float sign = -1.0f) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double s = 0.0;
     for (int i = 0; i < nblk; ++i) s += (double)partial[b * nblk + i];
-    out_log_prob[b] = (float)(-(s / (double)n));
+    out_log_prob[b] = (float)((double)sign * (s / (double)n));
 }
 
 __global__ __launch_bounds__(SDE_THREADS) void sde_step_bwd_kernel(
@@ -138,7 +138,9 @@ __global__ __launch_bounds__(SDE_THREADS) void sde_step_bwd_kernel(
     const void* __restrict__ x, int x_dt, const float* __restrict__ sigma,
     const float* __restrict__ sigma_prev, int sigma_stride, float sin_coeff,
     const void* __restrict__ prev, int prev_dt, const float* __restrict__ grad_lp,
-    void* __restrict__ g_u, void* __restrict__ g_t, int64_t n) {
+    void* __restrict__ g_u, void* __restrict__ g_t, int64_t n,
+    const float* __restrict__ mean_ref, float kl_weight, int B, float* __restrict__ kl_partial) {
+    __shared__ float red[SDE_THREADS / 64];
     const int b = blockIdx.y;
     const SdeCoef c = sde_coef(sigma, sigma_prev, sigma_stride, b, sin_coeff);
     const bool has_cfg = v_t != nullptr, bf = v_dt == ADVGRPO_BF16;
@@ -146,9 +148,14 @@ __global__ __launch_bounds__(SDE_THREADS) void sde_step_bwd_kernel(
     // d mean / d v, and d log_prob / d mean = 2 (prev - mean) / n
     const float dmu_dv = c.one_m_sigma * c.sq - c.sigma * c.one_m_sigma_prev;
     const float scale = grad_lp[b] * 2.0f / (float)n * dmu_dv;
+    // KL term (TP:1105-1108,1126-1130): loss += beta * mean_b mean_elem (mean - mean_ref)^2, mean_ref = the same step's mean
+    // under the adapter-free transformer; d/d mean = beta * 2 (mean - mean_ref) / (n B), then the same d mean / d v
+    const float kl_scale = mean_ref ? kl_weight * 2.0f / ((float)n * (float)B) * dmu_dv : 0.f;
+    float kl_acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * SDE_CHUNK + threadIdx.x * SDE_VEC; i < n;
          i += (int64_t)gridDim.x * SDE_CHUNK) {
-        float vu[8], vt[8], xs[8], pv[8], gu[8], gt[8];
+        float vu[8], vt[8], xs[8], pv[8], gu[8], gt[8], mr[8];
+        if (mean_ref) load8(mean_ref, ADVGRPO_F32, base + i, mr);
         load8(v_u, v_dt, base + i, vu);
         if (has_cfg) load8(v_t, v_dt, base + i, vt);
         load8(x, x_dt, base + i, xs);
@@ -160,12 +167,21 @@ __global__ __launch_bounds__(SDE_THREADS) void sde_step_bwd_kernel(
             const float x1 = xs[k] + v * c.one_m_sigma;
             const float mean = x0 * c.one_m_sigma_prev + x1 * c.sq;
             float gv = scale * (pv[k] - mean);
-            if (bf) gv = round_bf16(gv);  // autograd hands the f32 grad back through .float()
+            if (mean_ref) {
+                const float d = mean - mr[k];
+                gv += kl_scale * d;
+                kl_acc += d * d;
+            }
+            if (bf) gv = round_bf16(gv);  // autograd hands the (summed) f32 grad back through .float()
             gu[k] = has_cfg ? (1.0f - guidance) * gv : gv;
             gt[k] = guidance * gv;
         }
         store8(g_u, v_dt, base + i, gu);
         if (has_cfg) store8(g_t, v_dt, base + i, gt);
+    }
+    if (mean_ref) {      // per-sample KL value: block partials, summed in fixed order by sde_finalize_kernel
+        const float tot = block_sum<SDE_THREADS / 64>(kl_acc, red);
+        if (threadIdx.x == 0) kl_partial[b * gridDim.x + blockIdx.x] = tot;
     }
 }
 
@@ -242,7 +258,30 @@ extern "C" int advgrpo_sde_step_bwd(const void* v_uncond, const void* v_text, in
     ADVGRPO_CHECK(!v_text || grad_v_text, "sde_step_bwd: CFG needs grad_v_text");
     hipLaunchKernelGGL(sde_step_bwd_kernel, dim3(sde_blocks(n), B), dim3(SDE_THREADS), 0, as_stream(stream),
                        v_uncond, v_text, v_dtype, guidance_scale, x, x_dtype, sigma, sigma_prev, sigma_stride,
-                       sin_coeff, prev_sample, prev_dtype, grad_log_prob, grad_v_uncond, grad_v_text, n);
+                       sin_coeff, prev_sample, prev_dtype, grad_log_prob, grad_v_uncond, grad_v_text, n,
+                       (const float*)nullptr, 0.f, B, (float*)nullptr);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_sde_step_bwd_kl(const void* v_uncond, const void* v_text, int v_dtype, float guidance_scale,
+                                       const void* x, int x_dtype, const float* sigma, const float* sigma_prev,
+                                       int sigma_stride, float sin_coeff, const void* prev_sample, int prev_dtype,
+                                       const float* grad_log_prob, const float* mean_ref, float kl_weight,
+                                       void* grad_v_uncond, void* grad_v_text, float* kl_out, void* workspace, int B,
+                                       int64_t n, void* stream) {
+    if (check_common(v_dtype, x_dtype, B, n)) return -1;
+    ADVGRPO_CHECK(v_uncond && x && sigma && sigma_prev && prev_sample && grad_log_prob && grad_v_uncond && mean_ref &&
+                      kl_out && workspace, "sde_step_bwd_kl: null argument");
+    ADVGRPO_CHECK(!v_text || grad_v_text, "sde_step_bwd_kl: CFG needs grad_v_text");
+    const int nb = sde_blocks(n);
+    hipLaunchKernelGGL(sde_step_bwd_kernel, dim3(nb, B), dim3(SDE_THREADS), 0, as_stream(stream), v_uncond, v_text,
+                       v_dtype, guidance_scale, x, x_dtype, sigma, sigma_prev, sigma_stride, sin_coeff, prev_sample,
+                       prev_dtype, grad_log_prob, grad_v_uncond, grad_v_text, n, mean_ref, kl_weight, B,
+                       (float*)workspace);
+    ADVGRPO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sde_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream),
+                       (const float*)workspace, nb, n, kl_out, B, 1.0f);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

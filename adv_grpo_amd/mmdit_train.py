@@ -214,6 +214,27 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                     b[gk + ".w"] = wx
                     b[gk + ".A"] = A_cat
 
+    # ------------------------------------------------------------------ the adapter-free transformer (KL reference)
+    @torch.no_grad()
+    def forward_reference(self, hidden_states, timestep, encoder_hidden_states, pooled_projections):
+        """The forward under PEFT's `disable_adapter()` (TP:1105-1108: the reference policy of the KL term): the rollout
+        forward on the base weights of the adapted projections.  Returns v [B,16,h,w] bf16."""
+        saved = []
+        for i, b in enumerate(self.blocks):
+            for gk, (base, _) in self._base_T[i].items():
+                keys = [gk + ".w"] + ([gk + ".A"] if gk + ".A" in b else [])
+                saved.append((b, {k: b[k] for k in keys}))
+                b[gk + ".w"] = base
+                b.pop(gk + ".A", None)          # side mode: no side columns -> the plain [rows, D] input
+        ext, self.lora_ext = self.lora_ext, (0, 0)
+        try:
+            (v,) = SD3Transformer2DModel.__call__(self, hidden_states, timestep, encoder_hidden_states, pooled_projections)
+        finally:
+            self.lora_ext = ext
+            for b, kv in saved:
+                b.update(kv)
+        return v
+
     # ------------------------------------------------------------------ forward with saved activations
     @torch.no_grad()
     def forward_train(self, hidden_states, timestep, encoder_hidden_states, pooled_projections):

@@ -536,8 +536,9 @@ class Trainer:
                                              s["advantages"][:, j], guidance_scale=c.sample.guidance_scale,
                                              noise_level=c.sample.noise_level, adv_clip_max=c.train.adv_clip_max,
                                              clip_range=c.train.clip_range, loss_scale=1.0 / (GA * T),
-                                             step_index=samples["first_step_index"][i] + j)
-                    for k in ("loss", "approx_kl", "clipfrac", "clipfrac_gt_one", "clipfrac_lt_one", "policy_loss"):
+                                             step_index=samples["first_step_index"][i] + j, beta=c.train.beta)
+                    for k in ("loss", "approx_kl", "clipfrac", "clipfrac_gt_one", "clipfrac_lt_one", "policy_loss") + \
+                            (("kl_loss",) if c.train.beta > 0 else ()):                     # TP:1158-1160
                         agg[k] = agg.get(k, 0) + info[k]
                     n_acc += 1
                 if (i + 1) % GA == 0:                                                       # sync_gradients, TP:1166-1185

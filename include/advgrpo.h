@@ -79,6 +79,17 @@ int advgrpo_sde_step_bwd(const void* v_uncond, const void* v_text, int v_dtype, 
                          const float* sigma, const float* sigma_prev, int sigma_stride, float sin_coeff,
                          const void* prev_sample, int prev_dtype, const float* grad_log_prob,
                          void* grad_v_uncond, void* grad_v_text, int B, int64_t n, void* stream);
+/* The same backward with the KL term of TP:1105-1108,1126-1130 (config.train.beta > 0):
+ *   loss += kl_weight * mean_b mean_elem (mean - mean_ref)^2,
+ * mean_ref [B, n] f32 = prev_sample_mean of the same step under the adapter-free transformer (advgrpo_sde_step's out_mean of
+ * that forward).  The KL gradient joins the policy gradient before the bf16 rounding autograd applies once to their sum.
+ * kl_out[b] = mean_elem (mean - mean_ref)^2 (partials through `workspace`, advgrpo_sde_step_workspace_bytes, fixed order). */
+int advgrpo_sde_step_bwd_kl(const void* v_uncond, const void* v_text, int v_dtype, float guidance_scale,
+                            const void* x, int x_dtype, const float* sigma, const float* sigma_prev,
+                            int sigma_stride, float sin_coeff, const void* prev_sample, int prev_dtype,
+                            const float* grad_log_prob, const float* mean_ref, float kl_weight,
+                            void* grad_v_uncond, void* grad_v_text, float* kl_out, void* workspace, int B,
+                            int64_t n, void* stream);
 
 /* ------------------------------------------------------------------ group advantage
  * PerPromptStatTracker.update(type='grpo') on a fresh tracker -- adv_grpo/stat_tracking.py:18-47:

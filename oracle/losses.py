@@ -30,6 +30,11 @@ def grpo_loss(log_prob, old_log_prob, advantages, adv_clip_max, clip_range):
     return policy_loss, info
 
 
+def kl_loss(prev_sample_mean, prev_sample_mean_ref):
+    """train_sd3_fast_pickscore.py:1126-1128 (the live line: no division by 2 std_dev_t^2)."""
+    return torch.mean(((prev_sample_mean - prev_sample_mean_ref) ** 2).mean(dim=(1, 2, 3), keepdim=True))
+
+
 def clip_pair_loss(text_features, image_0_features, image_1_features, logit_scale):
     """CLIPCriterion.calc_loss with label_0=1 (real), label_1=0 (fake), no in-batch negatives
     (pick_score_training.py:137-199): 2-way CE on the diagonal text->image logits.

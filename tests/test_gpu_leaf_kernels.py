@@ -113,6 +113,60 @@ def test_sde_step_backward_matches_autograd(dev):
         assert (gu.cpu().float() - vu_r.grad.float()).abs().max().item() <= tol * scale
 
 
+def test_sde_step_backward_with_kl_term_matches_autograd(dev):
+    """config.train.beta > 0 (TP:1105-1108,1126-1130): loss = sum_b glp_b log_prob_b + w * mean_b mean_elem (mean - mean_ref)^2;
+    gradient w.r.t. both CFG halves and the per-sample KL value against torch autograd on the oracle's SDE step."""
+    from adv_grpo_amd import _lib
+    from adv_grpo_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from oracle import losses as o_loss
+    from oracle import sde as o_sde
+    from oracle.scheduler import FlowMatchEulerScheduler
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(6)
+    B, shape, w = 4, (4, 16, 16, 16), 0.37
+    for dt in (torch.float32, torch.bfloat16):
+        vu, vt, ru, rt, x = (torch.randn(shape, generator=g).to(dt) for _ in range(5))
+        prev = (x.float() + 0.1 * torch.randn(shape, generator=g)).to(dt)
+        glp = torch.randn(B, generator=g) * 1e-3          # (policy and KL gradients of the same order)
+        osch = FlowMatchEulerScheduler(); osch.set_timesteps(10)
+        step = lambda a, b: o_sde.sde_step_with_logprob(osch, o_sde.cfg_combine(a, b, 4.5).float(), osch.timesteps[1].repeat(B),
+                                                        x.float(), 0.8, prev_sample=prev.float())
+        with torch.no_grad():
+            _, _, mean_ref, _ = step(ru, rt)
+        vu_r = vu.clone().requires_grad_(True); vt_r = vt.clone().requires_grad_(True)
+        _, lp, mean, _ = step(vu_r, vt_r)
+        kl_ref = ((mean - mean_ref) ** 2).mean(dim=(1, 2, 3))
+        ((lp * glp).sum() + w * o_loss.kl_loss(mean, mean_ref)).backward()
+        sch = FlowMatchEulerDiscreteScheduler(device=dev); sch.set_timesteps(10)
+        gu = torch.empty(shape, dtype=dt, device=dev); gt = torch.empty(shape, dtype=dt, device=dev)
+        kl = torch.empty(B, dtype=torch.float32, device=dev)
+        n = vu[0].numel()
+        ws = torch.empty(max(1, lib.advgrpo_sde_step_workspace_bytes(B, n) // 4), dtype=torch.float32, device=dev)
+        a = [t_.to(dev).contiguous() for t_ in (vu, vt, x, prev, glp, mean_ref.float())]
+        _lib.check(lib.advgrpo_sde_step_bwd_kl(_lib.ptr(a[0]), _lib.ptr(a[1]), _lib.dtype_code(dt), 4.5, _lib.ptr(a[2]),
+                                               _lib.dtype_code(dt), _lib.ptr(sch.sigmas[1:2]), _lib.ptr(sch.sigmas[2:3]), 0,
+                                               float(math.sin(0.8 * math.pi / 2)), _lib.ptr(a[3]), _lib.dtype_code(dt),
+                                               _lib.ptr(a[4]), _lib.ptr(a[5]), w, _lib.ptr(gu), _lib.ptr(gt), _lib.ptr(kl),
+                                               _lib.ptr(ws), B, n, _lib.stream_ptr()))
+        tol = 1e-5 if dt == torch.float32 else 2e-2     # bf16: autograd itself rounds the summed gradient to bf16
+        scale = vt_r.grad.float().abs().max().item()
+        assert (gt.cpu().float() - vt_r.grad.float()).abs().max().item() <= tol * scale
+        assert (gu.cpu().float() - vu_r.grad.float()).abs().max().item() <= tol * scale
+        assert torch.allclose(kl.cpu(), kl_ref.detach(), rtol=2e-5 if dt == torch.float32 else 2e-2)
+        # and with weight 0 the policy-only entry point is reproduced bit for bit
+        gu0 = torch.empty_like(gu); gt0 = torch.empty_like(gt)
+        _lib.check(lib.advgrpo_sde_step_bwd(_lib.ptr(a[0]), _lib.ptr(a[1]), _lib.dtype_code(dt), 4.5, _lib.ptr(a[2]),
+                                            _lib.dtype_code(dt), _lib.ptr(sch.sigmas[1:2]), _lib.ptr(sch.sigmas[2:3]), 0,
+                                            float(math.sin(0.8 * math.pi / 2)), _lib.ptr(a[3]), _lib.dtype_code(dt),
+                                            _lib.ptr(a[4]), _lib.ptr(gu0), _lib.ptr(gt0), B, n, _lib.stream_ptr()))
+        _lib.check(lib.advgrpo_sde_step_bwd_kl(_lib.ptr(a[0]), _lib.ptr(a[1]), _lib.dtype_code(dt), 4.5, _lib.ptr(a[2]),
+                                               _lib.dtype_code(dt), _lib.ptr(sch.sigmas[1:2]), _lib.ptr(sch.sigmas[2:3]), 0,
+                                               float(math.sin(0.8 * math.pi / 2)), _lib.ptr(a[3]), _lib.dtype_code(dt),
+                                               _lib.ptr(a[4]), _lib.ptr(a[5]), 0.0, _lib.ptr(gu), _lib.ptr(gt), _lib.ptr(kl),
+                                               _lib.ptr(ws), B, n, _lib.stream_ptr()))
+        assert torch.equal(gu, gu0) and torch.equal(gt, gt0)
+
+
 def test_philox_noise_statistics_and_reproducibility(dev):
     from adv_grpo_amd import _lib
     lib = _lib.load()

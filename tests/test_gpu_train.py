@@ -189,6 +189,66 @@ def test_g_step_chain_log_prob_loss_backward_adamw():
     assert model.ema is not None
 
 
+def test_g_step_with_kl_term_vs_autograd():
+    """config.train.beta > 0 (TP:1105-1108,1126-1130): the second forward runs under disable_adapter(), the loss gains
+    beta * mean((prev_sample_mean - prev_sample_mean_ref)^2).  LoRA gradients and the logged kl_loss against fp32 autograd
+    through the oracle; beta large enough for the KL gradient to dominate (the policy part is checked above)."""
+    from adv_grpo_amd import g_step
+    from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
+    from adv_grpo_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from oracle import lora as o_lora
+    from oracle import losses as o_loss
+    from oracle import mmdit as o
+    from oracle import rollout as o_roll
+    from oracle.scheduler import FlowMatchEulerScheduler
+    cfg = o.MMDiTConfig(num_layers=3, num_heads=4, joint_attention_dim=128, pooled_projection_dim=64,
+                        pos_embed_max_size=96, dual_attention_layers=(0,))
+    G, beta = 4, 0.5
+    W, lora, _, _, _, _, g = _setup(cfg, 43, B=2 * G, hw=16, Nt=13)
+    # adapters that have moved well away from the base model: the KL value is a mean of SQUARED differences of two bf16
+    # velocities, so rounding noise adds to it (E[(d + e1 - e2)^2] = d^2 + 2 var e); with the small adapters of the other
+    # tests that bias is 10 % of the value (in the reference's bf16 autocast just the same), here it is below 1 %
+    lora = {k: 2.0 * v for k, v in lora.items()}
+    sch = FlowMatchEulerDiscreteScheduler(device="cuda"); sch.set_timesteps(10)
+    osch = FlowMatchEulerScheduler(); osch.device = "cuda"; osch.set_timesteps(10)
+    x = torch.randn(G, 16, 16, 16, generator=g).to(torch.bfloat16)
+    nxt = (x.float() * 0.95 + 0.3 * torch.randn(G, 16, 16, 16, generator=g)).to(torch.bfloat16)
+    embeds = torch.randn(2 * G, 13, 128, generator=g).to(torch.bfloat16)
+    pooled = torch.randn(2 * G, 64, generator=g).to(torch.bfloat16)
+    adv = torch.randn(G, generator=g)
+    sample = {"latents": x[:, None].cuda(), "next_latents": nxt[:, None].cuda(), "timesteps": sch.timesteps[1].repeat(G)[:, None]}
+    for mode in ("merged", "side"):
+        model = SD3TransformerLoRA(W, cfg, "cuda", lora_state=lora, lora_mode=mode)
+        W32 = {k: t.float().cuda() for k, t in W.items()}
+        lo = {k: t.cuda().requires_grad_(True) for k, t in lora.items()}
+        run = lambda weights: o_roll.compute_log_prob(
+            lambda xx, tt, cc, pp: o.mmdit_forward(weights, cfg, xx.float(), tt, cc.float(), pp.float()), osch, sample, 0,
+            embeds.cuda(), pooled.cuda(), guidance_scale=4.5, noise_level=0.8)
+        with torch.no_grad():
+            _, _, mean_ref, _ = run(W32)                                                    # disable_adapter()
+        _, lp_ref, mean, _ = run(o_lora.effective_weights(W32, lo))
+        kl_ref = o_loss.kl_loss(mean, mean_ref)
+        pl_ref, _ = o_loss.grpo_loss(lp_ref, lp_ref.detach(), adv.cuda(), 5, 1e-4)
+        (pl_ref + beta * kl_ref).backward()
+        probe = g_step.micro_step(model, sch, sample, 0, embeds.cuda(), pooled.cuda(), lp_ref.detach(), adv.cuda(),
+                                  guidance_scale=4.5, noise_level=0.8, adv_clip_max=5, clip_range=1e-4)
+        model.grads.zero_()
+        info = g_step.micro_step(model, sch, sample, 0, embeds.cuda(), pooled.cuda(), probe["log_prob"], adv.cuda(),
+                                 guidance_scale=4.5, noise_level=0.8, adv_clip_max=5, clip_range=1e-4, beta=beta)
+        print(mode, "kl_loss", float(info["kl_loss"]), "oracle", float(kl_ref.detach()))
+        kl_ref = float(kl_ref.detach())
+        assert abs(float(info["kl_loss"]) - kl_ref) <= 5e-2 * kl_ref     # bf16 transformer vs fp32 oracle
+        assert abs(float(info["loss"]) - float(info["policy_loss"]) - beta * float(info["kl_loss"])) < 1e-6
+        grads = model.lora_grads()
+        cs = [_cos(grads[k], lo[k].grad) for k in grads if lo[k].grad.norm() > 0]
+        print(mode, "G-step with KL, LoRA-grad cosines: min", min(cs), "mean", sum(cs) / len(cs))
+        assert min(cs) > 0.9 and sum(cs) / len(cs) > 0.97
+        # the adapter-free forward left the model as it was
+        again = g_step.micro_step(model, sch, sample, 0, embeds.cuda(), pooled.cuda(), probe["log_prob"], adv.cuda(),
+                                  guidance_scale=4.5, noise_level=0.8, adv_clip_max=5, clip_range=1e-4)
+        assert torch.equal(again["log_prob"], probe["log_prob"])
+
+
 def test_dino_d_step_vs_reference_golden_and_autograd():
     """train_dino (TD:156-232): loss / accuracy / Adam-updated head against the golden made by running the
     reference function (tests/golden/losses.npz 'dino/*'), on its stand-in features."""

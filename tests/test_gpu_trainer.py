@@ -61,6 +61,24 @@ def test_pickscore_variant_g_step():
     assert b["phase"] == "G" and not torch.equal(model.params, p0) and torch.isfinite(model.params).all()
 
 
+def test_g_step_epoch_with_kl_term_logs_kl_loss():
+    """config.train.beta > 0 through the epoch loop (TP:1105-1108,1126-1130,1158-1160): a second epoch, after the adapters
+    have moved, logs a positive kl_loss and loss = policy_loss + beta * kl_loss."""
+    tr_, model, _ = _build("pickscore", train_d=False)
+    tr_.cfg.train.beta = 0.04
+    recs = []
+    log = tr_.logger.log
+    tr_.logger.log = lambda rec, step=None: (recs.append(dict(rec)), log(rec, step))[1]
+    tr_.run_epoch()
+    tr_.run_epoch()
+    steps = [r for r in recs if "kl_loss" in r]
+    assert steps, recs
+    first, last = steps[0], steps[-1]
+    assert float(first["kl_loss"]) < 1e-12                   # B = 0 at initialisation: the policy IS the reference
+    assert float(last["kl_loss"]) > 0.0 and torch.isfinite(torch.tensor(float(last["loss"])))
+    assert abs(float(last["loss"]) - float(last["policy_loss"]) - 0.04 * float(last["kl_loss"])) < 1e-5
+
+
 def test_pickscore_variant_d_step_gate():
     """mean(reference reward) < mean(generated reward) -> D-step on the CLIP scorer's last layer (TP:1025-1037)."""
     tr_, model, _ = _build("pickscore", train_d=True)
