@@ -238,14 +238,15 @@ static int launch_pair(const GemmParams& a, const GemmParams& b, hipStream_t s) 
 //   two-stage BK=64 kernel: 0 = 128x128 (4 waves), 1 = 128x64, 2 = 64x128, 15 = 128x128 (8 waves 4x2), 26 = 192x128;
 //   conv: 5 = 128x64, 18 = 128x128 (8 waves); 30 = the 256x256 eight-phase persistent kernel of gemm8p.hip.
 //   An experiments build (make EXPERIMENTS=1 -> libadvgrpo_experiments.so, never the product library) adds 14 / 27 (other
-//   wave grids), 4 (conv, 4 waves), 11 / 17 (BK=32 ring kernel), 20 / 21 / 23 (ping-pong kernel)
+//   wave grids), 4 (conv, 4 waves), 11 / 17 (BK=32 ring kernel), 20 / 21 / 23 (ping-pong kernel), 31 (experiments/gemm4w.hip)
 //   and the ADVGRPO_GEMM_* environment overrides used for in-situ A/B runs; the product library reads no environment.
 #ifdef ADVGRPO_EXPERIMENTS
 struct ExperimentKnobs {
-    int force = -1, no8p = 0, debug = 0, fn = -1, fk = 0, fv = 0;
+    int force = -1, no8p = 0, use4w = 0, debug = 0, fn = -1, fk = 0, fv = 0;
     ExperimentKnobs() {
         if (const char* e = getenv("ADVGRPO_GEMM_FORCE")) force = atoi(e);
         if (const char* e = getenv("ADVGRPO_GEMM_NO8P")) no8p = atoi(e) ? 1 : 0;
+        if (const char* e = getenv("ADVGRPO_GEMM_4W")) use4w = atoi(e);
         if (const char* e = getenv("ADVGRPO_GEMM_DEBUG")) debug = atoi(e);
         if (const char* e = getenv("ADVGRPO_GEMM_FORCE_NK")) sscanf(e, "%d:%d:%d", &fn, &fk, &fv);
     }
@@ -258,6 +259,9 @@ static int gemm_variant(int M, int N, int K, int batch, int conv, int plain) {  
 #ifdef ADVGRPO_EXPERIMENTS
     if (knobs().force >= 0) return conv ? (knobs().force == 18 ? 18 : 4) : knobs().force;
     if (knobs().force == -3) return conv ? 4 : 0;
+    if (plain && M >= 8192 && N >= 1024 && batch == 1 && !knobs().no8p && N % 256 == 0 &&
+        (knobs().use4w == 1 || (knobs().use4w == 2 && K <= 2048)))
+        return 31;
     if (knobs().no8p && plain && M >= 8192 && N >= 1024) return 26;
 #endif
     if (conv) return 18;
@@ -322,6 +326,8 @@ int gemm_bf16_pair(const GemmParams& a_in, const GemmParams& b_in, hipStream_t s
 #ifdef ADVGRPO_EXPERIMENTS
     if (pairable && va == 17) return launch_pipe_pair<256, 128, 3, 4, 2>(a, b, s);
     if (pairable && va == 27) return launch_pair<128, 192, 2, 4>(a, b, s);
+    if (pairable && va == 31 && gemm8p_ok(a) && gemm8p_ok(b) && a.N % 256 == 0 && b.N % 256 == 0 && a.K % 64 == 0 && b.K % 64 == 0)
+        return gemm4w_launch_pair(&a, &b, s);
 #endif
     if (pairable && va == 26) return launch_pair<192, 128, 4, 2>(a, b, s);
     if (pairable && va == 30) return gemm8p_launch_pair(a, b, s);
@@ -351,6 +357,9 @@ int gemm_bf16(const GemmParams& p_in, hipStream_t s) {
         case 21: return launch_pp<256, 128, 4, 4, 2>(p, s);
         case 23: return launch_pp<256, 128, 3, 4, 2>(p, s);
         case 27: return launch<128, 192, 2, 4, false>(p, s);
+        case 31:
+            if (gemm8p_ok(p) && p.N % 256 == 0 && p.K % 64 == 0) return gemm4w_launch_pair(&p, nullptr, s);
+            return launch<128, 128, 4, 2, false>(p, s);
 #endif
     }
     set_error("gemm: bad variant %d", variant);

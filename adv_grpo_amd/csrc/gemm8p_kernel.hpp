@@ -16,7 +16,7 @@ constexpr int P8_BM = 256, P8_BN = 256, P8_BK = 64;
 constexpr int P8_HALF = 128 * P8_BK * 2;          // one ring item: 128 rows x 128 B
 constexpr int P8_BUF = 4 * P8_HALF;               // one k-tile buffer: A sub 0, A sub 1, W sub 0, W sub 1
 constexpr int P8_LDS = 2 * P8_BUF;                // 128 KiB
-constexpr int P8_SCRATCH = 2 * 16 * 64 * 4;       // per-wave scratch of the LDS-bounce epilogue: 2 slabs of 16 rows x 64 f32, inside buffer 1
+constexpr int P8_SCRATCH = 2 * 16 * 64 * 4;       // per-wave epilogue scratch: 2 slabs of 16 rows x 64 f32, inside buffer 1
 
 // One LDS-DMA instruction: 64 lanes x 16 bytes from (uniform base + per-lane 32-bit offset) to LDS [m0 .. m0 + 1 KiB).
 // Hand-written because the builtin form keeps every per-lane source as a 64-bit VGPR pair and re-adds the k offset on the
@@ -58,7 +58,7 @@ struct P8Tile {
     uint32_t a_off[2][2], b_off[2][2];
 };
 
-__device__ __forceinline__ void p8_setup(P8Tile& t, const GemmParams& pr, int id, int wave, bool perm_w) {
+__device__ __forceinline__ void p8_setup(P8Tile& t, const GemmParams& pr, int id, int wave) {
     const GemmParams* p = &pr;
     const int lane = p8_lane();
     const int tiles_n = (p->N + P8_BN - 1) / P8_BN, tiles_m = (p->M + P8_BM - 1) / P8_BM;
@@ -71,10 +71,7 @@ __device__ __forceinline__ void p8_setup(P8Tile& t, const GemmParams& pr, int id
     const int es = p->fp8 ? 1 : 2;                 // operand element size: a k-tile is 128 BYTES per row either way (64 bf16 / 128 fp8)
     t.nk = p->K * es / (P8_BK * 2);
     const int lrow = lane >> 3;                   // row inside an 8-row DMA instruction
-    const int schunk = (lane & 7) ^ lrow;         // pre-swizzled source chunk of this lane's LDS slot (A items: row & 7)
-    // W items: the fragment reads walk the slot rows in the order of p8_wrow (below), so the chunk swizzle of slot row sr is
-    // (sr & 3) | ((sr >> 3) & 1) << 2 -- eight distinct values over the eight rows a group of fragment lanes reads
-    const int schunk_w = perm_w ? (lane & 7) ^ ((lrow & 3) | ((wave & 1) << 2)) : schunk;   // ((sr >> 3) & 1 = (wave + 8 it) & 1)
+    const int schunk = (lane & 7) ^ lrow;         // pre-swizzled source chunk of this lane's LDS slot
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -90,7 +87,7 @@ __device__ __forceinline__ void p8_setup(P8Tile& t, const GemmParams& pr, int id
             t.a_off[sub][it] = (uint32_t)(ar * p->lda * es + schunk * 16);
             int n = t.n0 + (sr >> 5) * 64 + sub * 32 + (sr & 31);
             n = n < p->N ? n : p->N - 1;
-            t.b_off[sub][it] = (uint32_t)((int64_t)n * p->ldw * es + schunk_w * 16);
+            t.b_off[sub][it] = (uint32_t)((int64_t)n * p->ldw * es + schunk * 16);
         }
 }
 
@@ -155,9 +152,6 @@ __device__ __forceinline__ void p8_gst16(p8_gptr base, size_t byte_off, const ui
 __device__ __forceinline__ void p8_gst16_nt(p8_gptr base, size_t byte_off, const uint4& v) {
     __builtin_nontemporal_store(p8_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<__attribute__((address_space(1))) p8_u32x4*>(base + byte_off));
 }
-#ifndef P8_STORE_C
-#define P8_STORE_C p8_gst16_nt
-#endif
 // a value pinned into scalar registers (opaque to the optimiser from here on)
 template <class T>
 __device__ __forceinline__ T p8_sgpr(T v) {
@@ -209,7 +203,7 @@ __device__ __forceinline__ P8EpiArgs p8_epi_args(const GemmParams& g) {
 }
 
 template <int EPI>
-__device__ __forceinline__ void p8_epilogue_lds(const GemmParams& p_in, f32x4 (&acc)[8][4], int mw0, int nw0, char* scratch) {
+__device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)[8][4], int mw0, int nw0, char* scratch) {
     const int lane = p8_lane();
     constexpr bool G = EPI == EPI_GENERIC;
     const P8EpiArgs p = p8_epi_args<EPI>(p_in);
@@ -449,292 +443,6 @@ __device__ __forceinline__ void p8_epilogue_lds(const GemmParams& p_in, f32x4 (&
     });
 }
 
-
-// Which classes take the register path below instead of the LDS bounce above.  Measured per class (tile to tile, 16384 rows,
-// K = 1536, s_memtime; scripts/p8_stamps.py): bias + QK-norm 74.0 k -> 70.2 k, bias + GELU 73.1 k -> 69.7 k; bias alone
-// 66.3 k -> 69.3 k and bias + gate + residual 79.0 k -> 81.2 k: a lane group of the register path touches 64 bytes of a row
-// per instruction (the bounce: 128), twice the requests for the same lines, and the memory-bound classes lose more there
-// than they gain from the missing LDS traffic.  The G-step classes (aux reads / writes: memory-bound too) stay on the bounce.
-template <int EPI>
-constexpr bool p8_reg_epilogue() { return EPI != EPI_GENERIC && (EPI & (F_RMS | F_GELU)) != 0 && (EPI & (F_GATE_RES | F_AUX_OUT | F_DGELU)) == 0; }
-
-// Fused epilogue, register path (round 3).  Same arithmetic, in the same order, as gemm_epilogue_rows (gemm_device.hpp) and
-// as the LDS-bounce version above -- results stay bit-identical to the other tile variants -- but the accumulators
-// never leave the registers:
-//   * in the MFMA accumulator layout lane (mrow = lane & 15, q = lane >> 4) of block (i, j) holds row i*16 + mrow and four
-//     consecutive n-positions q*4 .. +3 of the block.  Which output COLUMN an n-position is depends only on which W row the
-//     fragment lane of that position read: the k loop reads the W rows of a 32-column sub-tile in the order
-//     position t of block jj <- row (t >> 2)*8 + jj*4 + (t & 3), so a block PAIR leaves every lane with 8 consecutive columns
-//     of its row (q*8 .. +3 from the first block, +4 .. +7 from the second) at no cost: no LDS bounce (32 ds_write_b128 +
-//     32 ds_read_b128 per wave tile, 512 KiB through the LDS pipe per tile, and the workgroup barrier that guarded the
-//     scratch), no lane swaps (64 v_permlane16_swap per wave tile were measured SLOWER than the bounce for the bias class);
-//   * the four lanes of a row cover 32 consecutive columns: a 16-byte access per lane is 64 contiguous bytes per row, the
-//     two column halves p = 0, 1 complete the 128-byte line;
-//   * a lane owns ONE row per 16-row slab (8 row computations per tile instead of 16 passes) and two fixed 8-column groups
-//     (bias / QK-norm weights / fp8 column scales: loaded once per tile);
-//   * the QK-norm's sum of squares keeps the summation tree of the row epilogues (8-column chunks summed in order, then
-//     chunk pairs (0,1)(2,3).. , then quads, then halves): a lane holds chunks q and 4 + q of its row, the partner chunks
-//     sit 16 and 32 lanes away (v_permlane16_swap / v_permlane32_swap adds).
-// Kept from the previous version: options fixed at compile time (EPI classes), the per-tile problem description in pinned
-// SGPRs, branch-free row-segment / gate cursors, unconditional prefetch of residual rows and gate vectors AHEAD slabs
-// ahead, arithmetic on explicit column pairs, streaming stores.
-template <int EPI>
-__device__ __forceinline__ void p8_epilogue_reg(const GemmParams& p_in, f32x4 (&acc)[8][4], int mw0, int nw0) {
-    const int lane = p8_lane();
-    constexpr bool G = EPI == EPI_GENERIC;
-    const P8EpiArgs p = p8_epi_args<EPI>(p_in);
-    // features: compile-time constants in the specialised classes (bf16 output, alpha = 1 is NOT assumed)
-    const bool has_bias = G ? p.bias != nullptr : (EPI & F_BIAS) != 0;
-    const bool has_rms = G ? p.rms_w != nullptr : (EPI & F_RMS) != 0;
-    const bool has_gate = G ? p.gate != nullptr : (EPI & F_GATE_RES) != 0;
-    const bool has_res = G ? p.residual != nullptr : (EPI & F_GATE_RES) != 0;
-    const bool has_aux_out = G ? p.aux_out != nullptr : (EPI & F_AUX_OUT) != 0;
-    const bool has_scale = G ? false : (EPI & F_SCALE) != 0;   // (fp8 operands run on specialised classes only)
-    const bool out_bf16 = G ? p.out_dtype == ADVGRPO_BF16 : true;
-    const int mrow = lane & 15, q = lane >> 4;
-    // this lane's two 8-column groups (h = 0, 1): columns h * 32 + q * 8 .. +7 of the wave tile
-    const int n0 = nw0 + q * 8;
-    const int ncol[2] = {n0, n0 + 32};
-    const bool n_ok[2] = {ncol[0] < p.N, ncol[1] < p.N};
-    // bf16 pair in a dword -> two f32 (shift / mask), and back with the hardware conversion (round-to-nearest-even)
-    auto up2 = [](uint32_t w) __attribute__((always_inline)) {
-        return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
-    };
-    auto unpack4 = [&](const uint4& q4, f32x2 (&f)[4]) __attribute__((always_inline)) {
-        f[0] = up2(q4.x); f[1] = up2(q4.y); f[2] = up2(q4.z); f[3] = up2(q4.w);
-    };
-    auto pk2 = [](f32x2 x) __attribute__((always_inline)) {
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2_t));
-    };
-    auto pack4 = [&](const f32x2 (&x)[4]) __attribute__((always_inline)) {
-        return uint4{pk2(x[0]), pk2(x[1]), pk2(x[2]), pk2(x[3])};
-    };
-    auto ld16 = [](p8_gcptr base, uint32_t elem) __attribute__((always_inline)) { return p8_gld16(base, elem * 2u); };
-    // alpha as ONE scalar register for the whole epilogue: left to the compiler the two problems' alphas of a paired launch
-    // sat in VGPRs, were spilled, and every pass reloaded both from scratch memory -- a memory operation whose
-    // s_waitcnt vmcnt(0) also drained the residual prefetch
-    const float alpha = p.alpha;
-    // QK-norm: the wave tile's 64 columns are ONE head -- its weight vector and whether it is normalised at all (q / k heads
-    // yes, v heads no) are fixed for the tile
-    f32x2 rms_w2[2][4];
-    bool rms_on = false;
-    const int hh = nw0 >> 6;
-    if (has_rms) {
-        rms_on = hh < p.rms_nheads && nw0 < p.N;
-        if (rms_on) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) unpack4(ld16(p.rms_w, (uint32_t)((hh / p.rms_hpw) * 64 + (ncol[h] - nw0))), rms_w2[h]);
-        }
-    }
-    f32x2 bias2[2][4];
-    if (has_bias) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            if (n_ok[h]) unpack4(ld16(p.bias, (uint32_t)ncol[h]), bias2[h]);
-    }
-    f32x2 wsc2[2][4];                            // fp8 operands: the per-output-channel scales of this lane's columns (f32)
-    if (has_scale) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            if (n_ok[h]) {
-                const uint4 s0 = p8_gld16(p.w_scale, (uint32_t)ncol[h] * 4u), s1 = p8_gld16(p.w_scale, (uint32_t)ncol[h] * 4u + 16u);
-                wsc2[h][0] = f32x2{__builtin_bit_cast(float, s0.x), __builtin_bit_cast(float, s0.y)};
-                wsc2[h][1] = f32x2{__builtin_bit_cast(float, s0.z), __builtin_bit_cast(float, s0.w)};
-                wsc2[h][2] = f32x2{__builtin_bit_cast(float, s1.x), __builtin_bit_cast(float, s1.y)};
-                wsc2[h][3] = f32x2{__builtin_bit_cast(float, s1.z), __builtin_bit_cast(float, s1.w)};
-            }
-    }
-    // wave-uniform bookkeeping of the slab's first row m_s: output row = seg_b * seg_stride + seg_off + seg_r (identity map:
-    // seg_rows = 0 -> one segment as long as M), gate vector = gate_b
-    const int seg_rows = p.seg_rows > 0 ? p.seg_rows : 0x7fffffff;
-    const int gate_rows = p.gate_rows > 0 ? p.gate_rows : 0x7fffffff;
-    const int seg_jump = p.seg_rows > 0 ? (int)p.seg_stride - p.seg_rows : 0;   // added to the row when it wraps
-    struct Cur { int seg_b, seg_r, gate_b, gate_r; };
-    auto start = [&](int m) __attribute__((always_inline)) {
-        Cur c;
-        c.seg_b = m / seg_rows; c.seg_r = m - c.seg_b * seg_rows;
-        c.gate_b = m / gate_rows; c.gate_r = m - c.gate_b * gate_rows;
-        return c;
-    };
-    // 16 rows further; segments / gate groups are at least 16 rows (gemm8p_ok): at most one wrap, done with scalar selects
-    // (as loops these were four real branches per slab, and a taken branch is an instruction-fetch bubble)
-    auto advance = [&](Cur& c) __attribute__((always_inline)) {
-        c.seg_r += 16;
-        const int ws = c.seg_r >= seg_rows ? 1 : 0;
-        c.seg_r -= ws ? seg_rows : 0;
-        c.seg_b += ws;
-        c.gate_r += 16;
-        const int wg = c.gate_r >= gate_rows ? 1 : 0;
-        c.gate_r -= wg ? gate_rows : 0;
-        c.gate_b += wg;
-    };
-    // output row of (slab cursor, row inside the slab)
-    // (segments and gate groups are at least a slab long, gemm8p_ok: a slab crosses at most one boundary)
-    auto out_row = [&](const Cur& c, int row) __attribute__((always_inline)) -> uint32_t {
-        const int base = p.seg_rows > 0 ? c.seg_b * (int)p.seg_stride + (int)p.seg_off + c.seg_r : c.seg_r;
-        return (uint32_t)(base + row + (seg_jump & -(int)(c.seg_r + row >= seg_rows)));
-    };
-    // what a slab needs from memory: this lane's residual row (two column groups), its gate vector and its fp8 row scale.
-    // The loads are UNCONDITIONAL (rows / columns past the edge read element 0 instead): with a load inside a branch the
-    // compiler can no longer count the younger memory operations and waits with vmcnt(0) -- which also waits for the
-    // prefetch it has just issued for the slab after next, so every slab paid a full memory latency (measured: 32 k
-    // cycles for the gate + residual epilogue against 15 k for bias + GELU).
-    struct Pre { uint4 r[2]; uint4 g[2]; float sa; };
-    auto prefetch = [&](const Cur& c, int i, Pre& f) __attribute__((always_inline)) {
-        const bool row_ok = mw0 + i * 16 + mrow < p.M;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            f.r[h] = uint4{0u, 0u, 0u, 0u};
-            if (has_res) {
-                const bool ok = row_ok && n_ok[h];
-                f.r[h] = ld16(p.residual, (__umul24(out_row(c, mrow), (uint32_t)p.ldr) + ncol[h]) & (0u - (uint32_t)ok));
-            }
-        }
-        f.sa = 1.0f;
-        if (has_scale) {     // per-token scale of the INPUT row (unconditional: rows past the end read row M - 1)
-            const int m_in = min(mw0 + i * 16 + mrow, p.M - 1);
-            f.sa = *reinterpret_cast<const __attribute__((address_space(1))) float*>(p.a_scale + (uint32_t)m_in * 4u);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            f.g[h] = uint4{0u, 0u, 0u, 0u};
-            if (has_gate) {     // (a row past the last one has no gate vector)
-                const bool ok = row_ok && n_ok[h];
-                const uint32_t gb = (uint32_t)(c.gate_b + (int)(c.gate_r + mrow >= gate_rows));
-                f.g[h] = ld16(p.gate, (__umul24(gb, (uint32_t)p.gate_stride) + ncol[h]) & (0u - (uint32_t)ok));
-            }
-        }
-    };
-    Cur cur = start(__builtin_amdgcn_readfirstlane(mw0)), cpre = cur;
-    constexpr int AHEAD = P8_EPI_AHEAD;       // slabs requested ahead of the one being written out
-    Pre f[AHEAD + 1];
-    prefetch(cpre, 0, f[0]);
-#pragma unroll
-    for (int a = 1; a < AHEAD; ++a) {
-        advance(cpre);
-        prefetch(cpre, a, f[a]);
-    }
-    const int act = G ? p.act : ((EPI & F_GELU) ? (int)ACT_GELU_TANH : ((EPI & F_DGELU) ? (int)ACT_DGELU_TANH : (int)ACT_NONE));
-    static_for<8>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const Pre& f0 = f[i % (AHEAD + 1)];
-        const Cur c0 = cur;
-        if constexpr (i + AHEAD < 8) {
-            advance(cpre);
-            prefetch(cpre, i + AHEAD, f[(i + AHEAD) % (AHEAD + 1)]);
-        }
-        // (the W rows entered the matrix unit in the order of p8_wrow: blocks 2h, 2h + 1 are columns +0..3, +4..7 of this lane's group h)
-        f32x2 v[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            v[h][0] = f32x2{acc[i][2 * h][0], acc[i][2 * h][1]}; v[h][1] = f32x2{acc[i][2 * h][2], acc[i][2 * h][3]};
-            v[h][2] = f32x2{acc[i][2 * h + 1][0], acc[i][2 * h + 1][1]}; v[h][3] = f32x2{acc[i][2 * h + 1][2], acc[i][2 * h + 1][3]};
-        }
-        const bool row_ok = mw0 + i * 16 + mrow < p.M;
-        const uint32_t orow = out_row(c0, mrow);
-        // (contraction off for the scale / bias / gate / residual steps: where a specialised class makes two of them
-        // unconditional the compiler would fuse them into an fma and the classes would stop agreeing bit for bit)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma clang fp contract(off)
-            if (has_scale) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[h][k] = (v[h][k] * f0.sa) * wsc2[h][k];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[h][k] = v[h][k] * alpha;
-            if (has_bias) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[h][k] = v[h][k] + bias2[h][k];
-            }
-        }
-        if (has_rms) {   // QK-norm: the wave tile's 64 columns are one head; this lane holds chunks c and c + 4 of its row
-            float sq[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                sq[h] = 0.f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    v[h][k] = up2(pk2(v[h][k]));             // the Linear's bf16 output is what gets normalised
-                    sq[h] += v[h][k].x * v[h][k].x;
-                    sq[h] += v[h][k].y * v[h][k].y;
-                }
-            }
-            // this lane's 8-column chunks: 4 h + q.  Tree of the row epilogues: (c0+c1)+(c2+c3) | (c4+c5)+(c6+c7): the neighbouring
-            // chunk is 16 lanes away, the neighbouring pair 32 (inline asm: the compiler's builtin for these swaps folds distinct
-            // calls into one on ROCm 7.2; asm statements are outside the hazard recogniser's view, hence the wait states)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float a = sq[h], b = sq[h];
-                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));   // (even row's, odd row's) on every lane
-                sq[h] = a + b;
-                a = sq[h]; b = sq[h];
-                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));   // (lower half's, upper half's)
-                sq[h] = a + b;
-            }
-            const float sqt = sq[0] + sq[1];
-            if (rms_on) {
-                const float rs = rsqrtf(sqt * (1.0f / 64.0f) + p.rms_eps);
-                if (p.rms_rs_out && q == 0 && row_ok)
-                    *reinterpret_cast<__attribute__((address_space(1))) float*>(p.rms_rs_out + ((size_t)orow * p.rms_nheads + hh) * 4) = rs;
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[h][k] = up2(pk2(v[h][k] * rs)) * rms_w2[h][k];
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (!row_ok || !n_ok[h]) continue;   // (unrolled: skips to the next column group)
-            const int n = ncol[h];
-            const uint32_t o_aux = __umul24(orow, (uint32_t)p.ld_aux) + n;
-            if (has_aux_out) p8_gst16(p.aux_out, (size_t)(o_aux * 2u), pack4(v[h]));
-            if ((G || (EPI & F_DGELU)) && act >= ACT_DGELU_TANH) {
-                f32x2 z[4];
-                unpack4(ld16(p.aux_in, o_aux), z);
-                if (act == ACT_DGELU_TANH) {
-                    dgelu_tanh_mul_pk4(v[h], z);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[h][k] = f32x2{v[h][k].x * dact_fn(z[k].x, act), v[h][k].y * dact_fn(z[k].y, act)};
-                }
-            } else if (act == ACT_GELU_TANH) {
-                gelu_tanh_pk4(v[h]);
-            } else if (act != ACT_NONE) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[h][k] = f32x2{act_fn(v[h][k].x, act), act_fn(v[h][k].y, act)};
-            }
-            if (has_gate) {
-                f32x2 g[4];
-                unpack4(f0.g[h], g);
-                {
-#pragma clang fp contract(off)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[h][k] = v[h][k] * g[k];
-                }
-            }
-            if (has_res) {
-                f32x2 r[4];
-                unpack4(f0.r[h], r);
-                {
-#pragma clang fp contract(off)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[h][k] = v[h][k] + r[k];
-                }
-            }
-            const uint32_t o = __umul24(orow, (uint32_t)p.ldc) + n;
-            if (out_bf16) {
-                P8_STORE_C(p.C, (size_t)(o * 2u), pack4(v[h]));
-            } else {
-                p8_gst16(p.C, (size_t)o * 4u, __builtin_bit_cast(uint4, make_float4(v[h][0].x, v[h][0].y, v[h][1].x, v[h][1].y)));
-                p8_gst16(p.C, (size_t)o * 4u + 16, __builtin_bit_cast(uint4, make_float4(v[h][2].x, v[h][2].y, v[h][3].x, v[h][3].y)));
-            }
-        }
-        advance(cur);
-    });
-}
-
 }  // namespace
 
 struct P8Sched { int tiles_a, tiles_total; unsigned long long* stamps; };   // stamps: experiment (ADVGRPO_P8_STAMPS)
@@ -755,7 +463,6 @@ __device__ __forceinline__ p8_v8i p8_cat(const bf16x8_t& lo, const bf16x8_t& hi)
 template <bool PAIR, int EPI, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const P8Sched sc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool REG = p8_reg_epilogue<EPI>();      // register-path epilogue: W rows enter the matrix unit in p8_wrow order
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;      // wave row (group) / wave column
     // this wave's fragment bases inside a k-tile buffer
@@ -771,8 +478,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
         const bool second = PAIR && id >= sc.tiles_a;
         if (second) id -= sc.tiles_a;
         t.second = second;
-        if (second) p8_setup(t, pp.b, id, wave, REG);
-        else p8_setup(t, pp.a, id, wave, REG);
+        if (second) p8_setup(t, pp.b, id, wave);
+        else p8_setup(t, pp.a, id, wave);
     };
     // the seven items the steady state would have issued before phase 0 of k-tile 0, in its order: A0 W0 W1 A1 of
     // k-tile 0 (buffer 0), then A0 W0 W1 of k-tile 1 (buffer 1)
@@ -810,19 +517,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
 
         // per-lane fragment offsets, recomputed per tile from an opaque copy of the lane id: kept live across the epilogue
         // they were spilled, and the reload's conservative s_waitcnt vmcnt(0) ended up INSIDE the k loop (draining the DMA)
-        // W fragments (p8_wrow): lane t of block j reads slot row (t >> 2) * 8 + j * 4 + (t & 3) of the sub-tile's 32, so that the
-        // accumulators of a block PAIR give every lane 8 consecutive output columns of its row (q * 8 .. +3 from block 0,
-        // +4 .. +7 from block 1) -- the transposition the row-wise epilogue needs, made by the ORDER in which W rows enter
-        // the matrix unit instead of an LDS bounce or lane swaps afterwards.  Same chunk swizzle term: (row & 3) | bit 3 = t & 7.
-        int frag_off[2], frag_off_w[2];
+        int frag_off[2];
         {
             const int l = p8_lane();
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int chunk = ((ks * 4 + (l >> 4)) ^ (l & 7)) << 4;
-                frag_off[ks] = (l & 15) * 128 + chunk;
-                frag_off_w[ks] = (REG ? ((l & 15) >> 2) * 8 + (l & 3) : (l & 15)) * 128 + chunk;
-            }
+            for (int ks = 0; ks < 2; ++ks) frag_off[ks] = (l & 15) * 128 + (((ks * 4 + (l >> 4)) ^ (l & 7)) << 4);
         }
         // the first two items must have landed for the first reads
         stamp(0);
@@ -844,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    b[ks][j] = *reinterpret_cast<const bf16x8_t*>(buf + b_base + sub * P8_HALF + j * (REG ? 4 : 16) * 128 + frag_off_w[ks]);
+                    b[ks][j] = *reinterpret_cast<const bf16x8_t*>(buf + b_base + sub * P8_HALF + j * 16 * 128 + frag_off[ks]);
         };
         // end of a load segment at global phase g (= 4 kt + ph): everything first read in phase g + 1 must have landed
         // (items 0 .. g + 2 of the issue order); 8 + g items have been issued (capped by n_items)
@@ -918,9 +617,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
         if (wr == 0) __builtin_amdgcn_s_barrier();       // matches group 1's stagger barrier: every ring read is complete
         stamp(2);
 
-        // ---- tile boundary: request the next tile's first k-tile (buffer 0), run the epilogue (LDS-bounce classes: through
-        // buffer 1), then request the rest of the next tile's pipeline fill.  (All seven items before a register-path
-        // epilogue would put 14 DMA loads in front of its first operand load, and loads return in order.)
+        // ---- tile boundary: request the next tile's first k-tile (buffer 0), run the epilogue through buffer 1, then
+        // request the rest of the next tile's pipeline fill
         const bool cur_second = t.second;
         const int mw0 = t.m0 + wr * 128, nw0 = t.n0 + wc * 64;
         const bool more = tile + nwg < sc.tiles_total;
@@ -931,15 +629,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmPair pp, const
         stamp(3);
         {
             const GemmParams& p = (PAIR && cur_second) ? pp.b : pp.a;
-            if constexpr (REG) p8_epilogue_reg<EPI>(p, acc, mw0, nw0);
-            else p8_epilogue_lds<EPI>(p, acc, mw0, nw0, smem + P8_BUF + wave * P8_SCRATCH);
+            p8_epilogue<EPI>(p, acc, mw0, nw0, smem + P8_BUF + wave * P8_SCRATCH);
         }
         stamp(4);
         if (more) {
-            if constexpr (!REG) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();             // every wave is done with its scratch in buffer 1
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                 // every wave is done with its scratch in buffer 1
             stamp(5);
             issue_second(t);
         }

@@ -451,6 +451,8 @@ bool gemm8p_ok(const GemmParams& p);
 int gemm8p_launch(const GemmParams& p, hipStream_t s);
 int gemm8p_launch_pair(const GemmParams& a, const GemmParams& b, hipStream_t s);
 #ifdef ADVGRPO_EXPERIMENTS
+// experiment (experiments/gemm4w.hip): the same wave tile in 4-wave workgroups, two per CU; b may be null
+int gemm4w_launch_pair(const GemmParams* a, const GemmParams* b, hipStream_t s);
 #endif
 
 }  // namespace advgrpo

@@ -14,7 +14,7 @@ GEMM_VARIANTS = {0: "gemm_bf16_kernel<128,128,2,2,false>", 1: "gemm_bf16_kernel<
                  17: "gemm_bf16_pipe_kernel<256,128,3,4,2>", 18: "gemm_bf16_kernel<128,128,4,2,true>",
                  20: "gemm_bf16_pp_kernel<256,256,4,2,4>", 21: "gemm_bf16_pp_kernel<256,128,4,4,2>",
                  23: "gemm_bf16_pp_kernel<256,128,3,4,2>", 26: "gemm_bf16_kernel<192,128,4,2,false>",
-                 27: "gemm_bf16_kernel<128,192,2,4,false>", 30: "gemm8p_kernel"}
+                 27: "gemm_bf16_kernel<128,192,2,4,false>", 30: "gemm8p_kernel", 31: "gemm4w_kernel"}
 # bench.py sets this to a list to collect (kernel name, flops, start event, end event) per GEMM launch;
 # events are recorded on the stream the kernel is launched on (torch's current stream).
 PROFILE = None
