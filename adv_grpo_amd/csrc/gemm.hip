@@ -424,7 +424,7 @@ extern "C" int advgrpo_gemm_fp8_grouped(const advgrpo_gemm_desc* descs, const ad
     for (int i = 0; i < count; ++i) {
         p[i] = from_desc(descs[i]);
         p[i].fp8 = 1; p[i].a_scale = scales[i].a_scale; p[i].w_scale = scales[i].w_scale;
-        ADVGRPO_CHECK(p[i].out_dtype == ADVGRPO_BF16 && !p[i].aux_out && !p[i].aux_in, "gemm_fp8_grouped: bf16 output, no aux operands");
+        ADVGRPO_CHECK(p[i].out_dtype == ADVGRPO_BF16 && !p[i].aux_in, "gemm_fp8_grouped: bf16 output, no d-activation input");
     }
     if (count == 1) return gemm8p_launch(p[0], as_stream(stream));
     return gemm8p_launch_pair(p[0], p[1], as_stream(stream));

@@ -92,7 +92,7 @@ int epi_class(const GemmParams& p) {
     if (p.aux_out) f |= F_AUX_OUT;
     if (p.fp8) {     // fp8 operands: the four rollout classes, each with the scale step
         switch (f) {
-            case EPI_BIAS: case EPI_BIAS_RMS: case EPI_BIAS_GELU: case EPI_BIAS_GATE_RES: return f | F_SCALE;
+            case EPI_BIAS: case EPI_BIAS_RMS: case EPI_BIAS_GELU: case EPI_BIAS_GATE_RES: case EPI_BIAS_GELU_AUX: return f | F_SCALE;
         }
         return -2;   // (no generic fp8 class)
     }
@@ -104,7 +104,7 @@ int epi_class(const GemmParams& p) {
 }
 
 int launch8p_any(int epi, const GemmPair& pp, const P8Sched& sc, hipStream_t s) {
-    if (epi == -2) { set_error("gemm8p: fp8 operands need a bf16 output and one of the epilogues bias / bias+QK-norm / bias+GELU / bias+gate+residual"); return -1; }
+    if (epi == -2) { set_error("gemm8p: fp8 operands need a bf16 output and one of the epilogues bias / bias+QK-norm / bias+GELU (+pre-activation) / bias+gate+residual"); return -1; }
     if (epi >= 0 && (epi & F_SCALE)) return gemm8p_launch_fp8_class(epi, pp, sc, s);
     switch (epi) {
         case EPI_BIAS: return launch8p<EPI_BIAS>(pp, sc, s);

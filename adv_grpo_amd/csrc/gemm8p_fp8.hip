@@ -1,5 +1,5 @@
-// gemm8p_fp8.hip -- the eight-phase GEMM (gemm8p_kernel.hpp) on fp8 (OCP e4m3) operands: the rollout's four epilogue classes
-// with the per-token x per-output-channel scale step, instantiated in their own translation unit.
+// gemm8p_fp8.hip -- the eight-phase GEMM (gemm8p_kernel.hpp) on fp8 (OCP e4m3) operands: the rollout's four epilogue classes and
+// the training forward's FF1 class, with the per-token x per-output-channel scale step, instantiated in their own translation unit.
 //
 //   C[M,N] = epilogue( (a_scale[m] * w_scale[n]) * sum_k A8[m,k] * W8[n,k] )        A8 [M,K], W8 [N,K] one byte per element
 //
@@ -19,6 +19,7 @@ int gemm8p_launch_fp8_class(int epi, const GemmPair& pp, const P8Sched& sc, hipS
         case EPI_BIAS_RMS | F_SCALE: return launch8p<EPI_BIAS_RMS | F_SCALE, true>(pp, sc, s);
         case EPI_BIAS_GELU | F_SCALE: return launch8p<EPI_BIAS_GELU | F_SCALE, true>(pp, sc, s);
         case EPI_BIAS_GATE_RES | F_SCALE: return launch8p<EPI_BIAS_GATE_RES | F_SCALE, true>(pp, sc, s);
+        case EPI_BIAS_GELU_AUX | F_SCALE: return launch8p<EPI_BIAS_GELU_AUX | F_SCALE, true>(pp, sc, s);   // training forward of FF1
     }
     set_error("gemm8p: class %d is not an fp8 class", epi);
     return -1;

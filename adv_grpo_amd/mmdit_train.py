@@ -213,6 +213,8 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                         wx[j * D:(j + 1) * D, K + j * RPAD:K + (j + 1) * RPAD] = (self.scale * B16.float()).to(torch.bfloat16)
                     b[gk + ".w"] = wx
                     b[gk + ".A"] = A_cat
+        if self.fp8 is not None:                 # fp8 Linears (enable_fp8): the merged weights have just changed
+            self.requantize()
 
     # ------------------------------------------------------------------ the adapter-free transformer (KL reference)
     @torch.no_grad()
@@ -262,12 +264,30 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             o = self.mod_off[key] + j * D
             return mods[:, o:o + D]
         ctx = {"B": B, "Ni": Ni, "Nt": Nt, "h": h, "w": wd, "mods": mods, "blocks": []}
+        # fp8 Linears (enable_fp8, mmdit.py): the replay runs the SAME arithmetic as the rollout -- same per-row quantisation of the
+        # same inputs, same kernels -- so the importance ratio starts at 1 as in bf16 mode; the backward differentiates the
+        # bf16 Linear (straight-through: quantisation is treated as the identity), from the bf16 activations saved here
+        f8 = self.fp8
+        Mi, Mt = B * Ni, B * Nt
+
+        def linears(i, b, items):
+            if f8 is not None:
+                return ops.gemm_grouped_fp8([ops.gemm_desc_fp8(a, f8[(i, key)], bias=b[key + ".b"], **kw) for a, key, kw in items])
+            return ops.gemm_grouped([ops.gemm_desc(a, b[key + ".w"], bias=b[key + ".b"], **kw) for a, key, kw in items])
+
+        def quant(t, **kw):
+            return ops.quant_fp8_rows(t, **kw)
+
         for i, b in enumerate(self.blocks):
             kx, kc = ("x", i), ("c", i)
             s = {"x_in": x.clone(), "c_in": c.clone()}
             Eq, Eo = self.lora_ext
-            nx_buf = torch.empty(B * Ni, D + Eq, dtype=bf16, device=dev)
-            nc_buf = torch.empty(B * Nt, D + Eq, dtype=bf16, device=dev)
+            if f8 is not None:      # one buffer for both streams: one quantiser launch per Linear pair (Eq = Eo = 0 in fp8 mode)
+                n_all = torch.empty(Mi + Mt, D, dtype=bf16, device=dev)
+                nx_buf, nc_buf = n_all[:Mi], n_all[Mi:]
+            else:
+                nx_buf = torch.empty(B * Ni, D + Eq, dtype=bf16, device=dev)
+                nc_buf = torch.empty(B * Nt, D + Eq, dtype=bf16, device=dev)
             if b["dual"]:
                 _, nx2 = ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), scale2=mod(kx, 7),
                                            shift2=mod(kx, 6), rows_per_batch=Ni)
@@ -275,56 +295,79 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                 ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
             ops.layernorm_mod(c, out=nc_buf[:, :D], scale=mod(kc, 0 if b["last"] else 1), shift=mod(kc, 1 if b["last"] else 0),
                               rows_per_batch=Nt)
-            nx_in, nc_in = self._lora_side_pair(b, [("qkv", nx_buf, None, None), ("cqkv", nc_buf, None, None)], D)
+            if f8 is not None:
+                q_n = quant(n_all)
+                nx_in, nc_in = q_n.rows(0, Mi), q_n.rows(Mi, Mi + Mt)
+            else:
+                nx_in, nc_in = self._lora_side_pair(b, [("qkv", nx_buf, None, None), ("cqkv", nc_buf, None, None)], D)
             nx, nc = nx_buf[:, :D], nc_buf[:, :D]                   # what the backward keeps: the Linear's input proper
             qkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
             qkv3 = qkv.view(B, S, 3 * D)
             rs = torch.empty(B * S, 2 * H, dtype=torch.float32, device=dev)
-            ops.gemm_grouped([
-                ops.gemm_desc(nx_in, b["qkv.w"], bias=b["qkv.b"], out=qkv, seg=(Ni, S, 0), rms=(b["rms_x"], 2 * H, H, 1e-6, rs)),
-                ops.gemm_desc(nc_in, b["cqkv.w"], bias=b["cqkv.b"], out=qkv, seg=(Nt, S, Ni), rms=(b["rms_c"], 2 * H, H, 1e-6, rs))])
+            linears(i, b, [(nx_in, "qkv", dict(out=qkv, seg=(Ni, S, 0), rms=(b["rms_x"], 2 * H, H, 1e-6, rs))),
+                           (nc_in, "cqkv", dict(out=qkv, seg=(Nt, S, Ni), rms=(b["rms_c"], 2 * H, H, 1e-6, rs)))])
             att_ext = torch.empty(B, S, D + Eo, dtype=bf16, device=dev)
             att = att_ext[:, :, :D]
             lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
             ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att, lse=lse)
             att_in = att_ext.view(B * S, D + Eo)
-            if Eo:
-                self._lora_side_pair(b, [("out", att_in, (Ni, S, 0), B * Ni)] +
-                                     ([] if b["last"] else [("cout", att_in, (Nt, S, Ni), B * Nt)]), D)
-            att2d = att_in[:, :D]
-            outs = [ops.gemm_desc(att_in, b["out.w"], bias=b["out.b"], gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x,
-                                  a_seg=(Ni, S, 0), M=B * Ni)]
-            if not b["last"]:
-                outs.append(ops.gemm_desc(att_in, b["cout.w"], bias=b["cout.b"], gate=mod(kc, 2), gate_rows=Nt, residual=c,
-                                          out=c, a_seg=(Nt, S, Ni), M=B * Nt))
-            ops.gemm_grouped(outs)
+            if f8 is not None:
+                q_a = quant(att_in, split=(Ni, S))
+                outs = [(q_a.rows(0, Mi), "out", dict(gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x))]
+                if not b["last"]:
+                    outs.append((q_a.rows(Mi, Mi + Mt), "cout", dict(gate=mod(kc, 2), gate_rows=Nt, residual=c, out=c)))
+            else:
+                if Eo:
+                    self._lora_side_pair(b, [("out", att_in, (Ni, S, 0), B * Ni)] +
+                                         ([] if b["last"] else [("cout", att_in, (Nt, S, Ni), B * Nt)]), D)
+                outs = [(att_in, "out", dict(gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x, a_seg=(Ni, S, 0), M=B * Ni))]
+                if not b["last"]:
+                    outs.append((att_in, "cout", dict(gate=mod(kc, 2), gate_rows=Nt, residual=c, out=c, a_seg=(Nt, S, Ni),
+                                                      M=B * Nt)))
+            linears(i, b, outs)
             s.update(nx=nx, nc=nc, qkv=qkv, rs=rs, att=att, lse=lse)
             if b["dual"]:
                 rs2 = torch.empty(B * Ni, 2 * H, dtype=torch.float32, device=dev)
-                (qkv2,) = ops.gemm_grouped([ops.gemm_desc(nx2, b["qkv2.w"], bias=b["qkv2.b"],
-                                                          rms=(b["rms_2"], 2 * H, H, 1e-6, rs2))])
+                (qkv2,) = linears(i, b, [(quant(nx2) if f8 is not None else nx2, "qkv2", dict(rms=(b["rms_2"], 2 * H, H, 1e-6, rs2)))])
                 q3 = qkv2.view(B, Ni, 3 * D)
                 lse2 = torch.empty(B, H, Ni, dtype=torch.float32, device=dev)
                 o2 = ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], H, lse=lse2)
-                ops.gemm(o2.view(B * Ni, D), b["out2.w"], bias=b["out2.b"], gate=mod(kx, 8), gate_rows=Ni, residual=x, out=x)
+                o2d = o2.view(B * Ni, D)
+                linears(i, b, [(quant(o2d) if f8 is not None else o2d, "out2", dict(gate=mod(kx, 8), gate_rows=Ni, residual=x, out=x))])
                 s.update(qkv2=qkv2, rs2=rs2, att2=o2, lse2=lse2)
             s["x_mid"] = x.clone()
-            nxm = ops.layernorm_mod(x, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
-            pre = torch.empty(B * Ni, 4 * D, dtype=bf16, device=dev)
-            ff1 = [ops.gemm_desc(nxm, b["ff1.w"], bias=b["ff1.b"], act="gelu_tanh", aux_out=pre)]
-            s.update(pre=pre)
             if not b["last"]:
                 s["c_mid"] = c.clone()
-                ncm = ops.layernorm_mod(c, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
-                cpre = torch.empty(B * Nt, 4 * D, dtype=bf16, device=dev)
-                ff1.append(ops.gemm_desc(ncm, b["cff1.w"], bias=b["cff1.b"], act="gelu_tanh", aux_out=cpre))
-                s.update(cpre=cpre)
-            hm = ops.gemm_grouped(ff1)
-            ff2 = [ops.gemm_desc(hm[0], b["ff2.w"], bias=b["ff2.b"], gate=mod(kx, 5), gate_rows=Ni, residual=x, out=x)]
+            pre = torch.empty(B * Ni, 4 * D, dtype=bf16, device=dev)
+            s.update(pre=pre)
+            cpre = None
             if not b["last"]:
-                ff2.append(ops.gemm_desc(hm[1], b["cff2.w"], bias=b["cff2.b"], gate=mod(kc, 5), gate_rows=Nt, residual=c,
-                                         out=c))
-            ops.gemm_grouped(ff2)
+                cpre = torch.empty(B * Nt, 4 * D, dtype=bf16, device=dev)
+                s.update(cpre=cpre)
+            if f8 is not None:
+                m_all = torch.empty(Mi + Mt, D, dtype=bf16, device=dev)
+                ops.layernorm_mod(x, out=m_all[:Mi], scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
+                if not b["last"]:
+                    ops.layernorm_mod(c, out=m_all[Mi:], scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
+                q_m = quant(m_all)                       # (last block: the text rows are uninitialised and unused)
+                h_all = torch.empty(Mi + Mt, 4 * D, dtype=bf16, device=dev)
+                ff1 = [(q_m.rows(0, Mi), "ff1", dict(act="gelu_tanh", aux_out=pre, out=h_all[:Mi]))]
+                if not b["last"]:
+                    ff1.append((q_m.rows(Mi, Mi + Mt), "cff1", dict(act="gelu_tanh", aux_out=cpre, out=h_all[Mi:])))
+                linears(i, b, ff1)
+                q_h = quant(h_all)
+                hm = [q_h.rows(0, Mi), q_h.rows(Mi, Mi + Mt)]
+            else:
+                nxm = ops.layernorm_mod(x, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
+                ff1 = [(nxm, "ff1", dict(act="gelu_tanh", aux_out=pre))]
+                if not b["last"]:
+                    ncm = ops.layernorm_mod(c, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
+                    ff1.append((ncm, "cff1", dict(act="gelu_tanh", aux_out=cpre)))
+                hm = linears(i, b, ff1)
+            ff2 = [(hm[0], "ff2", dict(gate=mod(kx, 5), gate_rows=Ni, residual=x, out=x))]
+            if not b["last"]:
+                ff2.append((hm[1], "cff2", dict(gate=mod(kc, 5), gate_rows=Nt, residual=c, out=c)))
+            linears(i, b, ff2)
             ctx["blocks"].append(s)
         ctx["x_final"] = x
         nx = ops.layernorm_mod(x, scale=mod(("out",), 0), shift=mod(("out",), 1), rows_per_batch=Ni)

@@ -166,7 +166,7 @@ def gemm_desc_fp8(a, w, **kw):
     """gemm_desc for fp8 operands: a, w are Fp8Rows (activation rows / weight output channels).  Returns
     (descriptor, out, scales): the triple gemm_grouped_fp8 takes."""
     assert a.q.dtype == torch.uint8 and w.q.dtype == torch.uint8 and a.q.shape[1] == w.q.shape[1]
-    assert "a_seg" not in kw and "aux_out" not in kw and "aux_in" not in kw
+    assert "a_seg" not in kw and "aux_in" not in kw
     d, out = gemm_desc(_As16(a.q), _As16(w.q), **kw)
     sc = _lib.Fp8Scales()
     sc.a_scale, sc.w_scale = a.scale.data_ptr(), w.scale.data_ptr()

@@ -307,7 +307,7 @@ int advgrpo_gemm_grouped(const advgrpo_gemm_desc* descs, int count /* 1 or 2 */,
  * advgrpo_gemm_fp8_grouped: descriptors as for advgrpo_gemm_grouped with A / W pointing at fp8 codes (lda / ldw in bytes),
  *     C = epilogue( a_scale[m] * w_scale[n] * sum_k A[m,k] W[n,k] ),
  * f32 accumulation on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales), bf16 output, K % 128 == 0, no A row map, and one
- * of the epilogues bias | bias + QK-norm | bias + GELU-tanh | bias + gate + residual. */
+ * of the epilogues bias | bias + QK-norm | bias + GELU-tanh (aux_out: keeps the pre-activation) | bias + gate + residual. */
 typedef struct advgrpo_fp8_scales { const float* a_scale; const float* w_scale; } advgrpo_fp8_scales;
 int advgrpo_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int M, int K,
                            int split_first, int split_period, void* stream);

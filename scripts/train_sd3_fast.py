@@ -30,6 +30,9 @@ def main():
                     help="override sample.groups_in_flight (prompt groups rolled out concurrently on separate HIP streams)")
     ap.add_argument("--lora-mode", default="merged", choices=["merged", "side"],
                     help="merged: LoRA folded into the bf16 weights (default); side: PEFT's side-path arithmetic (TP:490-511)")
+    ap.add_argument("--linear-dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: the block Linears of the MMDiT forward (rollout AND replay) on e4m3 operands (BASELINE config 5's fp8 MFMA "
+                         "path; needs --lora-mode merged); the backward stays bf16 (straight-through)")
     ap.add_argument("--vae-mode", default="bf16x3", choices=["bf16", "bf16x3"],
                     help="decoder arithmetic: bf16 (default) or the fp32-equivalent split-bf16 mode (the reference decodes in fp32, TP:481)")
     args = ap.parse_args()
@@ -67,6 +70,8 @@ def main():
             head = DinoHeadTrainable(device=device, seed=cfg.seed)
         else:
             scorer = PickScoreScorer(device, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
+    if args.linear_dtype == "fp8":
+        tr.enable_fp8()
     pipe = SD3Pipeline(tr, vae, device)
     data = SyntheticData(resolution=cfg.resolution, device=device)
     if cfg.train.lora_path:                                                      # TP:506-509

@@ -206,3 +206,60 @@ def test_mmdit_fp8_sd35_medium_512():
     e16, e8, d = _mmdit_pair(MMDiTConfig(), B=2, hw=64, Nt=205, seed=5)
     print("SD3.5-medium 512^2: bf16 vs oracle", e16, "fp8 vs oracle", e8, "fp8 vs bf16", d)
     assert e16 < 2e-2 and e8 < 7e-2
+
+
+def test_fp8_training_forward_replays_the_rollout_and_differentiates_straight_through():
+    """enable_fp8() on the trainable transformer: the replay (forward_train) is bit-identical to the rollout forward, so the
+    importance ratio starts at exactly 1 as in bf16 mode; the backward is the bf16 Linear's (straight-through), its LoRA
+    gradients stay close to the bf16 model's; the optimizer step re-merges and re-quantises the adapted weights."""
+    from adv_grpo_amd import g_step, synthetic
+    from adv_grpo_amd.mmdit import SD3Transformer2DModel
+    from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
+    from adv_grpo_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from oracle.mmdit import MMDiTConfig
+    cfg = MMDiTConfig(num_layers=3, num_heads=4, joint_attention_dim=128, pooled_projection_dim=64,
+                      pos_embed_max_size=96, dual_attention_layers=(0,))
+    G, Nt = 4, 19
+    W = {k: v.to(bf16) for k, v in synthetic.mmdit_weights(cfg, 7).items()}
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=gen).to(bf16)
+    models = {}
+    for mode in ("bf16", "fp8"):
+        m = SD3TransformerLoRA(W, cfg, "cuda", seed=5)
+        with torch.no_grad():                           # adapters away from their B = 0 initialisation
+            m.params.add_(0.02 * torch.randn(m.params.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9)))
+        m.refresh()
+        if mode == "fp8":
+            m.enable_fp8()
+        models[mode] = m
+    x, emb, pool = rnd(2 * G, 16, 16, 16), rnd(2 * G, Nt, 128), rnd(2 * G, 64)
+    t = torch.full((2 * G,), 913.3488, device="cuda")
+    m8 = models["fp8"]
+    (v_roll,) = SD3Transformer2DModel.__call__(m8, x, t, emb, pool)
+    v_train, _ = m8.forward_train(x, t, emb, pool)
+    assert torch.equal(v_roll, v_train)
+    # one G-step micro-batch in each mode: same sample, same old log-probs -> gradients of the two arithmetic modes
+    sch = FlowMatchEulerDiscreteScheduler(device="cuda"); sch.set_timesteps(10)
+    lat = rnd(G, 16, 16, 16)
+    nxt = (lat.float() * 0.95 + 0.3 * torch.randn(G, 16, 16, 16, device="cuda", generator=gen)).to(bf16)
+    sample = {"latents": lat[:, None], "next_latents": nxt[:, None], "timesteps": sch.timesteps[1].repeat(G)[:, None]}
+    adv = torch.randn(G, device="cuda", generator=gen)
+    kw = dict(guidance_scale=4.5, noise_level=0.8, adv_clip_max=5, clip_range=1e-4)
+    grads = {}
+    for mode, m in models.items():
+        probe = g_step.micro_step(m, sch, sample, 0, emb, pool, torch.zeros(G, device="cuda"), adv, **kw)
+        m.grads.zero_()
+        info = g_step.micro_step(m, sch, sample, 0, emb, pool, probe["log_prob"], adv, **kw)
+        assert float(info["approx_kl"]) == 0.0 and torch.equal(info["log_prob"], probe["log_prob"])     # ratio == 1
+        assert torch.isfinite(m.grads).all()
+        grads[mode] = m.grads.clone()
+    cos = torch.nn.functional.cosine_similarity(grads["fp8"], grads["bf16"], dim=0).item()
+    ratio = (grads["fp8"].norm() / grads["bf16"].norm()).item()
+    print("LoRA gradient, fp8 forward (straight-through) vs bf16: cosine", cos, "norm ratio", ratio)
+    assert cos > 0.95 and 0.8 < ratio < 1.25
+    q0 = m8.fp8[(0, "qkv")].q.clone()
+    m8.optimizer_step(lr=1e-2)
+    assert not torch.equal(m8.fp8[(0, "qkv")].q, q0)          # refresh() re-quantised the merged weight
+    (v_roll2,) = SD3Transformer2DModel.__call__(m8, x, t, emb, pool)
+    v_train2, _ = m8.forward_train(x, t, emb, pool)
+    assert torch.equal(v_roll2, v_train2) and not torch.equal(v_roll2, v_roll)
