@@ -62,6 +62,8 @@ SIGNATURES = {
     "advgrpo_quant_fp8_rows": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int, c_int, c_int, _P]),
     "advgrpo_layernorm_mod": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int,
                                       c_int, c_float, _P]),
+    "advgrpo_layernorm_mod_fp8": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int,
+                                          c_int, c_float, _P, _P, _P, _P, c_int64, _P]),
     "advgrpo_rmsnorm_heads": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int, c_float, c_int, c_int64, c_int64,
                                       _P, _P]),
     "advgrpo_rmsnorm_rows": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int, c_float, _P]),

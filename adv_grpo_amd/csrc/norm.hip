@@ -43,9 +43,38 @@ struct LnParams {
     int64_t mod_stride; int rows_per_batch;
     int M, D; float eps;
     int rms;   // 1: RMSNorm (T5LayerNorm: no mean subtraction, no bias)
+    // fp8 outputs (advgrpo_layernorm_mod_fp8): e4m3 codes + one f32 scale per row of the bf16-ROUNDED output, exactly what
+    // advgrpo_quant_fp8_rows makes of out0 / out1 (quantize.hip) -- the Linear that follows reads these, and out0 / out1
+    // themselves may then be omitted (null)
+    uint8_t* q0; uint8_t* q1; float* qs0; float* qs1; int64_t ldq;
 };
 
-template <int MAXC>
+// e4m3 codes of 8 bf16 values (packed in a uint4) scaled by inv: the arithmetic of quant_fp8_rows_kernel
+__device__ __forceinline__ uint2 ln_fp8_codes(const uint4& b, float inv) {
+    const uint32_t w[4] = {b.x, b.y, b.z, b.w};
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f[2 * k] = fminf(fmaxf(__builtin_bit_cast(float, w[k] << 16) * inv, -448.0f), 448.0f);
+        f[2 * k + 1] = fminf(fmaxf(__builtin_bit_cast(float, w[k] & 0xffff0000u) * inv, -448.0f), 448.0f);
+    }
+    uint32_t o0 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+    o0 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], (int)o0, true);
+    uint32_t o1 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+    o1 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], (int)o1, true);
+    return uint2{o0, o1};
+}
+__device__ __forceinline__ uint32_t ln_amax_bits(const uint4& b, uint32_t m) {
+    const uint32_t w[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        m = max(m, w[k] & 0x7fffu);
+        m = max(m, (w[k] >> 16) & 0x7fffu);
+    }
+    return m;
+}
+
+template <int MAXC, bool FP8 = false>
 __global__ __launch_bounds__(256) void layernorm_mod_kernel(const LnParams p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -78,6 +107,8 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const LnParams p) {
     }
     const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
     const int64_t mrow = p.rows_per_batch > 0 ? (int64_t)(row / p.rows_per_batch) * p.mod_stride : 0;
+    [[maybe_unused]] uint4 ob0[MAXC], ob1[MAXC];          // the outputs, packed bf16 (kept for the fp8 pass)
+    [[maybe_unused]] uint32_t amax0 = 0, amax1 = 0;       // |bf16| compares like its bit pattern
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane + i * 64;
@@ -107,14 +138,35 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const LnParams p) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = n[k];
         }
-        *reinterpret_cast<uint4*>(p.out0 + (int64_t)row * p.ldo + c * 8) = pack8(o);
-        if (p.out1) {
+        ob0[i] = pack8(o);
+        if (p.out0) *reinterpret_cast<uint4*>(p.out0 + (int64_t)row * p.ldo + c * 8) = ob0[i];
+        if (FP8) amax0 = ln_amax_bits(ob0[i], amax0);
+        if (p.out1 || (FP8 && p.q1)) {
             float sc[8], sh[8];
             unpack8(*reinterpret_cast<const uint4*>(p.scale1 + mrow + c * 8), sc);
             unpack8(*reinterpret_cast<const uint4*>(p.shift1 + mrow + c * 8), sh);
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = n[k] * (1.0f + sc[k]) + sh[k];
-            *reinterpret_cast<uint4*>(p.out1 + (int64_t)row * p.ldo + c * 8) = pack8(o);
+            ob1[i] = pack8(o);
+            if (p.out1) *reinterpret_cast<uint4*>(p.out1 + (int64_t)row * p.ldo + c * 8) = ob1[i];
+            if (FP8) amax1 = ln_amax_bits(ob1[i], amax1);
+        }
+    }
+    if constexpr (FP8) {   // second pass over the packed outputs kept in registers: row maximum -> scale -> codes
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint8_t* q = h ? p.q1 : p.q0;
+            if (!q) continue;
+            const float amax = wave_allreduce(bf2f((bf16_t)(h ? amax1 : amax0)), [](float a, float b) { return fmaxf(a, b); });
+            const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+            const float inv = 1.0f / scale;
+            if (lane == 0) (h ? p.qs1 : p.qs0)[row] = scale;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = lane + i * 64;
+                if (c >= nch) continue;
+                *reinterpret_cast<uint2*>(q + (int64_t)row * p.ldq + c * 8) = ln_fp8_codes(h ? ob1[i] : ob0[i], inv);
+            }
         }
     }
 }
@@ -227,9 +279,32 @@ extern "C" int advgrpo_layernorm_mod(const void* x, int64_t ldx, void* out0, voi
     ADVGRPO_CHECK(!out1 || (scale1 && shift1), "layernorm_mod: out1 needs scale1/shift1");
     LnParams p{(const bf16_t*)x, ldx, (bf16_t*)out0, (bf16_t*)out1, ldo, (const bf16_t*)w, (const bf16_t*)b,
                (const bf16_t*)scale0, (const bf16_t*)shift0, (const bf16_t*)scale1, (const bf16_t*)shift1,
-               mod_stride, rows_per_batch, M, D, eps, 0};
+               mod_stride, rows_per_batch, M, D, eps, 0, nullptr, nullptr, nullptr, nullptr, 0};
     if (D <= 2048) hipLaunchKernelGGL(layernorm_mod_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
     else hipLaunchKernelGGL(layernorm_mod_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+/* layernorm_mod whose outputs also (or only: out0 / out1 may be null) leave as fp8 rows for the fp8 Linears: q0 / q1 [M, D]
+ * e4m3 codes (pitch ldq bytes) and qs0 / qs1 [M] f32 scales, bit for bit what advgrpo_quant_fp8_rows makes of out0 / out1. */
+extern "C" int advgrpo_layernorm_mod_fp8(const void* x, int64_t ldx, void* out0, void* out1, int64_t ldo, const void* w,
+                                         const void* b, const void* scale0, const void* shift0, const void* scale1,
+                                         const void* shift1, int64_t mod_stride, int rows_per_batch, int M, int D, float eps,
+                                         void* q0, float* qs0, void* q1, float* qs1, int64_t ldq, void* stream) {
+    ADVGRPO_CHECK(x && q0 && qs0, "layernorm_mod_fp8: null pointer");
+    ADVGRPO_CHECK(M > 0 && D > 0 && D % 8 == 0 && D <= LN_MAX_CHUNKS * 512, "layernorm_mod_fp8: need D %% 8 == 0, D <= %d (D=%d)",
+                  LN_MAX_CHUNKS * 512, D);
+    ADVGRPO_CHECK(ldx % 8 == 0 && ldo % 8 == 0 && mod_stride % 8 == 0 && ldq % 8 == 0 && ldq >= D,
+                  "layernorm_mod_fp8: pitches must be multiples of 8");
+    ADVGRPO_CHECK((scale0 == nullptr) == (shift0 == nullptr), "layernorm_mod_fp8: scale0/shift0 come together");
+    ADVGRPO_CHECK(!(out1 || q1) || (scale1 && shift1), "layernorm_mod_fp8: a second output needs scale1/shift1");
+    ADVGRPO_CHECK(!q1 || qs1, "layernorm_mod_fp8: q1 needs qs1");
+    LnParams p{(const bf16_t*)x, ldx, (bf16_t*)out0, (bf16_t*)out1, ldo, (const bf16_t*)w, (const bf16_t*)b,
+               (const bf16_t*)scale0, (const bf16_t*)shift0, (const bf16_t*)scale1, (const bf16_t*)shift1,
+               mod_stride, rows_per_batch, M, D, eps, 0, (uint8_t*)q0, (uint8_t*)q1, qs0, qs1, ldq};
+    if (D <= 2048) hipLaunchKernelGGL((layernorm_mod_kernel<4, true>), dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL((layernorm_mod_kernel<8, true>), dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

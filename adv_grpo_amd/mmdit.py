@@ -183,11 +183,10 @@ class SD3Transformer2DModel:
         nc_buf = torch.empty(B * Nt, D + Eq, dtype=bf16, device=dev)
         f8 = self.fp8
         if f8 is not None:
-            # one buffer for the image rows and the text rows of every Linear input: ONE quantiser launch per Linear pair, the
-            # two Linears read its two row ranges
+            # one e4m3 buffer for the image rows and the text rows of every Linear input (the Linear pair reads its two row ranges):
+            # filled by the LayerNorms themselves, or by ONE quantiser launch for the attention / GELU outputs
             Mi, Mt = B * Ni, B * Nt
-            n_all = torch.empty(Mi + Mt, D, dtype=bf16, device=dev)
-            nx_buf, nc_buf = n_all[:Mi], n_all[Mi:]
+            q_n2 = ops.Fp8Rows(torch.empty(Mi, D, dtype=torch.uint8, device=dev), torch.empty(Mi, dtype=torch.float32, device=dev))
             q_n = ops.Fp8Rows(torch.empty(Mi + Mt, D, dtype=torch.uint8, device=dev), torch.empty(Mi + Mt, dtype=torch.float32, device=dev))
             q_h = ops.Fp8Rows(torch.empty(Mi + Mt, 4 * D, dtype=torch.uint8, device=dev), torch.empty(Mi + Mt, dtype=torch.float32, device=dev))
             h_all = torch.empty(Mi + Mt, 4 * D, dtype=bf16, device=dev)
@@ -202,19 +201,24 @@ class SD3Transformer2DModel:
             kx, kc = ("x", i), ("c", i)
             # --- norms + modulation (chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
             #     [, shift_msa2, scale_msa2, gate_msa2]); AdaLayerNormContinuous (last context): scale, shift
-            if b["dual"]:
-                _, nx2 = ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), scale2=mod(kx, 7),
-                                           shift2=mod(kx, 6), rows_per_batch=Ni)
-            else:
-                ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
-            if b["last"]:
-                ops.layernorm_mod(c, out=nc_buf[:, :D], scale=mod(kc, 0), shift=mod(kc, 1), rows_per_batch=Nt)
-            else:
-                ops.layernorm_mod(c, out=nc_buf[:, :D], scale=mod(kc, 1), shift=mod(kc, 0), rows_per_batch=Nt)
+            cs, ch = (0, 1) if b["last"] else (1, 0)
             if f8 is not None:
-                ops.quant_fp8_rows(n_all, out=q_n)
-                nx, nc = q_n.rows(0, Mi), q_n.rows(Mi, Mi + Mt)
+                # (fp8: the norms write the e4m3 rows the Linears read, and nothing else -- no bf16 copy, no quantiser launch)
+                q_x, q_c = q_n.rows(0, Mi), q_n.rows(Mi, Mi + Mt)
+                if b["dual"]:
+                    ops.layernorm_mod_fp8(x, q_x, q2=q_n2, scale=mod(kx, 1), shift=mod(kx, 0), scale2=mod(kx, 7), shift2=mod(kx, 6),
+                                          rows_per_batch=Ni)
+                else:
+                    ops.layernorm_mod_fp8(x, q_x, scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
+                ops.layernorm_mod_fp8(c, q_c, scale=mod(kc, cs), shift=mod(kc, ch), rows_per_batch=Nt)
+                nx, nc, nx2 = q_x, q_c, q_n2
             else:
+                if b["dual"]:
+                    _, nx2 = ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), scale2=mod(kx, 7),
+                                               shift2=mod(kx, 6), rows_per_batch=Ni)
+                else:
+                    ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
+                ops.layernorm_mod(c, out=nc_buf[:, :D], scale=mod(kc, cs), shift=mod(kc, ch), rows_per_batch=Nt)
                 nx, nc = self._lora_side_pair(b, [("qkv", nx_buf, None, None), ("cqkv", nc_buf, None, None)], D)
             # --- joint attention.  Each text-stream Linear rides in the launch of its image-stream twin
             #     (ops.gemm_grouped) and the QK RMSNorm is the epilogue of the fused QKV projection.
@@ -239,17 +243,16 @@ class SD3Transformer2DModel:
             linears(i, b, outs)
             if b["dual"]:
                 rms_2 = (b["rms_2"], 2 * H, H, 1e-6, None) if cfg.qk_norm else None
-                (qkv2,) = linears(i, b, [(ops.quant_fp8_rows(nx2) if f8 is not None else nx2, "qkv2", dict(rms=rms_2))])
+                (qkv2,) = linears(i, b, [(nx2, "qkv2", dict(rms=rms_2))])
                 q3 = qkv2.view(B, Ni, 3 * D)
                 o2 = ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], H).view(B * Ni, D)
                 linears(i, b, [(ops.quant_fp8_rows(o2) if f8 is not None else o2, "out2",
                                 dict(gate=mod(kx, 8), gate_rows=Ni, residual=x, out=x))])
             # --- MLPs
             if f8 is not None:
-                ops.layernorm_mod(x, out=nx_buf, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
+                ops.layernorm_mod_fp8(x, q_n.rows(0, Mi), scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
                 if not b["last"]:
-                    ops.layernorm_mod(c, out=nc_buf, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
-                ops.quant_fp8_rows(n_all, out=q_n)      # (last block: the text rows are stale and unused)
+                    ops.layernorm_mod_fp8(c, q_n.rows(Mi, Mi + Mt), scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
                 ff1 = [(q_n.rows(0, Mi), "ff1", dict(act="gelu_tanh", out=h_all[:Mi]))]
                 if not b["last"]:
                     ff1.append((q_n.rows(Mi, Mi + Mt), "cff1", dict(act="gelu_tanh", out=h_all[Mi:])))

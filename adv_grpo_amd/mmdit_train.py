@@ -282,23 +282,27 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             kx, kc = ("x", i), ("c", i)
             s = {"x_in": x.clone(), "c_in": c.clone()}
             Eq, Eo = self.lora_ext
-            if f8 is not None:      # one buffer for both streams: one quantiser launch per Linear pair (Eq = Eo = 0 in fp8 mode)
-                n_all = torch.empty(Mi + Mt, D, dtype=bf16, device=dev)
-                nx_buf, nc_buf = n_all[:Mi], n_all[Mi:]
-            else:
-                nx_buf = torch.empty(B * Ni, D + Eq, dtype=bf16, device=dev)
-                nc_buf = torch.empty(B * Nt, D + Eq, dtype=bf16, device=dev)
-            if b["dual"]:
-                _, nx2 = ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), scale2=mod(kx, 7),
-                                           shift2=mod(kx, 6), rows_per_batch=Ni)
-            else:
-                ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
-            ops.layernorm_mod(c, out=nc_buf[:, :D], scale=mod(kc, 0 if b["last"] else 1), shift=mod(kc, 1 if b["last"] else 0),
-                              rows_per_batch=Nt)
-            if f8 is not None:
-                q_n = quant(n_all)
+            nx_buf = torch.empty(B * Ni, D + Eq, dtype=bf16, device=dev)          # (Eq = Eo = 0 in fp8 mode)
+            nc_buf = torch.empty(B * Nt, D + Eq, dtype=bf16, device=dev)
+            cs, ch = (0, 1) if b["last"] else (1, 0)
+            if f8 is not None:      # the norms write the bf16 rows the backward keeps AND the e4m3 rows the Linears read
+                q_n = ops.Fp8Rows(torch.empty(Mi + Mt, D, dtype=torch.uint8, device=dev), torch.empty(Mi + Mt, dtype=torch.float32, device=dev))
                 nx_in, nc_in = q_n.rows(0, Mi), q_n.rows(Mi, Mi + Mt)
+                nx2 = ops.Fp8Rows(torch.empty(Mi, D, dtype=torch.uint8, device=dev), torch.empty(Mi, dtype=torch.float32, device=dev)) \
+                    if b["dual"] else None
+                if b["dual"]:
+                    ops.layernorm_mod_fp8(x, nx_in, q2=nx2, out=nx_buf, scale=mod(kx, 1), shift=mod(kx, 0), scale2=mod(kx, 7),
+                                          shift2=mod(kx, 6), rows_per_batch=Ni)
+                else:
+                    ops.layernorm_mod_fp8(x, nx_in, out=nx_buf, scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
+                ops.layernorm_mod_fp8(c, nc_in, out=nc_buf, scale=mod(kc, cs), shift=mod(kc, ch), rows_per_batch=Nt)
             else:
+                if b["dual"]:
+                    _, nx2 = ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), scale2=mod(kx, 7),
+                                               shift2=mod(kx, 6), rows_per_batch=Ni)
+                else:
+                    ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
+                ops.layernorm_mod(c, out=nc_buf[:, :D], scale=mod(kc, cs), shift=mod(kc, ch), rows_per_batch=Nt)
                 nx_in, nc_in = self._lora_side_pair(b, [("qkv", nx_buf, None, None), ("cqkv", nc_buf, None, None)], D)
             nx, nc = nx_buf[:, :D], nc_buf[:, :D]                   # what the backward keeps: the Linear's input proper
             qkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
@@ -328,7 +332,7 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             s.update(nx=nx, nc=nc, qkv=qkv, rs=rs, att=att, lse=lse)
             if b["dual"]:
                 rs2 = torch.empty(B * Ni, 2 * H, dtype=torch.float32, device=dev)
-                (qkv2,) = linears(i, b, [(quant(nx2) if f8 is not None else nx2, "qkv2", dict(rms=(b["rms_2"], 2 * H, H, 1e-6, rs2)))])
+                (qkv2,) = linears(i, b, [(nx2, "qkv2", dict(rms=(b["rms_2"], 2 * H, H, 1e-6, rs2)))])
                 q3 = qkv2.view(B, Ni, 3 * D)
                 lse2 = torch.empty(B, H, Ni, dtype=torch.float32, device=dev)
                 o2 = ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], H, lse=lse2)
@@ -345,11 +349,10 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                 cpre = torch.empty(B * Nt, 4 * D, dtype=bf16, device=dev)
                 s.update(cpre=cpre)
             if f8 is not None:
-                m_all = torch.empty(Mi + Mt, D, dtype=bf16, device=dev)
-                ops.layernorm_mod(x, out=m_all[:Mi], scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
+                q_m = ops.Fp8Rows(torch.empty(Mi + Mt, D, dtype=torch.uint8, device=dev), torch.empty(Mi + Mt, dtype=torch.float32, device=dev))
+                ops.layernorm_mod_fp8(x, q_m.rows(0, Mi), scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
                 if not b["last"]:
-                    ops.layernorm_mod(c, out=m_all[Mi:], scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
-                q_m = quant(m_all)                       # (last block: the text rows are uninitialised and unused)
+                    ops.layernorm_mod_fp8(c, q_m.rows(Mi, Mi + Mt), scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
                 h_all = torch.empty(Mi + Mt, 4 * D, dtype=bf16, device=dev)
                 ff1 = [(q_m.rows(0, Mi), "ff1", dict(act="gelu_tanh", aux_out=pre, out=h_all[:Mi]))]
                 if not b["last"]:

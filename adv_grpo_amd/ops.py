@@ -291,6 +291,29 @@ def layernorm_mod(x, out=None, w=None, b=None, scale=None, shift=None, scale2=No
     return (out, out2) if scale2 is not None else out
 
 
+def layernorm_mod_fp8(x, q, q2=None, out=None, out2=None, w=None, b=None, scale=None, shift=None, scale2=None, shift2=None,
+                      rows_per_batch=0, eps=1e-6):
+    """layernorm_mod whose output(s) leave as fp8 rows (q, q2: Fp8Rows of M rows) for the fp8 Linears; out / out2: the bf16
+    tensors to write as well, or None to skip them.  The codes equal quant_fp8_rows(layernorm_mod(...)) bit for bit."""
+    lib = _lib.load()
+    M, D = x.shape
+    assert q.q.shape == (M, D) and q.q.stride(1) == 1 and q.scale.numel() == M and (q2 is None) == (scale2 is None)
+    assert q2 is None or (q2.q.shape == (M, D) and q2.q.stride(0) == q.q.stride(0))
+    assert out2 is None or (out is not None and out2.stride() == out.stride())
+    ms = scale.stride(0) if scale is not None else 0
+    if scale is not None:
+        assert shift.stride(0) == ms and scale.stride(1) == 1
+    if scale2 is not None:
+        assert scale2.stride(0) == ms and shift2.stride(0) == ms
+    dp = lambda t: t.data_ptr() if t is not None else None
+    _lib.check(lib.advgrpo_layernorm_mod_fp8(x.data_ptr(), x.stride(0), dp(out), dp(out2), out.stride(0) if out is not None else D,
+                                             dp(w), dp(b), dp(scale), dp(shift), dp(scale2), dp(shift2), ms, int(rows_per_batch),
+                                             M, D, float(eps), q.q.data_ptr(), q.scale.data_ptr(),
+                                             q2.q.data_ptr() if q2 is not None else None,
+                                             q2.scale.data_ptr() if q2 is not None else None, q.q.stride(0), _lib.stream_ptr()))
+    return out, out2
+
+
 def rmsnorm_rows(x, w, eps=1e-6, out=None):
     """T5LayerNorm over the rows of x [M,D] bf16 (D <= 4096)."""
     lib = _lib.load()

@@ -149,6 +149,12 @@ int advgrpo_layernorm_mod(const void* x, int64_t ldx, void* out0, void* out1, in
                           const void* w, const void* b, const void* scale0, const void* shift0,
                           const void* scale1, const void* shift1, int64_t mod_stride, int rows_per_batch,
                           int M, int D, float eps, void* stream);
+/* The same with fp8 outputs for the fp8 Linears (below): q0 / q1 [M, D] e4m3 codes (pitch ldq bytes) + qs0 / qs1 [M] f32 row
+ * scales, bit for bit what advgrpo_quant_fp8_rows makes of out0 / out1 -- which may then be null (not written at all). */
+int advgrpo_layernorm_mod_fp8(const void* x, int64_t ldx, void* out0, void* out1, int64_t ldo, const void* w,
+                              const void* b, const void* scale0, const void* shift0, const void* scale1,
+                              const void* shift1, int64_t mod_stride, int rows_per_batch, int M, int D, float eps,
+                              void* q0, float* qs0, void* q1, float* qs1, int64_t ldq, void* stream);
 /* T5LayerNorm (transformers' T5: bf16(x * rsqrt(mean(x^2) + eps)) * w, f32 statistics, no bias): the norms of the T5-XXL
  * text encoder called by encode_prompt (adv_grpo/diffusers_patch/train_dreambooth_lora_sd3.py:19-56,125-133). */
 int advgrpo_rmsnorm_rows(const void* x, int64_t ldx, void* out, int64_t ldo, const void* w, int M, int D, float eps,

@@ -55,6 +55,34 @@ def test_quant_rows_split_map():
     assert torch.equal(r.scale, s_ref) and torch.equal(r.q, q_ref)
 
 
+@pytest.mark.parametrize("M,D,dual", [(333, 1536, False), (1024, 1536, True), (77, 2432, True), (64, 128, False)])
+def test_layernorm_mod_fp8_equals_norm_then_quantise(M, D, dual):
+    """The fused norm -> e4m3 rows (what the fp8 rollout uses) against the two-kernel path (norm, then quant_fp8_rows), bit for
+    bit, with and without the bf16 copy, and the second (dual-attention) output."""
+    from adv_grpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + D)
+    rnd = lambda *s, k=1.0: (torch.randn(*s, device="cuda", generator=g) * k).to(bf16)
+    Bt, rpb = 4, -(-M // 4)
+    x = rnd(M, D, k=3.0)
+    mods = rnd(Bt, 4 * D, k=0.3)
+    sc, sh, sc2, sh2 = (mods[:, j * D:(j + 1) * D] for j in range(4))
+    kw = dict(scale=sc, shift=sh, rows_per_batch=rpb)
+    if dual:
+        kw.update(scale2=sc2, shift2=sh2)
+    ref = ops.layernorm_mod(x, **kw)
+    ref = ref if dual else (ref,)
+    want = [ops.quant_fp8_rows(r) for r in ref]
+    new8 = lambda: ops.Fp8Rows(torch.zeros(M, D, dtype=torch.uint8, device="cuda"), torch.zeros(M, dtype=torch.float32, device="cuda"))
+    q, q2 = new8(), (new8() if dual else None)
+    ops.layernorm_mod_fp8(x, q, q2=q2, **kw)                                   # codes only
+    assert torch.equal(q.q, want[0].q) and torch.equal(q.scale, want[0].scale)
+    if dual:
+        assert torch.equal(q2.q, want[1].q) and torch.equal(q2.scale, want[1].scale)
+    qb, out = new8(), torch.zeros(M, D, dtype=bf16, device="cuda")
+    ops.layernorm_mod_fp8(x, qb, q2=(new8() if dual else None), out=out, **kw)   # codes + the bf16 rows
+    assert torch.equal(out, ref[0]) and torch.equal(qb.q, want[0].q)
+
+
 def _gelu_tanh(x):
     return torch.nn.functional.gelu(x, approximate="tanh")
 
