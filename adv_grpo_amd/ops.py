@@ -162,18 +162,6 @@ def quant_fp8_rows(x, out=None, split=None):
     return out
 
 
-def gemm_desc_fp8(a, w, **kw):
-    """gemm_desc for fp8 operands: a, w are Fp8Rows (activation rows / weight output channels).  Returns
-    (descriptor, out, scales): the triple gemm_grouped_fp8 takes."""
-    assert a.q.dtype == torch.uint8 and w.q.dtype == torch.uint8 and a.q.shape[1] == w.q.shape[1]
-    assert "a_seg" not in kw and "aux_in" not in kw
-    d, out = gemm_desc(_As16(a.q), _As16(w.q), **kw)
-    sc = _lib.Fp8Scales()
-    sc.a_scale, sc.w_scale = a.scale.data_ptr(), w.scale.data_ptr()
-    assert a.scale.numel() >= d.M and w.scale.numel() == d.N
-    return d, out, sc
-
-
 class _As16:
     """Presents a uint8 code matrix to gemm_desc (which checks for bf16 operands and takes pointers / pitches in elements)."""
     dtype = torch.bfloat16
@@ -186,6 +174,18 @@ class _As16:
 
     def data_ptr(self):
         return self.t.data_ptr()
+
+
+def gemm_desc_fp8(a, w, **kw):
+    """gemm_desc for fp8 operands: a, w are Fp8Rows (activation rows / weight output channels).  Returns
+    (descriptor, out, scales): the triple gemm_grouped_fp8 takes."""
+    assert a.q.dtype == torch.uint8 and w.q.dtype == torch.uint8 and a.q.shape[1] == w.q.shape[1]
+    assert "a_seg" not in kw and "aux_in" not in kw
+    d, out = gemm_desc(_As16(a.q), _As16(w.q), **kw)
+    sc = _lib.Fp8Scales()
+    sc.a_scale, sc.w_scale = a.scale.data_ptr(), w.scale.data_ptr()
+    assert a.scale.numel() >= d.M and w.scale.numel() == d.N
+    return d, out, sc
 
 
 def gemm_grouped_fp8(descs):

@@ -140,6 +140,8 @@ class Trainer:
         k = c.sample.num_image_per_prompt // c.sample.mini_num_image_per_prompt          # TP:577
         self.sampler = DistributedKRepeatSampler(range(len(data)), c.sample.train_batch_size, k, world, rank, seed=c.seed)
         self.stat_tracker = stat_tracking.PerPromptStatTracker(c.sample.global_std, device=self.device)
+        if c.get("linear_dtype", "bf16") == "fp8":       # BASELINE config 5's fp8 MFMA path (mmdit.enable_fp8): rollout and replay alike
+            pipeline.transformer.enable_fp8()
         self.clip_trainable = None
         if self.variant == "pickscore" and c.get("train_d", False):
             if c.tune_layer != -1:

@@ -30,6 +30,7 @@ def main():
                     help="override sample.groups_in_flight (prompt groups rolled out concurrently on separate HIP streams)")
     ap.add_argument("--lora-mode", default="merged", choices=["merged", "side"],
                     help="merged: LoRA folded into the bf16 weights (default); side: PEFT's side-path arithmetic (TP:490-511)")
+    ap.add_argument("--no-train-d", action="store_true", help="keep the discriminator frozen: every epoch is a G-step epoch")
     ap.add_argument("--linear-dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: the block Linears of the MMDiT forward (rollout AND replay) on e4m3 operands (BASELINE config 5's fp8 MFMA "
                          "path; needs --lora-mode merged); the backward stays bf16 (straight-through)")
@@ -56,6 +57,8 @@ def main():
         cfg.sample.num_image_per_prompt = args.images_per_prompt
     if args.groups_in_flight:
         cfg.sample.groups_in_flight = args.groups_in_flight
+    if args.no_train_d:
+        cfg.train_d = False
     if args.batches:
         cfg.sample.num_batches_per_epoch = args.batches
         cfg.train.gradient_accumulation_steps = max(1, args.batches // 2)
