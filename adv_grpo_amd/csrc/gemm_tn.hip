@@ -223,8 +223,10 @@ extern "C" int advgrpo_gemm_tn_f32acc(const void* P, int64_t ldp, int p_seg_rows
     p.ws = (float*)workspace; p.M = M; p.N1 = N1;
     const int nchunks = (M + 63) / 64, tiles = N1 / 128;
     // ~1 workgroup per CU (measured best of 128..1024: more slices cost more partial-tile traffic than they hide latency)
-    static int target = -1;
-    if (target < 0) { const char* e = getenv("ADVGRPO_TN_BLOCKS"); target = e ? atoi(e) : 256; }
+    int target = 256;
+#ifdef ADVGRPO_EXPERIMENTS
+    { static int knob = -1; if (knob < 0) { const char* e = getenv("ADVGRPO_TN_BLOCKS"); knob = e ? atoi(e) : 0; } if (knob > 0) target = knob; }
+#endif
     int slices = (target + tiles - 1) / tiles;
     if (slices > (nchunks + 1) / 2) slices = (nchunks + 1) / 2;
     if (slices < 1) slices = 1;
