@@ -105,13 +105,20 @@ SIGNATURES = {
     "advgrpo_conv3x3_nhwc_x3": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
     "advgrpo_groupnorm_nhwc_x3": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "advgrpo_softmax_rows_x3": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "advgrpo_layernorm_x3": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "advgrpo_split_act_bf16x3": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, _P]),
+    "advgrpo_softmax_rows_x3_masked": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_float, _P]),
     "advgrpo_add_rows_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
     "advgrpo_latents_to_nhwc_x3": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
     "advgrpo_image_postprocess": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _P]),
     "advgrpo_clip_preprocess_patches": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P,
                                                 _P, c_int, POINTER(c_float), POINTER(c_float), c_int, _P]),
+    "advgrpo_clip_preprocess_patches_x3": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P,
+                                                   _P, c_int, POINTER(c_float), POINTER(c_float), c_int, _P]),
     "advgrpo_dino_preprocess_patches": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_float),
                                                 POINTER(c_float), _P]),
+    "advgrpo_dino_preprocess_patches_x3": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_float),
+                                                   POINTER(c_float), _P]),
     "advgrpo_gather_l2norm_rows": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "advgrpo_dino_head_combine": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     "advgrpo_pickscore_pairs": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P]),

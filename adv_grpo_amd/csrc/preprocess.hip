@@ -46,6 +46,8 @@ __global__ void clip_resize_h_kernel(const void* __restrict__ img, int dt, uint8
 }
 
 // ---- CLIP: vertical PIL pass + rescale/normalise + im2col.  tmp u8 [B,3,H,OW] -> patches bf16 [B*P, 640]
+// X3: the normalised pixel stays f32 and leaves as the split-bf16 left operand [hi | hi | lo], row pitch 3 * 640 (x3.hip)
+template <bool X3>
 __global__ void clip_resize_v_patches_kernel(const uint8_t* __restrict__ tmp, bf16_t* __restrict__ patches, int B, int H,
                                              int OH, int OW, const int* __restrict__ bounds,
                                              const int* __restrict__ coefs, int ksize, float3 mean, float3 stdv) {
@@ -55,7 +57,12 @@ __global__ void clip_resize_v_patches_kernel(const uint8_t* __restrict__ tmp, bf
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int col = i % PATCH_KPAD;
         const int64_t prow = i / PATCH_KPAD;
-        if (col >= PATCH_K) { patches[i] = 0; continue; }
+        bf16_t* o3 = patches + prow * (3 * PATCH_KPAD) + col;
+        if (col >= PATCH_K) {
+            if (X3) { o3[0] = 0; o3[PATCH_KPAD] = 0; o3[2 * PATCH_KPAD] = 0; }
+            else patches[i] = 0;
+            continue;
+        }
         const int p = prow % P, b = prow / P;
         const int c = col / (PATCH * PATCH), iy = (col / PATCH) % PATCH, ix = col % PATCH;
         const int oy = (p / gw) * PATCH + iy, ox = (p % gw) * PATCH + ix;
@@ -69,7 +76,13 @@ __global__ void clip_resize_v_patches_kernel(const uint8_t* __restrict__ tmp, bf
         const float m = c == 0 ? mean.x : (c == 1 ? mean.y : mean.z);
         const float s = c == 0 ? stdv.x : (c == 1 ? stdv.y : stdv.z);
         const float x = (float)q * 0.00392156862745098f;
-        patches[i] = f2bf((x - m) / s);
+        const float v = (x - m) / s;
+        if (X3) {
+            const bf16_t hi = f2bf(v);
+            o3[0] = hi; o3[PATCH_KPAD] = hi; o3[2 * PATCH_KPAD] = f2bf(v - bf2f(hi));
+        } else {
+            patches[i] = f2bf(v);
+        }
     }
 }
 
@@ -82,6 +95,9 @@ __device__ inline void cubic_coeffs(float t, float c[4]) {
     c[2] = ((A + 2.0f) * x3 - (A + 3.0f)) * x3 * x3 + 1.0f;
     c[3] = ((A * x4 - 5.0f * A) * x4 + 8.0f * A) * x4 - 4.0f * A;
 }
+// X3 (the fp32 tower of image_similarity_score, rewards.py:147-203): no bf16 rounding anywhere, the normalised pixel leaves as
+// the split-bf16 left operand [hi | hi | lo], row pitch 3 * 640
+template <bool X3>
 __global__ void dino_preprocess_patches_kernel(const void* __restrict__ img, int dt, bf16_t* __restrict__ patches, int B,
                                                int H, int W, int OH, int OW, float3 mean, float3 stdv) {
     const int gw = OW / PATCH;
@@ -91,7 +107,12 @@ __global__ void dino_preprocess_patches_kernel(const void* __restrict__ img, int
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int col = i % PATCH_KPAD;
         const int64_t prow = i / PATCH_KPAD;
-        if (col >= PATCH_K) { patches[i] = 0; continue; }
+        bf16_t* o3 = patches + prow * (3 * PATCH_KPAD) + col;
+        if (col >= PATCH_K) {
+            if (X3) { o3[0] = 0; o3[PATCH_KPAD] = 0; o3[2 * PATCH_KPAD] = 0; }
+            else patches[i] = 0;
+            continue;
+        }
         const int p = prow % P, b = prow / P;
         const int c = col / (PATCH * PATCH), iy = (col / PATCH) % PATCH, ix = col % PATCH;
         const int oy = (p / gw) * PATCH + iy, ox = (p % gw) * PATCH + ix;
@@ -110,15 +131,21 @@ __global__ void dino_preprocess_patches_kernel(const void* __restrict__ img, int
             for (int d = 0; d < 4; ++d) {
                 const int xx = min(max(x0 - 1 + d, 0), W - 1);
                 float v = ld_img(img, dt, base + (int64_t)yy * W + xx);
-                if (dt != ADVGRPO_BF16) v = round_bf16(v);   // the reference casts images to bf16 first (TP:816)
+                if (!X3 && dt != ADVGRPO_BF16) v = round_bf16(v);   // the reference casts images to bf16 first (TP:816)
                 r += cx[d] * v;
             }
             acc += cy[a] * r;
         }
-        const float rb = round_bf16(acc);
+        const float rb = X3 ? acc : round_bf16(acc);
         const float m = c == 0 ? mean.x : (c == 1 ? mean.y : mean.z);
         const float s = c == 0 ? stdv.x : (c == 1 ? stdv.y : stdv.z);
-        patches[i] = f2bf((rb - m) / s);
+        const float v = (rb - m) / s;
+        if (X3) {
+            const bf16_t hi = f2bf(v);
+            o3[0] = hi; o3[PATCH_KPAD] = hi; o3[2 * PATCH_KPAD] = f2bf(v - bf2f(hi));
+        } else {
+            patches[i] = f2bf(v);
+        }
     }
 }
 
@@ -183,11 +210,10 @@ __global__ __launch_bounds__(64) void pickscore_pairs_kernel(const bf16_t* __res
 
 using namespace advgrpo;
 
-extern "C" int advgrpo_clip_preprocess_patches(const void* image, int image_dtype, void* patches, uint8_t* tmp, int B,
-                                               int H, int W, int OH, int OW, const int* bounds_h, const int* coefs_h,
-                                               int ksize_h, const int* bounds_v, const int* coefs_v, int ksize_v,
-                                               const float* mean3_host, const float* std3_host, int quant_trunc,
-                                               void* stream) {
+static int clip_preprocess_impl(bool x3, const void* image, int image_dtype, void* patches, uint8_t* tmp, int B, int H, int W,
+                                int OH, int OW, const int* bounds_h, const int* coefs_h, int ksize_h, const int* bounds_v,
+                                const int* coefs_v, int ksize_v, const float* mean3_host, const float* std3_host,
+                                int quant_trunc, void* stream) {
     ADVGRPO_CHECK(image && patches && tmp && bounds_h && coefs_h && bounds_v && coefs_v && mean3_host && std3_host,
                   "clip_preprocess: null pointer");
     ADVGRPO_CHECK(OH % PATCH == 0 && OW % PATCH == 0 && B > 0, "clip_preprocess: output must be a multiple of 14");
@@ -195,9 +221,49 @@ extern "C" int advgrpo_clip_preprocess_patches(const void* image, int image_dtyp
     hipLaunchKernelGGL(clip_resize_h_kernel, dim3(2048), dim3(256), 0, s, image, image_dtype, tmp, (int64_t)B * 3 * H, W,
                        OW, bounds_h, coefs_h, ksize_h, quant_trunc);
     ADVGRPO_LAUNCH_CHECK();
-    hipLaunchKernelGGL(clip_resize_v_patches_kernel, dim3(2048), dim3(256), 0, s, tmp, (bf16_t*)patches, B, H, OH, OW,
-                       bounds_v, coefs_v, ksize_v, make_float3(mean3_host[0], mean3_host[1], mean3_host[2]),
-                       make_float3(std3_host[0], std3_host[1], std3_host[2]));
+    const float3 m = make_float3(mean3_host[0], mean3_host[1], mean3_host[2]);
+    const float3 sd = make_float3(std3_host[0], std3_host[1], std3_host[2]);
+    if (x3)
+        hipLaunchKernelGGL(clip_resize_v_patches_kernel<true>, dim3(2048), dim3(256), 0, s, tmp, (bf16_t*)patches, B, H, OH, OW,
+                           bounds_v, coefs_v, ksize_v, m, sd);
+    else
+        hipLaunchKernelGGL(clip_resize_v_patches_kernel<false>, dim3(2048), dim3(256), 0, s, tmp, (bf16_t*)patches, B, H, OH, OW,
+                           bounds_v, coefs_v, ksize_v, m, sd);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_clip_preprocess_patches(const void* image, int image_dtype, void* patches, uint8_t* tmp, int B,
+                                               int H, int W, int OH, int OW, const int* bounds_h, const int* coefs_h,
+                                               int ksize_h, const int* bounds_v, const int* coefs_v, int ksize_v,
+                                               const float* mean3_host, const float* std3_host, int quant_trunc,
+                                               void* stream) {
+    return clip_preprocess_impl(false, image, image_dtype, patches, tmp, B, H, W, OH, OW, bounds_h, coefs_h, ksize_h, bounds_v,
+                                coefs_v, ksize_v, mean3_host, std3_host, quant_trunc, stream);
+}
+
+/* the same with the normalised pixels kept in f32 and written as the split-bf16 left operand: patches3 [B*P, 3*640] */
+extern "C" int advgrpo_clip_preprocess_patches_x3(const void* image, int image_dtype, void* patches3, uint8_t* tmp, int B,
+                                                  int H, int W, int OH, int OW, const int* bounds_h, const int* coefs_h,
+                                                  int ksize_h, const int* bounds_v, const int* coefs_v, int ksize_v,
+                                                  const float* mean3_host, const float* std3_host, int quant_trunc,
+                                                  void* stream) {
+    return clip_preprocess_impl(true, image, image_dtype, patches3, tmp, B, H, W, OH, OW, bounds_h, coefs_h, ksize_h, bounds_v,
+                                coefs_v, ksize_v, mean3_host, std3_host, quant_trunc, stream);
+}
+
+static int dino_preprocess_impl(bool x3, const void* image, int image_dtype, void* patches, int B, int H, int W, int OH, int OW,
+                                const float* mean3_host, const float* std3_host, void* stream) {
+    ADVGRPO_CHECK(image && patches && mean3_host && std3_host, "dino_preprocess: null pointer");
+    ADVGRPO_CHECK(OH % PATCH == 0 && OW % PATCH == 0 && B > 0, "dino_preprocess: output must be a multiple of 14");
+    const float3 m = make_float3(mean3_host[0], mean3_host[1], mean3_host[2]);
+    const float3 sd = make_float3(std3_host[0], std3_host[1], std3_host[2]);
+    if (x3)
+        hipLaunchKernelGGL(dino_preprocess_patches_kernel<true>, dim3(4096), dim3(256), 0, as_stream(stream), image, image_dtype,
+                           (bf16_t*)patches, B, H, W, OH, OW, m, sd);
+    else
+        hipLaunchKernelGGL(dino_preprocess_patches_kernel<false>, dim3(4096), dim3(256), 0, as_stream(stream), image, image_dtype,
+                           (bf16_t*)patches, B, H, W, OH, OW, m, sd);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
@@ -205,13 +271,14 @@ extern "C" int advgrpo_clip_preprocess_patches(const void* image, int image_dtyp
 extern "C" int advgrpo_dino_preprocess_patches(const void* image, int image_dtype, void* patches, int B, int H, int W,
                                                int OH, int OW, const float* mean3_host, const float* std3_host,
                                                void* stream) {
-    ADVGRPO_CHECK(image && patches && mean3_host && std3_host, "dino_preprocess: null pointer");
-    ADVGRPO_CHECK(OH % PATCH == 0 && OW % PATCH == 0 && B > 0, "dino_preprocess: output must be a multiple of 14");
-    hipLaunchKernelGGL(dino_preprocess_patches_kernel, dim3(4096), dim3(256), 0, as_stream(stream), image, image_dtype,
-                       (bf16_t*)patches, B, H, W, OH, OW, make_float3(mean3_host[0], mean3_host[1], mean3_host[2]),
-                       make_float3(std3_host[0], std3_host[1], std3_host[2]));
-    ADVGRPO_LAUNCH_CHECK();
-    return 0;
+    return dino_preprocess_impl(false, image, image_dtype, patches, B, H, W, OH, OW, mean3_host, std3_host, stream);
+}
+
+/* the fp32 pipeline of image_similarity_score (rewards.py:147-203): f32 bicubic, no bf16 rounding; patches3 [B*P, 3*640] */
+extern "C" int advgrpo_dino_preprocess_patches_x3(const void* image, int image_dtype, void* patches3, int B, int H, int W,
+                                                  int OH, int OW, const float* mean3_host, const float* std3_host,
+                                                  void* stream) {
+    return dino_preprocess_impl(true, image, image_dtype, patches3, B, H, W, OH, OW, mean3_host, std3_host, stream);
 }
 
 extern "C" int advgrpo_gather_l2norm_rows(const void* feats, const int64_t* idx, void* out, int B, int T, int D, int n,

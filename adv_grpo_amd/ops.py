@@ -475,6 +475,42 @@ def add_rows_f32(a, b=None, bias=None):
     return y
 
 
+# ---- bf16x3 ViT towers (csrc/x3.hip): row kernels between two split-bf16 matrix products
+X3_ACT = {None: 0, "gelu": 1, "quick_gelu": 2}
+
+
+def layernorm_x3(x, w, b, eps=1e-5):
+    """x f32 [M, D] -> LayerNorm with f32 affine -> split rows bf16 [M, 3D] (left operand)."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and w.dtype == torch.float32 and b.dtype == torch.float32
+    M, D = x.shape
+    out = torch.empty(M, 3 * D, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.advgrpo_layernorm_x3(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), M, D, float(eps), _lib.stream_ptr()))
+    return out
+
+
+def split_act_x3(x, order=0, bias=None, act=None):
+    """split(act(x + bias)): x f32 [..., K] -> bf16 [..., 3K]; act None | "gelu" (erf) | "quick_gelu"."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and (bias is None or bias.dtype == torch.float32)
+    K = x.shape[-1]
+    out = torch.empty(*x.shape[:-1], 3 * K, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.advgrpo_split_act_bf16x3(x.data_ptr(), _lib.ptr(bias), out.data_ptr(), x.numel() // K, K, int(order), X3_ACT[act],
+                                            _lib.stream_ptr()))
+    return out
+
+
+def softmax_rows_x3_masked(s, n_valid, causal_period=0, alpha=1.0):
+    """softmax(alpha * s) over the first n_valid keys (causal: row r keeps r % causal_period + 1 of them) -> split rows [rows, 3n]."""
+    lib = _lib.load()
+    assert s.dtype == torch.float32 and s.is_contiguous()
+    n = s.shape[-1]
+    out = torch.empty(*s.shape[:-1], 3 * n, dtype=torch.bfloat16, device=s.device)
+    _lib.check(lib.advgrpo_softmax_rows_x3_masked(s.data_ptr(), out.data_ptr(), s.numel() // n, n, int(n_valid), int(causal_period),
+                                                  float(alpha), _lib.stream_ptr()))
+    return out
+
+
 def latents_to_nhwc_x3(z, cpad, scaling_factor, shift_factor):
     lib = _lib.load()
     B, C, H, W = z.shape

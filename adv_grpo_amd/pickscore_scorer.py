@@ -8,15 +8,16 @@ Differences that come with the platform, none of which change the number compute
   * prompts are either strings (needs a ``tokenizer`` callable; no tokenizer files exist on the GPU box) or
     ready ``input_ids`` [N,77];
   * weights come from a state dict (``model_sd``) because no checkpoint can be downloaded here;
-  * ``dtype`` is accepted for signature parity and recorded, but the towers always compute in bf16 on the MFMA units
-    with f32 accumulation: gfx950 has no fast fp32 matrix path (1/16 of the bf16 rate), so the fp32 scorer the
-    reference builds for ``pickscore`` (rewards.py:564) differs from this one by bf16 tower rounding (bounded against
-    the fp32 oracle in tests/test_gpu_vit.py); ``compute_dtype`` says what actually runs.
+  * ``dtype`` selects the arithmetic as in the reference: ``torch.bfloat16`` (the co-trained scorer, TP:514) runs the
+    bf16 towers of vit.py; ``torch.float32`` (the ``pickscore`` reward factory, rewards.py:564,596) runs vit_x3.py --
+    fp32-equivalent split-bf16 products (gfx950 has no fast fp32 matrix path: 1/16 of the bf16 rate), everything between
+    two products in f32; both are bounded against the fp32 oracle in tests/test_gpu_vit.py.  ``compute_dtype`` says
+    what runs ("bf16" or "bf16x3").
 """
 import numpy as np
 import torch
 
-from . import vit
+from . import vit, vit_x3
 
 
 class PickScoreScorer(torch.nn.Module):
@@ -26,9 +27,11 @@ class PickScoreScorer(torch.nn.Module):
             raise RuntimeError("PickScoreScorer needs model_sd + clip_cfg (no checkpoint download on this platform)")
         self.device = device
         self.dtype = dtype
-        self.compute_dtype = torch.bfloat16
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError(f"PickScoreScorer: dtype must be torch.float32 or torch.bfloat16, got {dtype}")
+        self.compute_dtype = "bf16x3" if dtype == torch.float32 else "bf16"
         self.tokenizer = tokenizer
-        self.model = vit.CLIPModel(model_sd, clip_cfg, device)
+        self.model = (vit_x3.CLIPModelX3 if dtype == torch.float32 else vit.CLIPModel)(model_sd, clip_cfg, device)
 
     def _images(self, images):
         if isinstance(images, torch.Tensor):
@@ -49,4 +52,6 @@ class PickScoreScorer(torch.nn.Module):
     def __call__(self, prompt, images):
         image_embs = self.model.get_image_features(images=self._images(images))
         text_embs = self.model.get_text_features(self._ids(prompt))
+        if self.dtype == torch.float32:
+            return vit_x3.pickscore_scores_f32(image_embs, text_embs, self.model.logit_scale)
         return vit.pickscore_scores(image_embs, text_embs, self.model.logit_scale)

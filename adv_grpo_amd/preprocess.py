@@ -71,14 +71,15 @@ def _f3(v):
     return (ctypes.c_float * 3)(*v)
 
 
-def clip_patches(images, size=224):
+def clip_patches(images, size=224, x3=False):
     """images [B,3,H,W] in [0,1] (f32 or bf16, device) -> bf16 [B*(size/14)^2, 640] patch rows (CLIPProcessor)."""
-    return pil_patches(images, size, CLIP_MEAN, CLIP_STD, trunc=False)
+    return pil_patches(images, size, CLIP_MEAN, CLIP_STD, trunc=False, x3=x3)
 
 
-def pil_patches(images, size, mean, std, trunc=False):
+def pil_patches(images, size, mean, std, trunc=False, x3=False):
     """uint8 quantisation (round, or truncation as np.astype does) -> Pillow antialiased BICUBIC resize to
-    size x size -> /255 -> (x-mean)/std -> 14x14 patch rows, all on the device and bit-exact with PIL."""
+    size x size -> /255 -> (x-mean)/std -> 14x14 patch rows, all on the device and bit-exact with PIL.
+    x3: the normalised pixels stay f32 and are returned as the split-bf16 left operand [B*P, 3*640] (vit_x3.py)."""
     lib = _lib.load()
     B, C, H, W = images.shape
     assert C == 3
@@ -86,23 +87,24 @@ def pil_patches(images, size, mean, std, trunc=False):
     bh, ch, kh = _tables(W, size, dev)
     bv, cv, kv = _tables(H, size, dev)
     P = (size // 14) ** 2
-    patches = torch.empty(B * P, 640, dtype=torch.bfloat16, device=dev)
+    patches = torch.empty(B * P, 3 * 640 if x3 else 640, dtype=torch.bfloat16, device=dev)
     tmp = torch.empty(B * 3 * H * size, dtype=torch.uint8, device=dev)
     images = images.contiguous()
-    _lib.check(lib.advgrpo_clip_preprocess_patches(
+    _lib.check((lib.advgrpo_clip_preprocess_patches_x3 if x3 else lib.advgrpo_clip_preprocess_patches)(
         _lib.ptr(images), _lib.dtype_code(images.dtype), patches.data_ptr(), tmp.data_ptr(), B, H, W, size,
         size, bh.data_ptr(), ch.data_ptr(), kh, bv.data_ptr(), cv.data_ptr(), kv, _f3(mean), _f3(std), int(trunc),
         _lib.stream_ptr()))
     return patches
 
 
-def dino_patches(images, size=518):
+def dino_patches(images, size=518, x3=False):
+    """x3: the fp32 pipeline (no bf16 rounding), patches returned as the split-bf16 left operand [B*P, 3*640] (vit_x3.py)."""
     lib = _lib.load()
     B, C, H, W = images.shape
     P = (size // 14) ** 2
-    patches = torch.empty(B * P, 640, dtype=torch.bfloat16, device=images.device)
+    patches = torch.empty(B * P, 3 * 640 if x3 else 640, dtype=torch.bfloat16, device=images.device)
     images = images.contiguous()
-    _lib.check(lib.advgrpo_dino_preprocess_patches(_lib.ptr(images), _lib.dtype_code(images.dtype),
+    _lib.check((lib.advgrpo_dino_preprocess_patches_x3 if x3 else lib.advgrpo_dino_preprocess_patches)(_lib.ptr(images), _lib.dtype_code(images.dtype),
                                                    patches.data_ptr(), B, H, W, size, size, _f3(IMAGENET_MEAN),
                                                    _f3(IMAGENET_STD), _lib.stream_ptr()))
     return patches

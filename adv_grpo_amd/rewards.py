@@ -86,8 +86,9 @@ def dino_cotrain_score(device):
 def image_similarity_score(device):
     """rewards.py:147-203 (eval): max over the reference images of the cosine similarity of DINOv2 CLS embeddings.
     On the kernels of the path: fused preprocess + DINOv2 tower, CLS rows L2-normalised by ``gather_l2norm_rows``, the
-    [N, M] similarity matrix by the MFMA GEMM (f32 out); only the row maximum is index plumbing.  (The reference runs
-    this tower in fp32; the towers here are bf16-MFMA / f32-accumulate -- DESIGN.md, deviations.)
+    [N, M] similarity matrix by the MFMA GEMM (f32 out); only the row maximum is index plumbing.  The reference runs this
+    tower in fp32: configure a vit_x3.DinoV2X3 backbone for that arithmetic (split-bf16 products, f32 in between); with a
+    vit.DinoV2 backbone the tower is bf16-MFMA / f32-accumulate (deviations).
     Needs a backbone: configure with rewards.configure_dino(model)."""
     def _cls_rows(model, images):
         from . import _lib
@@ -97,6 +98,9 @@ def image_similarity_score(device):
             images = images.permute(0, 3, 1, 2)
         if images.dtype == torch.uint8 or images.max() > 1.0:                   # RW:163-164
             images = images.float() / 255.0
+        if getattr(model, "x3", False):                                         # fp32-equivalent tower: f32 CLS rows
+            cls = model.forward_features(images=images.to(device).float())[:, 0]
+            return (cls / cls.norm(dim=-1, keepdim=True)).contiguous()
         feats = model.forward_features(images=images.to(device).to(torch.bfloat16)).contiguous()   # [N, 1+P, D], final norm applied
         N, T, Dm = feats.shape
         rows = torch.empty(N, Dm, dtype=torch.bfloat16, device=feats.device)    # n = 0: the CLS row of every image only
@@ -109,6 +113,8 @@ def image_similarity_score(device):
         if model is None:
             raise RuntimeError("call rewards.configure_dino(model) first (no checkpoint download)")
         a, b = _cls_rows(model, images), _cls_rows(model, ref_images)
+        if a.dtype == torch.float32:                                            # split-bf16 product of the f32 rows
+            a, b = ops.split_x3(a, 0), ops.split_x3(b, 1)
         scores = ops.gemm(a, b, out_dtype=torch.float32)                        # [N, M] cosine similarities (RW:191)
         return scores.max(dim=1).values, {"pairwise": scores}
     return _fn

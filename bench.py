@@ -64,7 +64,10 @@ def build(device, large=False, vae_mode="bf16x3"):
     with synthetic.on_device(device):
         tr = SD3Transformer2DModel(synthetic.mmdit_weights(mcfg, 1234), mcfg, device)
         vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(vcfg, 4321), vcfg, device, mode=vae_mode)
-        clip = vit.CLIPModel(synthetic.clip_weights(ccfg, 777), ccfg, device)
+        # config 2's reward is the co-trained bf16 scorer (TP:514); config 4's `pickscore` reward is the fp32 scorer of the
+        # reward factory (RW:561-574): the fp32-equivalent split-bf16 towers
+        from adv_grpo_amd import vit_x3
+        clip = (vit_x3.CLIPModelX3 if large else vit.CLIPModel)(synthetic.clip_weights(ccfg, 777), ccfg, device)
     return SD3Pipeline(tr, vae, device), clip
 
 
@@ -111,7 +114,7 @@ def full_epoch(device, world=1, rank=0):
     with synthetic.on_device(device):
         tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, device, seed=cfg.seed)
         vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321), VaeConfig(), device)
-        scorer = PickScoreScorer(device, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
+        scorer = PickScoreScorer(device, dtype=torch.bfloat16, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
     trainer = Trainer(cfg, SD3Pipeline(tr, vae, device), SyntheticData(resolution=cfg.resolution, device=device), scorer,
                       None, rank, world, log_path=None)
     trainer.run_epoch()                      # warm-up epoch
@@ -277,8 +280,13 @@ def main():
             negative_pooled_prompt_embeds=nppe, num_inference_steps=STEPS, guidance_scale=4.5, output_type="pt",
             height=RES, width=RES, noise_level=0.8, mini_num_image_per_prompt=G, train_num_steps=T,
             process_index=rank, sample_num_steps=STEPS, random_timestep=0, seed=rollout_seed(42, it, rank))
-        scores = vit.pickscore_scores(clip.get_image_features(images=image.to(torch.bfloat16)),
-                                      clip.get_text_features(ids), clip.logit_scale)
+        if c4:      # fp32 scorer (RW:561-574)
+            from adv_grpo_amd import vit_x3
+            scores = vit_x3.pickscore_scores_f32(clip.get_image_features(images=image.float()), clip.get_text_features(ids),
+                                                 clip.logit_scale)
+        else:
+            scores = vit.pickscore_scores(clip.get_image_features(images=image.to(torch.bfloat16)),
+                                          clip.get_text_features(ids), clip.logit_scale)
         rewards = scores.unsqueeze(1).repeat(1, T)                          # TP:926-928
         gids = torch.full((G,), prompt_idx, dtype=torch.int32, device=device)
         rewards, gids = D.gather_rewards(rewards, gids)                     # TP:930-966 packed into one all-gather
@@ -427,7 +435,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("BASELINE config 4 shapes: SD3.5-large (38 blocks, D=2432) LoRA-merged 1024x1024, 10 steps, CFG 4.5, "
-                                    "G=4, SDE window 2 @ noise 0.8, VAE decode, PickScore reward (the OCR half of the reward is a "
+                                    "G=4, SDE window 2 @ noise 0.8, VAE decode (" + pipe.vae.mode + "), fp32-equivalent PickScore reward (the OCR half of the reward is a "
                                     "host plugin outside the timed path), reward all-gather + group advantage") if c4 else
                                    ("BASELINE config 2: SD3.5-medium LoRA-merged 512x512, 10 steps, CFG 4.5, G=8, "
                                     "SDE window 2 @ noise 0.8, VAE decode (" + pipe.vae.mode + "), PickScore (CLIP ViT-H/14) reward, "

@@ -248,6 +248,17 @@ int advgrpo_groupnorm_nhwc_x3(const float* x, void* y3, double* stats, const flo
 int advgrpo_softmax_rows_x3(const float* s, void* out3, int64_t rows, int n, void* stream);
 /* y[r, c] = a[r, c] + b[r, c] (optional) + bias[c] (optional), f32; C % 4 == 0 */
 int advgrpo_add_rows_f32(const float* a, const float* b, const float* bias, float* y, int64_t rows, int C, void* stream);
+/* ---- bf16x3 ViT towers: the fp32 PickScore scorer of rewards.py:561-574 (PickScoreScorer(dtype=torch.float32), config 4's
+ * `pickscore` reward) on the same split-bf16 products.  Row kernels between two matrix products (csrc/x3.hip):
+ *   layernorm_x3:            x f32 [M, D] -> LayerNorm(w, b f32; D <= 2048) -> split rows [M, 3D], order 0
+ *   split_act_bf16x3:        split(act(x + bias)); act 0 none, 1 GELU (erf), 2 quick_gelu
+ *   softmax_rows_x3_masked:  softmax(alpha * s) over the first n_valid keys of every row (causal_period > 0: row r keeps
+ *                            min(n_valid, r % causal_period + 1) keys), zeros past them; s [rows, n] f32 -> [rows, 3n] */
+int advgrpo_layernorm_x3(const float* x, const float* w, const float* b, void* out3, int M, int D, float eps, void* stream);
+int advgrpo_split_act_bf16x3(const float* x, const float* bias, void* out3, int64_t rows, int K, int order, int act,
+                             void* stream);
+int advgrpo_softmax_rows_x3_masked(const float* s, void* out3, int64_t rows, int n, int n_valid, int causal_period,
+                                   float alpha, void* stream);
 /* advgrpo_latents_to_nhwc writing the split layout [B,H,W,3*Cpad] */
 int advgrpo_latents_to_nhwc_x3(const void* z, int z_dtype, void* out3, int B, int C, int H, int W, int Cpad,
                                float scaling_factor, float shift_factor, void* stream);
@@ -266,11 +277,22 @@ int advgrpo_clip_preprocess_patches(const void* image, int image_dtype, void* pa
                                     const int* bounds_v, const int* coefs_v, int ksize_v,
                                     const float* mean3_host, const float* std3_host, int quant_trunc,
                                     void* stream);
+/* The same with the normalised pixels kept in f32 and written as the split-bf16 left operand [hi | hi | lo]:
+ * patches3 [B*P, 3*640] -- the input of the fp32-equivalent scorer towers (below, "bf16x3 ViT towers"). */
+int advgrpo_clip_preprocess_patches_x3(const void* image, int image_dtype, void* patches3, uint8_t* tmp, int B,
+                                       int H, int W, int OH, int OW, const int* bounds_h, const int* coefs_h,
+                                       int ksize_h, const int* bounds_v, const int* coefs_v, int ksize_v,
+                                       const float* mean3_host, const float* std3_host, int quant_trunc,
+                                       void* stream);
 /* DINO path (adv_grpo/rewards.py:379-391): F.interpolate(bicubic, align_corners=False) to OH x OW on
  * bf16-rounded pixels, bf16 round, (x-mean)/std in f32, bf16; same im2col output. */
 int advgrpo_dino_preprocess_patches(const void* image, int image_dtype, void* patches, int B, int H, int W,
                                     int OH, int OW, const float* mean3_host, const float* std3_host,
                                     void* stream);
+/* The fp32 pipeline of image_similarity_score (rewards.py:147-203): f32 bicubic, no bf16 rounding anywhere, the normalised
+ * pixels written as the split-bf16 left operand: patches3 [B*P, 3*640]. */
+int advgrpo_dino_preprocess_patches_x3(const void* image, int image_dtype, void* patches3, int B, int H, int W,
+                                       int OH, int OW, const float* mean3_host, const float* std3_host, void* stream);
 /* rows [B*(1+n), D]: row 0 = feats[b,0], rows 1.. = feats[b, 1+idx[b,j]], each x/(||x||+eps) (rewards.py:400-412). */
 int advgrpo_gather_l2norm_rows(const void* feats, const int64_t* idx, void* out, int B, int T, int D, int n,
                                float eps, void* stream);

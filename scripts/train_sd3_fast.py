@@ -72,7 +72,7 @@ def main():
             scorer = vit.DinoV2(synthetic.dino_weights(DinoConfig(), 888), DinoConfig(), device)
             head = DinoHeadTrainable(device=device, seed=cfg.seed)
         else:
-            scorer = PickScoreScorer(device, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
+            scorer = PickScoreScorer(device, dtype=torch.bfloat16, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
     if args.linear_dtype == "fp8":
         tr.enable_fp8()
     pipe = SD3Pipeline(tr, vae, device)

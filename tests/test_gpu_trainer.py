@@ -37,7 +37,7 @@ def _build(reward, **over):
         head = DinoHeadTrainable(device="cuda", seed=0)
     else:
         cc = ClipConfig(v_layers=2, t_layers=2)
-        scorer = PickScoreScorer("cuda", model_sd=synthetic.clip_weights(cc, 4), clip_cfg=cc)
+        scorer = PickScoreScorer("cuda", dtype=torch.bfloat16, model_sd=synthetic.clip_weights(cc, 4), clip_cfg=cc)
     data = SyntheticData(n_prompts=100, n_tokens=21, ctx_dim=256, pooled_dim=128, resolution=256)
     return Trainer(cfg, SD3Pipeline(tr, vae, "cuda"), data, scorer, head), tr, head
 
@@ -392,7 +392,7 @@ def test_full_size_epoch_config2(tmp_path):
     with synthetic.on_device("cuda"):
         tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, "cuda", seed=cfg.seed)
         vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321), VaeConfig(), "cuda")
-        scorer = PickScoreScorer("cuda", model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
+        scorer = PickScoreScorer("cuda", dtype=torch.bfloat16, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
     log = tmp_path / "metrics.jsonl"
     trainer = Trainer(cfg, SD3Pipeline(tr, vae, "cuda"), SyntheticData(resolution=cfg.resolution, device="cuda"), scorer, None, 0, 1,
                       log_path=str(log))

@@ -212,7 +212,7 @@ def test_bf16_vae_decode_reward_deltas_vs_fp32_decode_at_config2():
           f"bf16x3 {flips_x:.4%}, bf16 {flips_b:.2%}")
     assert errx.max().item() < 1e-4 and flips_x < 2e-3 and (u8(img_x) - u8(img_f)).abs().max().item() <= 1
     ccfg, dcfg = ClipConfig(), DinoConfig()
-    pick = PickScoreScorer("cuda", model_sd=synthetic.clip_weights(ccfg, 777), clip_cfg=ccfg)
+    pick = PickScoreScorer("cuda", dtype=torch.bfloat16, model_sd=synthetic.clip_weights(ccfg, 777), clip_cfg=ccfg)
     ids = synthetic.clip_input_ids(1, 3).repeat(8, 1).cuda()
     dino = vit.DinoV2({k: v.to(torch.bfloat16) for k, v in synthetic.dino_weights(dcfg, 7).items()}, dcfg, "cuda")
     head = DinoHeadTrainable(device="cuda", seed=0)

@@ -82,6 +82,56 @@ def test_clip_towers_and_pickscore_vs_oracle():
     assert (s.cpu() - rs.cpu()).abs().max().item() < 2e-2 * max(1.0, rs.abs().max().item())
 
 
+def test_clip_towers_fp32_equivalent_vs_oracle():
+    """The fp32 scorer of rewards.py:561-574 (PickScoreScorer(dtype=torch.float32)) on split-bf16 products (vit_x3.py): full
+    ViT-H / text widths, 3 layers, fp32 weights, against the fp32 oracle on PIL-preprocessed pixels.  Tolerance: each of the
+    ~25 matrix products between pixels and features is good to ~2^-16; features are held to 5e-5 (measured 1e-5), the score (logit scale
+    100 on a cosine, / 26) to 1e-4 (measured 3e-6) -- a tenth of SURVEY 7's 1e-3."""
+    from adv_grpo_amd import synthetic, vit_x3
+    from adv_grpo_amd.pickscore_scorer import PickScoreScorer
+    from oracle import rewards as o_rw
+    from oracle import vit as o
+    cfg = o.ClipConfig(v_layers=3, t_layers=3)
+    W = synthetic.clip_weights(cfg, 5)                                    # f32 weights, used unrounded
+    scorer = PickScoreScorer("cuda", dtype=torch.float32, model_sd=W, clip_cfg=cfg)
+    assert scorer.compute_dtype == "bf16x3" and isinstance(scorer.model, vit_x3.CLIPModelX3)
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand(4, 3, 512, 512, generator=g)
+    ids = synthetic.clip_input_ids(4, 3)
+    ie = scorer.model.get_image_features(images=img.cuda())
+    te = scorer.model.get_text_features(ids)
+    assert ie.dtype == torch.float32 and te.dtype == torch.float32
+    W32 = {k: v.float().cuda() for k, v in W.items()}
+    px = _pil_clip_preprocess(o_rw.to_uint8(img).permute(0, 2, 3, 1).numpy()).cuda()
+    ri = o.clip_image_features(W32, cfg, px)
+    rt = o.clip_text_features(W32, cfg, ids.cuda())
+    print("bf16x3 CLIP towers vs fp32 oracle: image", _rel(ie, ri), "text", _rel(te, rt))
+    assert _rel(ie, ri) < 5e-5 and _rel(te, rt) < 5e-5
+    s = scorer(ids, img.cuda())
+    rs = o_rw.pickscore_from_embeddings(ri, rt, W32["logit_scale"])
+    print("scores", s.tolist(), "oracle", rs.tolist())
+    assert (s.cpu() - rs.cpu()).abs().max().item() < 1e-4
+    # and the bf16 scorer of the co-training loop (TP:514) is the other arithmetic
+    assert PickScoreScorer("cuda", dtype=torch.bfloat16, model_sd=W, clip_cfg=cfg).compute_dtype == "bf16"
+
+
+def test_clip_vit_h_full_depth_fp32_equivalent_image_tower():
+    """All 32 layers of the ViT-H image tower in the fp32-equivalent arithmetic: the error must not compound past 1e-4 (measured 1.1e-5)."""
+    from adv_grpo_amd import synthetic, vit_x3
+    from oracle import vit as o
+    cfg = o.ClipConfig(t_layers=1)
+    W = synthetic.clip_weights(cfg, 6)
+    model = vit_x3.CLIPModelX3(W, cfg, "cuda")
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(2, 3, 224, 224, generator=g)
+    from oracle import rewards as o_rw
+    px = _pil_clip_preprocess(o_rw.to_uint8(img).permute(0, 2, 3, 1).numpy()).cuda()
+    ie = model.get_image_features(images=img.cuda())
+    ri = o.clip_image_features({k: v.float().cuda() for k, v in W.items()}, cfg, px)
+    print("ViT-H 32 layers, bf16x3 vs fp32 oracle:", _rel(ie, ri))
+    assert _rel(ie, ri) < 1e-4
+
+
 def test_clip_vit_h_full_depth_image_tower():
     from adv_grpo_amd import synthetic, vit
     from oracle import vit as o
@@ -97,6 +147,43 @@ def test_clip_vit_h_full_depth_image_tower():
     ie = model.get_image_features(pixel_patches=patches.cuda())
     ri = o.clip_image_features({k: v.float().cuda() for k, v in Wb.items()}, cfg, px.float().cuda())
     assert _rel(ie, ri) < 3e-2, _rel(ie, ri)
+
+
+def test_dinov2_fp32_equivalent_tower_and_image_similarity_vs_oracle():
+    """image_similarity_score's tower in the reference's fp32 arithmetic (rewards.py:147-203): full ViT-B/14 @ 518 (12 layers,
+    1370 tokens, LayerScale) on split-bf16 products against the fp32 oracle fed by torch's own f32 bicubic resize; then the
+    scorer end to end (max over the reference images of the CLS cosine)."""
+    import torch.nn.functional as F
+    from adv_grpo_amd import rewards, synthetic, vit_x3
+    from adv_grpo_amd.preprocess import IMAGENET_MEAN, IMAGENET_STD
+    from oracle import vit as o
+    cfg = o.DinoConfig()
+    W = synthetic.dino_weights(cfg, 7)
+    model = vit_x3.DinoV2X3(W, cfg, "cuda")
+    g = torch.Generator().manual_seed(4)
+    img, ref_img = torch.rand(3, 3, 512, 512, generator=g), torch.rand(2, 3, 384, 384, generator=g)
+
+    def pre(x):                                                 # RW:151-170
+        x = F.interpolate(x.cuda(), size=(518, 518), mode="bicubic", align_corners=False)
+        m = torch.tensor(IMAGENET_MEAN, device="cuda")[None, :, None, None]
+        s = torch.tensor(IMAGENET_STD, device="cuda")[None, :, None, None]
+        return (x - m) / s
+    W32 = {k: v.float().cuda() for k, v in W.items()}
+    feats = model.forward_features(images=img.cuda())
+    want = o.dino_forward_features(W32, cfg, pre(img))
+    assert feats.shape == (3, 1370, 768) and feats.dtype == torch.float32
+    print("DINOv2 bf16x3 vs fp32 oracle:", _rel(feats, want))
+    assert _rel(feats, want) < 1e-4
+    rewards.configure_dino(model)
+    try:
+        s, info = rewards.image_similarity_score("cuda")(img, ref_img)
+    finally:
+        rewards.configure_dino(None)
+    a = want[:, 0] / want[:, 0].norm(dim=-1, keepdim=True)
+    b = o.dino_forward_features(W32, cfg, pre(ref_img))[:, 0]
+    b = b / b.norm(dim=-1, keepdim=True)
+    pair = a @ b.T
+    assert (info["pairwise"] - pair).abs().max().item() < 1e-4 and (s - pair.max(dim=1).values).abs().max().item() < 1e-4
 
 
 def test_dinov2_features_and_patch_head_vs_oracle():
