@@ -146,6 +146,9 @@ class Trainer:
         if self.variant == "pickscore" and c.get("train_d", False):
             if c.tune_layer != -1:
                 raise NotImplementedError("PickScore D-step is built for tune_layer = -1 (the shipped config)")
+            if getattr(scorer, "compute_dtype", "bf16") != "bf16":
+                raise ValueError("the co-trained PickScore scorer is the bf16 one (TP:514): build it with "
+                                 "PickScoreScorer(dtype=torch.bfloat16, ...); dtype=torch.float32 is the frozen reward scorer")
             self.clip_trainable = ClipLastLayerTrainable(scorer.model)                    # TP:1016-1020
         if world > 1:
             # every trainable state starts identical on all ranks: rank 0's values are broadcast, as DDP / DeepSpeed do
