@@ -24,7 +24,8 @@ def _quant_ref(x):
     return q.view(torch.uint8), scale
 
 
-@pytest.mark.parametrize("M,K,pitch", [(37, 1536, 1536), (1024, 2432, 2432), (5, 6144, 6144), (64, 128, 256), (9, 8192, 8192)])
+@pytest.mark.parametrize("M,K,pitch", [(37, 1536, 1536), (1024, 2432, 2432), (5, 6144, 6144), (64, 128, 256), (9, 8192, 8192),
+                                       (33, 9728, 9728)])     # (9728 = 4 x 2432: the FF2 input of SD3.5-large)
 def test_quant_rows_matches_definition(M, K, pitch):
     from adv_grpo_amd import ops
     g = torch.Generator(device="cuda").manual_seed(M * 7 + K)
@@ -118,7 +119,8 @@ def _close(out, ref, what, roundings=1):
     assert (err <= bound).all(), (what, (err - bound).max().item(), err.max().item())
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 1536, 1536), (1000, 2432, 2432), (16, 256, 128), (300, 4608, 1536), (4101, 1536, 6144)])
+@pytest.mark.parametrize("M,N,K", [(512, 1536, 1536), (1000, 2432, 2432), (16, 256, 128), (300, 4608, 1536), (4101, 1536, 6144),
+                                   (520, 2432, 9728)])
 def test_gemm_fp8_bias_and_gelu(M, N, K):
     from adv_grpo_amd import ops
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
