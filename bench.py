@@ -52,6 +52,51 @@ def parse():
     return ap.parse_args()
 
 
+class PowerSampler:
+    """rocm-smi samples (shader clock, socket power) of one GPU beside the timed steps, on a host thread: the rollout runs at
+    the package power limit and the sustained clock, not the nominal one, is what the MFMA peak scales with."""
+
+    def __init__(self, gpu_index, period=0.5):
+        import threading
+        self.gpu, self.period, self.samples, self._stop = gpu_index, period, [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "-d", str(self.gpu), "--showpower", "--showclocks"], capture_output=True, text=True,
+                                     timeout=5).stdout
+                clk = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+                pw = re.search(r"Power \(W\): ([0-9.]+)", out)
+                if clk and pw:
+                    self.samples.append((int(clk.group(1)), float(pw.group(1))))
+            except Exception:
+                return
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self.gpu >= 0:                 # (only rank 0 samples)
+            self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._t.is_alive():
+            self._t.join(timeout=6)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        clk = sorted(c for c, _ in self.samples)
+        pw = sorted(p for _, p in self.samples)
+        med = lambda v: v[len(v) // 2]
+        return {"samples": len(self.samples), "sclk_mhz_median": med(clk), "sclk_mhz_min": clk[0], "sclk_mhz_max": clk[-1],
+                "socket_power_w_median": med(pw), "socket_power_w_max": pw[-1],
+                "note": "rocm-smi every 0.5 s during the timed steps (rank 0's GPU); nominal peak assumes 2400 MHz"}
+
+
 def build(device, large=False, vae_mode="bf16x3"):
     from adv_grpo_amd import synthetic, vit
     from adv_grpo_amd.mmdit import SD3Transformer2DModel
@@ -302,11 +347,12 @@ def main():
         step(it)
     ops.PROFILE = []
     sync()
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        out = step(args.warmup + it)
-    sync()
-    dt = time.perf_counter() - t0
+    with PowerSampler(local_rank if rank == 0 else -1) as power:
+        t0 = time.perf_counter()
+        for it in range(args.steps):
+            out = step(args.warmup + it)
+        sync()
+        dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
     assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all()
     if dist is not None:
@@ -455,6 +501,7 @@ def main():
                     if "bf16x3" in vae_ms else None,
                     "value_if_bf16": round(images / (dt + args.steps * (vae_ms["bf16"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)
                     if "bf16" in vae_ms else None},
+            "clock_and_power": power.summary(),
             "overlap": overlap,
             "fp8_linears": fp8,
             "lora": {"mode": "merged",

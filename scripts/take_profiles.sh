@@ -14,7 +14,9 @@ python $R/bench.py --config c4 --steps 3 --warmup 1 > $O/bench_c4.json 2> $O/ben
 # 2. kernel tables: rollout (timed configuration only) and one G-step micro-batch
 rocprofv3 --kernel-trace --stats -d $O/kt_c2 -o x -- python $R/bench.py $FAST > $O/bench_c2_prof.json 2>/dev/null
 python $R/scripts/rocpd_stats.py $O/kt_c2/x_results.db $O/kernel_stats_c2.md > /dev/null
-rocprofv3 --kernel-trace --stats -d $O/kt_gstep -o x -- python $R/scripts/bench_gstep.py > $O/gstep.txt 2>/dev/null
+python $R/scripts/bench_gstep.py > $O/gstep.txt 2>/dev/null              # the number: without the profiler attached
+python $R/scripts/bench_gstep.py fp8 >> $O/gstep.txt 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $O/kt_gstep -o x -- python $R/scripts/bench_gstep.py > $O/gstep_under_rocprof.txt 2>/dev/null
 python $R/scripts/rocpd_stats.py $O/kt_gstep/x_results.db $O/kernel_stats_gstep.md > /dev/null
 # 3. HBM-side traffic (separate passes, MI355X_MICROARCH "HBM"), per config
 for cfg in c2 c4; do
