@@ -75,6 +75,20 @@ def main():
             scorer = PickScoreScorer(device, dtype=torch.bfloat16, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
     if args.linear_dtype == "fp8":
         tr.enable_fp8()
+    # reward factories that need a backbone (adv_grpo.rewards builds them from checkpoints; none can be downloaded here): the fp32
+    # scorers get synthetic weights of the real architecture, on the fp32-equivalent towers (vit_x3.py)
+    from adv_grpo_amd import rewards, vit_x3
+    wanted = set(cfg.reward_fn.keys()) | (set(cfg.eval_reward_fn.keys()) if args.eval and cfg.get("eval_reward_fn") else set())
+    with synthetic.on_device(device):
+        if "pickscore" in wanted:
+            rewards.configure_pickscore(synthetic.clip_weights(ClipConfig(), 777), ClipConfig())
+        if "image_similarity" in wanted:
+            rewards.configure_dino(vit_x3.DinoV2X3(synthetic.dino_weights(DinoConfig(), 888), DinoConfig(), device))
+    if "ocr" in wanted:
+        try:
+            import paddleocr  # noqa: F401  (adv_grpo/ocr.py:8-65 uses it when present)
+        except ImportError:
+            rewards.configure_ocr(lambda img: "")      # no recogniser in this image: every OCR reward is the empty-read score
     pipe = SD3Pipeline(tr, vae, device)
     data = SyntheticData(resolution=cfg.resolution, device=device)
     if cfg.train.lora_path:                                                      # TP:506-509
