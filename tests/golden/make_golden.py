@@ -212,6 +212,24 @@ def gold_losses():
         out[f"grpo_{name}/grad"] = lp.grad.numpy()
         for k, v in ns["info"].items():
             out[f"grpo_{name}/{k}"] = v[0].detach().numpy()
+    # ---- the same block with config.train.beta > 0: the KL term against prev_sample_mean_ref (TP:1126-1130,1158-1160)
+    g = torch.Generator().manual_seed(77)
+    old = -torch.rand(6, 2, generator=g)
+    lp = (old[:, 0] + torch.randn(6, generator=g) * 2e-5).requires_grad_(True)
+    adv = torch.randn(6, 2, generator=g) * 3
+    mean = torch.randn(6, 4, 8, 8, generator=g).requires_grad_(True)
+    mean_ref = (mean.detach() + 0.05 * torch.randn(6, 4, 8, 8, generator=g))
+    cfg = types.SimpleNamespace(train=types.SimpleNamespace(adv_clip_max=5, clip_range=1e-5, beta=0.04))
+    ns = dict(torch=torch, config=cfg, sample={"advantages": adv, "log_probs": old}, j=0, log_prob=lp, info=defaultdict(list),
+              prev_sample_mean=mean, prev_sample_mean_ref=mean_ref)
+    exec(block, ns)
+    ns["loss"].backward()
+    out["grpo_kl/log_prob"] = lp.detach().numpy(); out["grpo_kl/old"] = old[:, 0].numpy(); out["grpo_kl/adv"] = adv[:, 0].numpy()
+    out["grpo_kl/mean"] = mean.detach().numpy(); out["grpo_kl/mean_ref"] = mean_ref.numpy()
+    out["grpo_kl/beta"] = np.array(0.04); out["grpo_kl/clip"] = np.array(1e-5)
+    out["grpo_kl/grad_log_prob"] = lp.grad.numpy(); out["grpo_kl/grad_mean"] = mean.grad.numpy()
+    for k, v in ns["info"].items():
+        out[f"grpo_kl/{k}"] = v[0].detach().numpy()
     # ---- CLIPCriterion.calc_loss (pick_score_training.py:118-199)
     from adv_grpo.pick_score_training import CLIPCriterion, CLIPCriterionConfig
     crit = CLIPCriterion(CLIPCriterionConfig())

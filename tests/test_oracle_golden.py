@@ -91,6 +91,23 @@ def test_grpo_loss(case):
         assert np.array_equal(info[k].detach().numpy(), g[k]), k
 
 
+def test_grpo_loss_with_kl_term():
+    """config.train.beta > 0: the golden was made by exec'ing the trainer's own loss block (TP:1111-1162) with a KL reference
+    mean; pins oracle.losses.kl_loss, the composition loss = policy_loss + beta * kl_loss and both gradients."""
+    g = _groups(np.load(os.path.join(G, "losses.npz")))["grpo_kl"]
+    lp = torch.from_numpy(g["log_prob"]).requires_grad_(True)
+    mean = torch.from_numpy(g["mean"]).requires_grad_(True)
+    pl, info = losses.grpo_loss(lp, torch.from_numpy(g["old"]), torch.from_numpy(g["adv"]), 5, float(g["clip"]))
+    kl = losses.kl_loss(mean, torch.from_numpy(g["mean_ref"]))
+    loss = pl + float(g["beta"]) * kl
+    loss.backward()
+    assert np.array_equal(kl.detach().numpy(), g["kl_loss"]) and np.array_equal(pl.detach().numpy(), g["policy_loss"])
+    assert np.array_equal(loss.detach().numpy(), g["loss"])
+    assert np.array_equal(lp.grad.numpy(), g["grad_log_prob"]) and np.array_equal(mean.grad.numpy(), g["grad_mean"])
+    for k in ("approx_kl", "clipfrac", "clipfrac_gt_one", "clipfrac_lt_one"):
+        assert np.array_equal(info[k].detach().numpy(), g[k]), k
+
+
 def test_clip_pair_loss():
     g = _groups(np.load(os.path.join(G, "losses.npz")))["clip"]
     t, i0, i1 = (torch.from_numpy(g[k]) for k in ("text", "img0", "img1"))
