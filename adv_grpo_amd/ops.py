@@ -18,6 +18,8 @@ GEMM_VARIANTS = {0: "gemm_bf16_kernel<128,128,2,2,false>", 1: "gemm_bf16_kernel<
 # bench.py sets this to a list to collect (kernel name, flops, start event, end event) per GEMM launch;
 # events are recorded on the stream the kernel is launched on (torch's current stream).
 PROFILE = None
+PROFILE_STRIDE = 1      # bench.py: HIP events around every PROFILE_STRIDE-th launch OF EACH GEMM KERNEL (1 = all of them)
+PROFILE_COUNTS = {}     # kernel name -> launches seen while PROFILE is on (sampled or not)
 
 
 class _Prof:
@@ -26,6 +28,9 @@ class _Prof:
         if self.on:
             lib = _lib.load()
             self.name = GEMM_VARIANTS[lib.advgrpo_gemm_variant(M, N, K, batch, conv)]
+            n = PROFILE_COUNTS[self.name] = PROFILE_COUNTS.get(self.name, 0) + 1
+            self.on = n % PROFILE_STRIDE == 0
+        if self.on:
             self.flops = 2.0 * M * N * K * batch
             self.shape = (M, N, K, batch, conv)
             self.s = torch.cuda.Event(enable_timing=True)
