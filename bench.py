@@ -351,7 +351,7 @@ def main():
         step(it)
     ops.PROFILE, ops.PROFILE_STRIDE = [], max(1, args.event_stride)
     sync()
-    with PowerSampler(local_rank if rank == 0 else -1) as power:
+    with PowerSampler(local_rank if rank == 0 and os.environ.get("ADVGRPO_BENCH_NO_SMI", "0") != "1" else -1) as power:
         t0 = time.perf_counter()
         for it in range(args.steps):
             out = step(args.warmup + it)
