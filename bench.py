@@ -41,7 +41,7 @@ def parse():
                                                          "all-reduce of the G-step, now runs by default at every N)")
     ap.add_argument("--spawn", action="store_true", help="take the self-spawn path (torch.distributed.run, RCCL process group) at N = 1 "
                                                          "as well: exercises the launcher on a one-GPU box")
-    ap.add_argument("--event-stride", type=int, default=7,
+    ap.add_argument("--event-stride", type=int, default=13,
                     help="HIP events around every Nth launch of each GEMM kernel in the timed steps (1 = every launch).  The roofline's "
                          "per-launch average is then a 1-in-N sample; a prime N walks through the 4 / 6 launches of a block.  Events "
                          "around all ~1220 GEMM launches of a step cost 1.7 %% of the step (measured, DESIGN.md 6)")
