@@ -72,7 +72,7 @@ class CLIPModel:
     def __init__(self, sd, cfg, device="cuda"):
         self.cfg, dev = cfg, torch.device(device)
         self.device = dev
-        self.logit_scale = sd["logit_scale"].float()
+        self.logit_scale = sd["logit_scale"].float().cpu()      # a host scalar: read by every scoring call (no device -> host copy there)
 
         layers = lambda pfx, n: pack_clip_layers(sd, pfx, n, dev)
         act = "gelu"

@@ -98,7 +98,7 @@ class CLIPModelX3:
     def __init__(self, sd, cfg, device="cuda"):
         self.cfg, dev = cfg, torch.device(device)
         self.device = dev
-        self.logit_scale = sd["logit_scale"].float()
+        self.logit_scale = sd["logit_scale"].float().cpu()      # a host scalar: read by every scoring call (no device -> host copy there)
         v, t = "vision_model", "text_model"
         act = "quick_gelu" if getattr(cfg, "act", "gelu") == "quick_gelu" else "gelu"
         self.v_enc = _EncoderX3(pack_clip_layers_x3(sd, v, cfg.v_layers, dev), cfg.v_heads, 1e-5, act)
