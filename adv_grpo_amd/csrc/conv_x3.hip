@@ -13,11 +13,16 @@
 // convolution -- which is what the two-stage structure needs to keep the matrix pipe busy.
 //   * operands are read where the round-2 layout has them (activations [.., 3C] = [hi | hi | lo], weights per tap
 //     [hi | lo | hi]): hi at +0, x_lo at +2C, w_lo at +C; nothing else in the decoder changes
-//   * workgroup 512 threads = 8 waves (4 x 2), tile 128 x 128 x 64, wave tile 32 x 64, v_mfma_f32_16x16x32_bf16 with swapped
-//     operands (a lane owns 4 consecutive output channels of one pixel: float4 stores in the f32 epilogue)
-//   * LDS: 2 stages x 4 pieces x 16 KiB = 128 KiB (one workgroup per CU, two waves per SIMD); HBM/L2 -> LDS by
-//     global_load_lds_dwordx4, lane-linear 1 KiB images with the chunk ^ (row & 7) source swizzle of gemm.hip
-//   * 48 MFMAs per wave and k-tile behind 24 ds_read_b128 and 8 DMA instructions
+//   * workgroup 512 threads = 8 waves (4 x 2), tile 192 pixels x 128 channels x 64, wave tile 48 x 64,
+//     v_mfma_f32_16x16x32_bf16 with swapped operands (a lane owns 4 consecutive output channels of one pixel: float4 stores
+//     in the f32 epilogue)
+//   * LDS: 2 stages x (2 x 24 KiB pixel pieces + 2 x 16 KiB weight pieces) = 160 KiB, ALL of a CU's LDS (one workgroup per
+//     CU, two waves per SIMD); HBM/L2 -> LDS by global_load_lds_dwordx4, lane-linear 1 KiB images with the
+//     chunk ^ (row & 7) source swizzle of gemm.hip
+//   * 72 MFMAs per wave and k-tile behind 28 ds_read_b128 and 10 DMA instructions.  The kernel is bound by the LDS port
+//     (fragment reads + DMA writes), not by L2 or the matrix pipe: the 128-pixel tile of round 2 read 0.50 KiB of
+//     fragments per MFMA and wrote 64 KiB per 48 MFMA-slots, this one 0.39 KiB and 80 KiB per 72 (measured: 8 x 512^2
+//     decode 73.6 -> 69.9 ms, rollout step 422.9 -> 418.3 ms on the same box)
 #include "gemm_device.hpp"
 
 namespace advgrpo {
@@ -27,14 +32,17 @@ namespace {
 typedef __attribute__((address_space(3))) void* x3_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* x3_gptr_t;
 
-constexpr int X3_BM = 128, X3_BN = 128, X3_WM = 4, X3_WN = 2, X3_BK = 64;
-constexpr int X3_PIECE = X3_BM * X3_BK * 2;          // 16 KiB: one 128-row x 64-channel bf16 piece
-constexpr int X3_STAGE = 4 * X3_PIECE;               // x_hi, x_lo, w_hi, w_lo
-constexpr int X3_LDS = 2 * X3_STAGE;
+constexpr int X3_BN = 128, X3_WM = 4, X3_WN = 2, X3_BK = 64;
+constexpr int X3_PIECE_W = X3_BN * X3_BK * 2;        // 16 KiB: one 128-row x 64-channel bf16 weight piece
+constexpr int x3_lds_bytes(int bm) { return 2 * (2 * bm * X3_BK * 2 + 2 * X3_PIECE_W); }   // 2 stages x (x_hi, x_lo, w_hi, w_lo)
 
+template <int X3_BM>
 __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) {
     constexpr int NW = X3_WM * X3_WN, TM = X3_BM / X3_WM, TN = X3_BN / X3_WN, FM = TM / 16, FN = TN / 16;
-    constexpr int INST = X3_BM / 8 / NW;             // DMA instructions per wave and piece (8 rows each): 2
+    constexpr int INST = X3_BM / 8 / NW;             // DMA instructions per wave and pixel piece (8 rows each): 2 or 3
+    constexpr int INST_W = X3_BN / 8 / NW;           // ... and weight piece: 2
+    constexpr int X3_PIECE = X3_BM * X3_BK * 2;      // one BM-row x 64-channel bf16 pixel piece
+    constexpr int X3_STAGE = 2 * X3_PIECE + 2 * X3_PIECE_W;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -51,7 +59,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
     const int lrow = lane >> 3, schunk = (lane & 7) ^ lrow;
     int a_y[INST], a_x[INST];
     int64_t a_img[INST];
-    const bf16_t* w_src[INST];
+    const bf16_t* w_src[INST_W];
 #pragma unroll
     for (int it = 0; it < INST; ++it) {
         int r = m0 + (wave + it * NW) * 8 + lrow;
@@ -61,6 +69,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
         a_y[it] = rem / p.Wout;
         a_x[it] = rem - a_y[it] * p.Wout;
         a_img[it] = (int64_t)bi * (p.Hout >> p.ups) * (p.Wout >> p.ups) * p.Cin;
+    }
+#pragma unroll
+    for (int it = 0; it < INST_W; ++it) {
         int n = n0 + (wave + it * NW) * 8 + lrow;
         n = n < p.N ? n : p.N - 1;
         w_src[it] = p.W + (int64_t)n * p.ldw + schunk * 8;
@@ -81,9 +92,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
             char* dst = base + (wave + it * NW) * 1024;
             __builtin_amdgcn_global_load_lds((x3_gptr_t)hi, (x3_lds_ptr_t)dst, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((x3_gptr_t)lo, (x3_lds_ptr_t)(dst + X3_PIECE), 16, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < INST_W; ++it) {
+            char* dst = base + 2 * X3_PIECE + (wave + it * NW) * 1024;
             const bf16_t* wh = w_src[it] + (int64_t)tap * p.Cin + c0;         // per tap [hi | lo | hi]
-            __builtin_amdgcn_global_load_lds((x3_gptr_t)wh, (x3_lds_ptr_t)(dst + 2 * X3_PIECE), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((x3_gptr_t)(wh + C), (x3_lds_ptr_t)(dst + 3 * X3_PIECE), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((x3_gptr_t)wh, (x3_lds_ptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((x3_gptr_t)(wh + C), (x3_lds_ptr_t)(dst + X3_PIECE_W), 16, 0, 0);
         }
     };
 
@@ -110,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             bh[j] = *reinterpret_cast<const bf16x8_t*>(tb + j * 2048 + frag_off[ks]);
-            bl[j] = *reinterpret_cast<const bf16x8_t*>(tb + X3_PIECE + j * 2048 + frag_off[ks]);
+            bl[j] = *reinterpret_cast<const bf16x8_t*>(tb + X3_PIECE_W + j * 2048 + frag_off[ks]);
         }
     };
     // the three products of one 32-deep step; small terms first, the hi * hi product last
@@ -157,13 +172,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
 int conv3x3_x3_launch(const GemmParams& p, hipStream_t s) {
     ADVGRPO_CHECK(p.conv && p.f32_io && p.Cin % 192 == 0 && p.zero_page && p.batch == 1 && p.splitk == 1,
                   "conv3x3_x3: bad parameter block");
+    constexpr int BM = 192, LDS = x3_lds_bytes(BM);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+        ADVGRPO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<BM>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess,
+                      "conv3x3_x3: %d bytes of LDS refused", LDS);
         attr_set = true;
     }
-    const int tiles = ((p.M + X3_BM - 1) / X3_BM) * ((p.N + X3_BN - 1) / X3_BN);
-    hipLaunchKernelGGL(conv3x3_x3_kernel, dim3(tiles), dim3(512), X3_LDS, s, p);
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + X3_BN - 1) / X3_BN);
+    hipLaunchKernelGGL(conv3x3_x3_kernel<BM>, dim3(tiles), dim3(512), LDS, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
