@@ -75,13 +75,24 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restric
     float sum[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};   // halves: channels [0,4) and [4,8) of the slice
     const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
     const T* xb = x + (int64_t)b * HW * C;
-    for (int p = p0 + prow; p < p1; p += pstep) {
-        float v[8];
-        load8(xb + (int64_t)p * C + slice * 8, v);
+    // four pixels' loads are issued before the first is consumed (a 32-byte load per thread and trip left the kernel at
+    // 2.8 TB/s: too few bytes in flight); the sums are still formed pixel by pixel, so the statistics keep their bits
+    constexpr int U = 4;
+    for (int p = p0 + prow; p < p1; p += U * pstep) {
+        float v[U][8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            sum[k >> 2] += v[k];
-            sq[k >> 2] += v[k] * v[k];
+        for (int u = 0; u < U; ++u) {
+            const int pp = p + u * pstep;
+            if (pp < p1) load8(xb + (int64_t)pp * C + slice * 8, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p + u * pstep >= p1) break;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                sum[k >> 2] += v[u][k];
+                sq[k >> 2] += v[u][k] * v[u][k];
+            }
         }
     }
     s_part[threadIdx.x][0] = sum[0]; s_part[threadIdx.x][1] = sq[0];
@@ -135,14 +146,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restrict__ x, bf16_t* __restrict__ y,
                                                               const float* __restrict__ mr,
                                                               const T* __restrict__ w, const T* __restrict__ bb,
-                                                              int HW, int C, int G, int silu, int64_t total8) {
+                                                              int HW, int C, int G, int silu, int pair_only, int64_t total8) {
     const int c8n = C >> 3, cpg = C / G;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+    auto finish = [&](int64_t i, float (&v)[8]) __attribute__((always_inline)) {
         const int slice = i % c8n;
         const int64_t pix = i / c8n;
         const int b = pix / HW;
-        float v[8], ww[8], bv[8];
-        load8(x + i * 8, v);
+        float ww[8], bv[8];
         load8(w + slice * 8, ww);
         load8(bb + slice * 8, bv);
 #pragma unroll
@@ -164,14 +174,25 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
             split8(v, hi, lo);
             bf16_t* row = y + pix * 3 * C + slice * 8;
             *reinterpret_cast<uint4*>(row) = hi;
-            *reinterpret_cast<uint4*>(row + C) = hi;
+            if (!pair_only) *reinterpret_cast<uint4*>(row + C) = hi;
             *reinterpret_cast<uint4*>(row + 2 * C) = lo;
         }
+    };
+    // two slices per trip, both loads in flight before the arithmetic of the first
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += 2 * stride) {
+        float va[8], vb[8];
+        const int64_t j = i + stride;
+        load8(x + i * 8, va);
+        if (j < total8) load8(x + j * 8, vb);
+        finish(i, va);
+        if (j < total8) finish(j, vb);
     }
 }
 
 // f32 [rows, K] (+ bias[K]) -> bf16 [rows, 3K]: order 0 = [hi | hi | lo] (left operand: activations), 1 = [hi | lo | hi]
-// (right operand: weights)
+// (right operand: weights), 2 = [hi | unwritten | lo] (activations of the dedicated 3x3 kernel, conv_x3.hip, which reads the hi
+// and lo thirds only)
 __global__ __launch_bounds__(256) void split_x3_kernel(const float* __restrict__ x, const float* __restrict__ bias,
                                                        bf16_t* __restrict__ out, int K, int order, int64_t total8) {
     const int k8n = K >> 3;
@@ -190,8 +211,8 @@ __global__ __launch_bounds__(256) void split_x3_kernel(const float* __restrict__
         split8(v, hi, lo);
         bf16_t* row = out + r * 3 * K + slice * 8;
         *reinterpret_cast<uint4*>(row) = hi;
-        *reinterpret_cast<uint4*>(row + K) = order ? lo : hi;
-        *reinterpret_cast<uint4*>(row + 2 * K) = order ? hi : lo;
+        if (order != 2) *reinterpret_cast<uint4*>(row + K) = order ? lo : hi;
+        *reinterpret_cast<uint4*>(row + 2 * K) = order == 1 ? hi : lo;
     }
 }
 
@@ -365,13 +386,13 @@ extern "C" int advgrpo_groupnorm_nhwc(const void* x, void* y, double* stats, con
     int64_t blocks = (total8 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(groupnorm_apply_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, mr,
-                       (const bf16_t*)weight, (const bf16_t*)bias, HW, C, G, silu, total8);
+                       (const bf16_t*)weight, (const bf16_t*)bias, HW, C, G, silu, 0, total8);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int advgrpo_groupnorm_nhwc_x3(const float* x, void* y3, double* stats, const float* weight, const float* bias,
-                                         int B, int HW, int C, int G, float eps, int silu, void* stream) {
+                                         int B, int HW, int C, int G, float eps, int silu, int pair_only, void* stream) {
     ADVGRPO_CHECK(x && y3 && stats && weight && bias, "groupnorm_x3: null pointer");
     ADVGRPO_CHECK(B > 0 && HW > 0 && C % 8 == 0 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 4 == 0 && 256 % (C / 8) == 0,
                   "groupnorm_x3: unsupported shape C=%d G=%d", C, G);
@@ -387,15 +408,15 @@ extern "C" int advgrpo_groupnorm_nhwc_x3(const float* x, void* y3, double* stats
     int64_t blocks = (total8 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(groupnorm_apply_kernel<float>, dim3((int)blocks), dim3(256), 0, s, x, (bf16_t*)y3, mr, weight, bias,
-                       HW, C, G, silu, total8);
+                       HW, C, G, silu, pair_only, total8);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int advgrpo_split_bf16x3(const float* x, const float* bias, void* out, int64_t rows, int K, int order,
                                     void* stream) {
-    ADVGRPO_CHECK(x && out && rows > 0 && K > 0 && K % 8 == 0 && (order == 0 || order == 1),
-                  "split_bf16x3: need K %% 8 == 0 and order 0|1 (K=%d)", K);
+    ADVGRPO_CHECK(x && out && rows > 0 && K > 0 && K % 8 == 0 && order >= 0 && order <= 2,
+                  "split_bf16x3: need K %% 8 == 0 and order 0|1|2 (K=%d)", K);
     const int64_t total8 = rows * (K / 8);
     int64_t blocks = (total8 + 255) / 256;
     if (blocks > 8192) blocks = 8192;

@@ -421,7 +421,8 @@ def groupnorm_nhwc(x, weight, bias, groups=32, eps=1e-6, silu=False):
 
 # ---- split-bf16 ("bf16x3") VAE mode: f32 between the matrix products, operands as [hi|hi|lo] x [hi|lo|hi] (include/advgrpo.h)
 def split_x3(x, order=0, bias=None):
-    """f32 [..., K] (+ bias[K]) -> bf16 [..., 3K]; order 0 = left operand (activations), 1 = right operand (weights)."""
+    """f32 [..., K] (+ bias[K]) -> bf16 [..., 3K]; order 0 = left operand (activations), 1 = right operand (weights),
+    2 = [hi | unwritten | lo] for the activations of conv3x3_x3 with Cout >= 128 only."""
     lib = _lib.load()
     assert x.dtype == torch.float32 and x.is_contiguous()
     K = x.shape[-1]
@@ -447,8 +448,9 @@ def conv3x3_x3(x3, w3, bias=None, upsample=False, act=None, residual=None):
     return y
 
 
-def groupnorm_nhwc_x3(x, weight, bias, groups=32, eps=1e-6, silu=False):
-    """f32 NHWC in, f32 affine -> split bf16 [..., 3C]."""
+def groupnorm_nhwc_x3(x, weight, bias, groups=32, eps=1e-6, silu=False, pair_only=False):
+    """f32 NHWC in, f32 affine -> split bf16 [..., 3C]; pair_only: the middle third stays unwritten (the output feeds
+    conv3x3_x3 with Cout >= 128, which reads hi and lo only)."""
     lib = _lib.load()
     assert x.dtype == torch.float32 and x.is_contiguous() and weight.dtype == torch.float32
     B, C = x.shape[0], x.shape[-1]
@@ -456,7 +458,7 @@ def groupnorm_nhwc_x3(x, weight, bias, groups=32, eps=1e-6, silu=False):
     y = torch.empty(*x.shape[:-1], 3 * C, dtype=torch.bfloat16, device=x.device)
     stats = torch.empty(lib.advgrpo_groupnorm_scratch_bytes(B, HW, groups) // 8, dtype=torch.float64, device=x.device)
     _lib.check(lib.advgrpo_groupnorm_nhwc_x3(x.data_ptr(), y.data_ptr(), stats.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), B,
-                                             HW, C, groups, float(eps), int(silu), _lib.stream_ptr()))
+                                             HW, C, groups, float(eps), int(silu), int(pair_only), _lib.stream_ptr()))
     return y
 
 

@@ -110,17 +110,19 @@ class AutoencoderKLDecoder:
     def _conv3(self, name, x3, **kw):
         return ops.conv3x3_x3(x3, self.w[name + ".weight"], bias=self.w[name + ".bias"], **kw)
 
-    def _gn3(self, name, x, silu):
-        return ops.groupnorm_nhwc_x3(x, self.w[name + ".weight"], self.w[name + ".bias"], self.G, 1e-6, silu)
+    def _gn3(self, name, x, silu, pair_only=False):
+        return ops.groupnorm_nhwc_x3(x, self.w[name + ".weight"], self.w[name + ".bias"], self.G, 1e-6, silu, pair_only)
 
     def _res3(self, p, x):
-        h = self._conv3(f"{p}.conv1", self._gn3(f"{p}.norm1", x, True))
+        # a convolution with >= 128 output channels runs on the kernel that reads the hi and lo thirds only
+        po = lambda name: self.w[name + ".weight"].shape[0] >= 128
+        h = self._conv3(f"{p}.conv1", self._gn3(f"{p}.norm1", x, True, pair_only=po(f"{p}.conv1")))
         sc = x
         if f"{p}.conv_shortcut.weight" in self.w:
             B, H, W, C = x.shape
             sc = ops.gemm(ops.split_x3(x).view(-1, 3 * C), self.w[f"{p}.conv_shortcut.weight"], out_dtype=torch.float32
                           ).view(B, H, W, -1)
-        return self._conv3(f"{p}.conv2", self._gn3(f"{p}.norm2", h, True), residual=sc)
+        return self._conv3(f"{p}.conv2", self._gn3(f"{p}.norm2", h, True, pair_only=po(f"{p}.conv2")), residual=sc)
 
     def _attn3(self, p, x):
         B, H, W, C = x.shape
@@ -152,7 +154,8 @@ class AutoencoderKLDecoder:
             for j in range(cfg.layers_per_block + 1):
                 x = self._res3(f"decoder.up_blocks.{i}.resnets.{j}", x)
             if i < n - 1:
-                x = self._conv3(f"decoder.up_blocks.{i}.upsamplers.0.conv", ops.split_x3(x), upsample=True)
+                name = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+                x = self._conv3(name, ops.split_x3(x, order=2 if self.w[name + ".weight"].shape[0] >= 128 else 0), upsample=True)
         y = self._conv3("decoder.conv_out", self._gn3("decoder.conv_norm_out", x, True))
         return ops.image_postprocess(y)
 

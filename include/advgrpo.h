@@ -234,16 +234,19 @@ int advgrpo_image_postprocess(const void* y, int y_dtype, int ldc, float* image,
  * the bf16 MFMA with f32 accumulation (3x the flops of the bf16 mode, ~2^-16 relative error per product).  Left operands
  * (activations) are laid out along K as [hi | hi | lo] (order 0), right operands (weights) as [hi | lo | hi] (order 1);
  * everything between two matrix products (bias, residual, GroupNorm input, softmax input) stays f32. */
-/* f32 [rows, K] (+ bias[K], optional) -> bf16 [rows, 3K];  K % 8 == 0 */
+/* f32 [rows, K] (+ bias[K], optional) -> bf16 [rows, 3K];  K % 8 == 0.  order 2 = [hi | unwritten | lo]: the activations of
+ * advgrpo_conv3x3_nhwc_x3 with Cout >= 128, whose kernel reads the hi and lo thirds only (4 instead of 6 bytes written
+ * per element); every other consumer needs order 0. */
 int advgrpo_split_bf16x3(const float* x, const float* bias, void* out, int64_t rows, int K, int order, void* stream);
 /* advgrpo_conv3x3_nhwc over split operands: x3 [B,Hin,Win,Cin3=3C], w3 [Cout, 9*Cin3] (each tap [hi|lo|hi]); bias,
  * residual, y: f32 */
 int advgrpo_conv3x3_nhwc_x3(const void* x3, const void* w3, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
                             int upsample, const float* bias, int act, const float* residual, const void* zero_page,
                             void* stream);
-/* GroupNorm over f32 NHWC [B,HW,C], f32 affine (+ SiLU) -> split output [B,HW,3C]; stats scratch as above */
+/* GroupNorm over f32 NHWC [B,HW,C], f32 affine (+ SiLU) -> split output [B,HW,3C]; stats scratch as above.
+ * pair_only != 0 leaves the middle third unwritten (order 2 above: output consumed by the Cout >= 128 3x3 kernel only) */
 int advgrpo_groupnorm_nhwc_x3(const float* x, void* y3, double* stats, const float* weight, const float* bias, int B,
-                              int HW, int C, int G, float eps, int silu, void* stream);
+                              int HW, int C, int G, float eps, int silu, int pair_only, void* stream);
 /* softmax over f32 rows [rows, n] -> split rows [rows, 3n] (left operand of P.V) */
 int advgrpo_softmax_rows_x3(const float* s, void* out3, int64_t rows, int n, void* stream);
 /* y[r, c] = a[r, c] + b[r, c] (optional) + bias[c] (optional), f32; C % 4 == 0 */

@@ -8,7 +8,10 @@ pytestmark = pytest.mark.gpu
 def test_conv3x3_implicit_gemm_matches_fp32_conv():
     from adv_grpo_amd import ops
     g = torch.Generator(device="cuda").manual_seed(1)
-    for (B, H, W, Ci, Co, up) in [(2, 16, 24, 64, 96, False), (1, 8, 8, 128, 64, True), (2, 32, 32, 128, 3, False)]:
+    # Cout >= 128 runs on the dedicated kernel (192-pixel tiles: 768 = 4 x 192 pixels, 1600 is ragged), below it on the
+    # generic one over the tripled contraction axis
+    for (B, H, W, Ci, Co, up) in [(2, 16, 24, 64, 96, False), (1, 8, 8, 128, 64, True), (2, 32, 32, 128, 3, False),
+                                  (2, 16, 24, 64, 128, False), (1, 20, 20, 128, 256, True), (1, 13, 11, 192, 384, False)]:
         x = torch.randn(B, H, W, Ci, device="cuda", generator=g).to(torch.bfloat16)
         wt = (torch.randn(Co, Ci, 3, 3, device="cuda", generator=g) / (3 * Ci ** 0.5)).to(torch.bfloat16)
         bias = torch.randn(Co, device="cuda", generator=g).to(torch.bfloat16)
@@ -85,7 +88,10 @@ def test_split_bf16x3_kernels_vs_fp32():
         assert torch.equal(hi, (x + b).to(torch.bfloat16).float())
         assert torch.equal(s3[:, 64:128] if order == 0 else s3[:, 128:], hi)
         assert ((hi + lo - (x + b)).abs() <= 2.0 ** -16 * (x + b).abs()).all()
-    for (B, H, W, Ci, Co, up) in [(2, 16, 24, 64, 96, False), (1, 8, 8, 128, 64, True), (2, 32, 32, 128, 3, False)]:
+    # Cout >= 128 runs on the dedicated kernel (192-pixel tiles: 768 = 4 x 192 pixels, 1600 is ragged), below it on the
+    # generic one over the tripled contraction axis
+    for (B, H, W, Ci, Co, up) in [(2, 16, 24, 64, 96, False), (1, 8, 8, 128, 64, True), (2, 32, 32, 128, 3, False),
+                                  (2, 16, 24, 64, 128, False), (1, 20, 20, 128, 256, True), (1, 13, 11, 192, 384, False)]:
         x = torch.randn(B, H, W, Ci, device="cuda", generator=g)
         wt = torch.randn(Co, Ci, 3, 3, device="cuda", generator=g) / (3 * Ci ** 0.5)
         bias = torch.randn(Co, device="cuda", generator=g)
@@ -100,6 +106,11 @@ def test_split_bf16x3_kernels_vs_fp32():
         err = (y.double() - ref).abs().max().item()
         print("conv x3", (B, H, W, Ci, Co, up), "max err", err, "of", ref.abs().max().item())
         assert err < 1e-4 * ref.abs().max().item()
+        if Co >= 128:      # the dedicated kernel reads the hi and lo thirds only: order 2 leaves the middle one unwritten
+            x2 = torch.full((B, H, W, 3 * Ci), float("nan"), device="cuda", dtype=torch.bfloat16)
+            x2[..., :Ci] = ops.split_x3(x, 2)[..., :Ci]
+            x2[..., 2 * Ci:] = ops.split_x3(x, 2)[..., 2 * Ci:]
+            assert torch.equal(ops.conv3x3_x3(x2, w3, bias=bias, upsample=up, residual=res), y)
     for C in (128, 256, 512):
         x = torch.randn(2, 24, 24, C, device="cuda", generator=g) * 2 + 0.5
         w = torch.randn(C, device="cuda", generator=g)
@@ -110,6 +121,8 @@ def test_split_bf16x3_kernels_vs_fp32():
         assert torch.equal(y3[..., :C], y3[..., C:2 * C])
         got = y3[..., :C].double() + y3[..., 2 * C:].double()
         assert ((got - ref).abs() <= 2.0 ** -15 * ref.abs() + 2e-6).all()
+        p3 = ops.groupnorm_nhwc_x3(x, w, b, 32, 1e-6, True, pair_only=True).float()
+        assert torch.equal(p3[..., :C], y3[..., :C]) and torch.equal(p3[..., 2 * C:], y3[..., 2 * C:])
     s = torch.randn(37, 4096, device="cuda", generator=g) * 3
     p3 = ops.softmax_rows_x3(s).float()
     got = p3[:, :4096].double() + p3[:, 8192:].double()
