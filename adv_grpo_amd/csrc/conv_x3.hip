@@ -8,21 +8,28 @@
 //
 // Round 2 ran this through the plain convolution kernel by TRIPLING the contraction axis ([hi | hi | lo] x [hi | lo | hi]):
 // three k-tiles, three stage loads and three barriers per 64 channels, each with the bf16 kernel's MFMA : byte ratio.  Here one
-// k-tile stages the four 64-wide pieces (x_hi, x_lo, w_hi, w_lo) ONCE and issues the three MFMA products from them:
-// 2/3 of the L2 -> LDS bytes and 1/3 of the barriers for the same MFMA work, i.e. 1.5x the arithmetic intensity of the bf16
-// convolution -- which is what the two-stage structure needs to keep the matrix pipe busy.
+// k-tile stages the 64-wide pieces ONCE and issues the three MFMA products from them, and the three taps of one kernel row
+// share ONE pixel stage:
 //   * operands are read where the round-2 layout has them (activations [.., 3C] = [hi | hi | lo], weights per tap
-//     [hi | lo | hi]): hi at +0, x_lo at +2C, w_lo at +C; nothing else in the decoder changes
+//     [hi | lo | hi]): hi at +0, x_lo at +2C, w_lo at +C; the middle third of an activation row is never read
 //   * workgroup 512 threads = 8 waves (4 x 2), tile 192 pixels x 128 channels x 64, wave tile 48 x 64,
 //     v_mfma_f32_16x16x32_bf16 with swapped operands (a lane owns 4 consecutive output channels of one pixel: float4 stores
-//     in the f32 epilogue)
-//   * LDS: 2 stages x (2 x 24 KiB pixel pieces + 2 x 16 KiB weight pieces) = 160 KiB, ALL of a CU's LDS (one workgroup per
-//     CU, two waves per SIMD); HBM/L2 -> LDS by global_load_lds_dwordx4, lane-linear 1 KiB images with the
-//     chunk ^ (row & 7) source swizzle of gemm.hip
-//   * 72 MFMAs per wave and k-tile behind 28 ds_read_b128 and 10 DMA instructions.  The kernel is bound by the LDS port
-//     (fragment reads + DMA writes), not by L2 or the matrix pipe: the 128-pixel tile of round 2 read 0.50 KiB of
-//     fragments per MFMA and wrote 64 KiB per 48 MFMA-slots, this one 0.39 KiB and 80 KiB per 72 (measured: 8 x 512^2
-//     decode 73.6 -> 69.9 ms, rollout step 422.9 -> 418.3 ms on the same box)
+//     in the f32 epilogue); 72 MFMAs per wave and k-tile behind 28 ds_read_b128
+//   * k order: group (dy, 64-channel slice) -> taps dx = -1, 0, +1.  A group stages the tile's 192 consecutive output
+//     pixels displaced by dy PLUS one pixel on each side (x_hi, x_lo: 2 x 25 KiB, LDS row j = pixel m0 - 1 + j); tap dx
+//     reads its fragments one row up or down, and a pixel in the first / last column of its image row (whose shifted row
+//     holds the neighbouring image row) gets a zero fragment instead.  One pixel stage per THREE k-tiles: 43 % fewer
+//     L2 -> LDS bytes than a stage per tap.
+//   * weights (w_hi, w_lo of one tap: 2 x 16 KiB) travel through a ring of three stages -- the tap index is the slot --
+//     requested two k-tiles ahead; the single pixel stage is re-requested on the last tap of a group, behind a barrier
+//     that follows that k-tile's fragment reads.  LDS: 50 + 96 = 146 KiB, one workgroup per CU.
+//   * raw s_barrier and hand-counted s_waitcnt vmcnt(4) (the youngest weight stage stays in flight): __syncthreads() drains
+//     every LDS-DMA.  HBM/L2 -> LDS by global_load_lds_dwordx4, lane-linear 1 KiB images, chunk ^ (row & 7) source swizzle.
+// Measured (8 x 512^2 decode, same box): round-2 form 83.9 ms; one stage per tap, 128-pixel tile 73.6; 192-pixel tile 69.9
+// (the kernel pays a fixed latency per k-tile -- DMA round trip, fragment reads in front of the first MFMA, barrier -- so
+// more MFMAs per k-tile pay, fewer bytes alone do not: the shared pixel stage with two weight stages gave 0.6 ms); weight ring
+// 66.0.  What is left per k-tile is the fragment-read phase in front of the MFMAs (both waves of a SIMD are in the same phase)
+// and the prologue / epilogue of a one-workgroup-per-CU, non-persistent tile.
 #include "gemm_device.hpp"
 
 namespace advgrpo {
@@ -32,17 +39,18 @@ namespace {
 typedef __attribute__((address_space(3))) void* x3_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* x3_gptr_t;
 
-constexpr int X3_BN = 128, X3_WM = 4, X3_WN = 2, X3_BK = 64;
-constexpr int X3_PIECE_W = X3_BN * X3_BK * 2;        // 16 KiB: one 128-row x 64-channel bf16 weight piece
-constexpr int x3_lds_bytes(int bm) { return 2 * (2 * bm * X3_BK * 2 + 2 * X3_PIECE_W); }   // 2 stages x (x_hi, x_lo, w_hi, w_lo)
+constexpr int X3_BM = 192, X3_BN = 128, X3_WM = 4, X3_WN = 2, X3_BK = 64;
+constexpr int X3_XINST = (X3_BM + 2 + 7) / 8;        // 25 DMA instructions (8 pixel rows each) per pixel piece: pixels m0-1 .. m0+198
+constexpr int X3_XPIECE = X3_XINST * 1024;           // 25 KiB: the tile's pixels and one halo pixel on each side, 64 channels
+constexpr int X3_XSTAGE = 2 * X3_XPIECE;             // x_hi, x_lo: ONE stage, reloaded once per three k-tiles
+constexpr int X3_WPIECE = X3_BN * X3_BK * 2;         // 16 KiB: 128 output channels x 64 input channels of one tap
+constexpr int X3_WSTAGE = 2 * X3_WPIECE;             // w_hi, w_lo
+constexpr int X3_LDS = X3_XSTAGE + 3 * X3_WSTAGE;    // 146 KiB: a ring of three weight stages (the tap index IS the ring slot)
 
-template <int X3_BM>
 __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) {
     constexpr int NW = X3_WM * X3_WN, TM = X3_BM / X3_WM, TN = X3_BN / X3_WN, FM = TM / 16, FN = TN / 16;
-    constexpr int INST = X3_BM / 8 / NW;             // DMA instructions per wave and pixel piece (8 rows each): 2 or 3
-    constexpr int INST_W = X3_BN / 8 / NW;           // ... and weight piece: 2
-    constexpr int X3_PIECE = X3_BM * X3_BK * 2;      // one BM-row x 64-channel bf16 pixel piece
-    constexpr int X3_STAGE = 2 * X3_PIECE + 2 * X3_PIECE_W;
+    constexpr int XI = (X3_XINST + NW - 1) / NW;     // pixel-piece DMA instructions per wave: 3 (the last one on 5 waves only)
+    constexpr int WI = X3_BN / 8 / NW;               // weight-piece DMA instructions per wave: 2
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -55,56 +63,81 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
     tile_coords(swz, tiles_m, tiles_n, 4, tile_m, tile_n);
     const int m0 = tile_m * X3_BM, n0 = tile_n * X3_BN;
 
-    // ---- per-lane DMA sources: output pixel of this lane's A rows, weight row pointers
+    // ---- per-lane DMA sources.  LDS row j of a pixel piece holds output pixel m0 - 1 + j displaced by the group's dy
     const int lrow = lane >> 3, schunk = (lane & 7) ^ lrow;
-    int a_y[INST], a_x[INST];
-    int64_t a_img[INST];
-    const bf16_t* w_src[INST_W];
+    const int hw = p.Hout * p.Wout;
+    int a_y[XI], a_x[XI];
+    int64_t a_img[XI];
 #pragma unroll
-    for (int it = 0; it < INST; ++it) {
-        int r = m0 + (wave + it * NW) * 8 + lrow;
-        r = r < p.M ? r : p.M - 1;
-        const int hw = p.Hout * p.Wout;
-        const int bi = r / hw, rem = r - bi * hw;
+    for (int it = 0; it < XI; ++it) {
+        int q = m0 - 1 + (wave + it * NW) * 8 + lrow;
+        q = q < 0 ? 0 : (q < p.M ? q : p.M - 1);
+        const int bi = q / hw, rem = q - bi * hw;
         a_y[it] = rem / p.Wout;
         a_x[it] = rem - a_y[it] * p.Wout;
         a_img[it] = (int64_t)bi * (p.Hout >> p.ups) * (p.Wout >> p.ups) * p.Cin;
     }
+    const bf16_t* w_src[WI];
 #pragma unroll
-    for (int it = 0; it < INST_W; ++it) {
+    for (int it = 0; it < WI; ++it) {
         int n = n0 + (wave + it * NW) * 8 + lrow;
         n = n < p.N ? n : p.N - 1;
         w_src[it] = p.W + (int64_t)n * p.ldw + schunk * 8;
     }
     const int win = p.Wout >> p.ups;
-    const int kt_per_tap = C / X3_BK;
-    auto stage = [&](int buf, int kt) {
-        char* base = smem + buf * X3_STAGE;
-        const int tap = kt / kt_per_tap, c0 = (kt - tap * kt_per_tap) * X3_BK;
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const int slices = C / X3_BK;
+    // group g = (dy, 64-channel slice): one pixel stage, three k-tiles (dx = -1, 0, +1) that each stage their own weights
+    auto stage_x = [&](int g) {
+        char* base = smem;
+        const int dyi = g / slices, c0 = (g - dyi * slices) * X3_BK;
 #pragma unroll
-        for (int it = 0; it < INST; ++it) {
-            const int yy = a_y[it] + dy, xx = a_x[it] + dx;
-            const bool ok = (unsigned)yy < (unsigned)p.Hout && (unsigned)xx < (unsigned)p.Wout;
-            const bf16_t* hi = ok ? p.A + a_img[it] + ((int64_t)(yy >> p.ups) * win + (xx >> p.ups)) * p.Cin + c0 + schunk * 8
+        for (int it = 0; it < XI; ++it) {
+            if (wave + it * NW >= X3_XINST) break;    // wave-uniform
+            const int yy = a_y[it] + dyi - 1;
+            const bool ok = (unsigned)yy < (unsigned)p.Hout;
+            const bf16_t* hi = ok ? p.A + a_img[it] + ((int64_t)(yy >> p.ups) * win + (a_x[it] >> p.ups)) * p.Cin + c0 + schunk * 8
                                   : p.zero_page + schunk * 8;
             const bf16_t* lo = ok ? hi + 2 * C : hi;                          // [hi | hi | lo]
             char* dst = base + (wave + it * NW) * 1024;
             __builtin_amdgcn_global_load_lds((x3_gptr_t)hi, (x3_lds_ptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((x3_gptr_t)lo, (x3_lds_ptr_t)(dst + X3_PIECE), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((x3_gptr_t)lo, (x3_lds_ptr_t)(dst + X3_XPIECE), 16, 0, 0);
         }
+    };
+    auto stage_w = [&](int buf, int g, int dxi) {
+        char* base = smem + X3_XSTAGE + buf * X3_WSTAGE;
+        const int dyi = g / slices, c0 = (g - dyi * slices) * X3_BK;
+        const int tap = dyi * 3 + dxi;
 #pragma unroll
-        for (int it = 0; it < INST_W; ++it) {
-            char* dst = base + 2 * X3_PIECE + (wave + it * NW) * 1024;
+        for (int it = 0; it < WI; ++it) {
+            char* dst = base + (wave + it * NW) * 1024;
             const bf16_t* wh = w_src[it] + (int64_t)tap * p.Cin + c0;         // per tap [hi | lo | hi]
             __builtin_amdgcn_global_load_lds((x3_gptr_t)wh, (x3_lds_ptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((x3_gptr_t)(wh + C), (x3_lds_ptr_t)(dst + X3_PIECE_W), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((x3_gptr_t)(wh + C), (x3_lds_ptr_t)(dst + X3_WPIECE), 16, 0, 0);
         }
     };
 
-    int frag_off[2];
+    // fragment offsets: a lane's pixel row of tap dx is LDS row (lane & 15) + 1 + dx of its 16-row block
+    int off_x[3][2], off_w[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) frag_off[ks] = (lane & 15) * 128 + (((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4);
+    for (int ks = 0; ks < 2; ++ks) {
+        off_w[ks] = (lane & 15) * 128 + (((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4);
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi) {
+            const int r = (lane & 15) + dxi;
+            off_x[dxi][ks] = r * 128 + (((ks * 4 + (lane >> 4)) ^ (r & 7)) << 4);
+        }
+    }
+    // a pixel in the first / last column of its image row has no left / right neighbour: the shifted LDS row holds the
+    // neighbouring image row's pixel there, so the fragment is zeroed instead (bit i: block i of this wave)
+    uint32_t no_left = 0, no_right = 0;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        int m = m0 + wm * TM + i * 16 + (lane & 15);
+        m = m < p.M ? m : p.M - 1;
+        const int x = (m % hw) % p.Wout;
+        no_left |= (x == 0 ? 1u : 0u) << i;
+        no_right |= (x == p.Wout - 1 ? 1u : 0u) << i;
+    }
 
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -112,22 +145,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = 9 * kt_per_tap;
-    stage(0, 0);
-    __syncthreads();          // (hipcc drains the LDS-DMA before the barrier)
-    auto load_frags = [&](const char* ta, const char* tb, int ks, bf16x8_t (&ah)[FM], bf16x8_t (&al)[FM], bf16x8_t (&bh)[FN],
-                          bf16x8_t (&bl)[FN]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            ah[i] = *reinterpret_cast<const bf16x8_t*>(ta + i * 2048 + frag_off[ks]);
-            al[i] = *reinterpret_cast<const bf16x8_t*>(ta + X3_PIECE + i * 2048 + frag_off[ks]);
-        }
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            bh[j] = *reinterpret_cast<const bf16x8_t*>(tb + j * 2048 + frag_off[ks]);
-            bl[j] = *reinterpret_cast<const bf16x8_t*>(tb + X3_PIECE_W + j * 2048 + frag_off[ks]);
-        }
-    };
+    // Waits are counted by hand (raw s_barrier: __syncthreads() would drain every LDS-DMA): a wave has 2 * WI = 4 weight
+    // instructions per k-tile in flight behind whatever the next k-tile reads.
+    const int ngroups = 3 * slices, nk = 3 * ngroups;
+    stage_x(0);
+    stage_w(0, 0, 0);
+    stage_w(1, 0, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     // the three products of one 32-deep step; small terms first, the hi * hi product last
     auto products = [&](const bf16x8_t (&ah)[FM], const bf16x8_t (&al)[FM], const bf16x8_t (&bh)[FN], const bf16x8_t (&bl)[FN])
                         __attribute__((always_inline)) {
@@ -144,24 +169,68 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
     };
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const char* ta = smem + cur * X3_STAGE + wm * TM * 128;
-        const char* tb = smem + cur * X3_STAGE + 2 * X3_PIECE + wn * TN * 128;
-        // order (pinned): fragments of step 0 | request the next tile | fragments of step 1 | products 0 | products 1.  The
-        // second step's LDS latency and the DMA issue sit under the first step's 24 MFMAs.
-        bf16x8_t ah0[FM], al0[FM], bh0[FN], bl0[FN], ah1[FM], al1[FM], bh1[FN], bl1[FN];
-        load_frags(ta, tb, 0, ah0, al0, bh0, bl0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_frags(ta, tb, 1, ah1, al1, bh1, bl1);
-        __builtin_amdgcn_sched_barrier(0);
-        products(ah0, al0, bh0, bl0);
-        __builtin_amdgcn_sched_barrier(0);
-        products(ah1, al1, bh1, bl1);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+    for (int g = 0; g < ngroups; ++g) {
+        const char* ta = smem + wm * TM * 128;
+        static_for<3>([&](auto dxi_c) {
+            constexpr int dxi = decltype(dxi_c)::value;      // k-tile kt = 3g + dxi reads weight slot dxi
+            const int kt = 3 * g + dxi;
+            const char* tb = smem + X3_XSTAGE + dxi * X3_WSTAGE + wn * TN * 128;
+            auto load_frags = [&](int ks, bf16x8_t (&ah)[FM], bf16x8_t (&al)[FM], bf16x8_t (&bh)[FN], bf16x8_t (&bl)[FN])
+                                  __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8_t*>(ta + i * 2048 + off_x[dxi][ks]);
+                    al[i] = *reinterpret_cast<const bf16x8_t*>(ta + X3_XPIECE + i * 2048 + off_x[dxi][ks]);
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8_t*>(tb + j * 2048 + off_w[ks]);
+                    bl[j] = *reinterpret_cast<const bf16x8_t*>(tb + X3_WPIECE + j * 2048 + off_w[ks]);
+                }
+            };
+            auto mask = [&](bf16x8_t (&ah)[FM], bf16x8_t (&al)[FM]) __attribute__((always_inline)) {
+                if constexpr (dxi != 1) {
+                    const uint32_t bits = dxi == 0 ? no_left : no_right;
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        const bool z = (bits >> i) & 1u;
+                        const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                        ah[i] = z ? zero : ah[i];
+                        al[i] = z ? zero : al[i];
+                    }
+                }
+            };
+            // order (pinned): fragments of step 0 | weights of k-tile kt + 2 into the slot k-tile kt - 1 read | fragments of
+            // step 1 | products.  On the last tap of a group every wave is done with the pixel stage once its fragments have
+            // arrived: a barrier there frees it for the next group's pixels, requested BEFORE that k-tile's weight prefetch
+            // so that the closing vmcnt(4) covers them.
+            bf16x8_t ah0[FM], al0[FM], bh0[FN], bl0[FN], ah1[FM], al1[FM], bh1[FN], bl1[FN];
+            const bool more = kt + 2 < nk;                   // (then group g + 1 exists as well when dxi == 2)
+            load_frags(0, ah0, al0, bh0, bl0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (dxi < 2 && more) stage_w((dxi + 2) % 3, dxi == 0 ? g : g + 1, (dxi + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(1, ah1, al1, bh1, bl1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (dxi == 2) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (g + 1 < ngroups) {
+                    stage_x(g + 1);
+                    stage_w(1, g + 1, 1);                    // k-tile kt + 2 = (g + 1, tap 1)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mask(ah0, al0);
+            products(ah0, al0, bh0, bl0);
+            __builtin_amdgcn_sched_barrier(0);
+            mask(ah1, al1);
+            products(ah1, al1, bh1, bl1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        });
     }
     gemm_epilogue_f32io<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
@@ -172,16 +241,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
 int conv3x3_x3_launch(const GemmParams& p, hipStream_t s) {
     ADVGRPO_CHECK(p.conv && p.f32_io && p.Cin % 192 == 0 && p.zero_page && p.batch == 1 && p.splitk == 1,
                   "conv3x3_x3: bad parameter block");
-    constexpr int BM = 192, LDS = x3_lds_bytes(BM);
     static bool attr_set = false;
     if (!attr_set) {
-        ADVGRPO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<BM>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess,
-                      "conv3x3_x3: %d bytes of LDS refused", LDS);
+        ADVGRPO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) == hipSuccess,
+                      "conv3x3_x3: %d bytes of LDS refused", X3_LDS);
         attr_set = true;
     }
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + X3_BN - 1) / X3_BN);
-    hipLaunchKernelGGL(conv3x3_x3_kernel<BM>, dim3(tiles), dim3(512), LDS, s, p);
+    const int tiles = ((p.M + X3_BM - 1) / X3_BM) * ((p.N + X3_BN - 1) / X3_BN);
+    hipLaunchKernelGGL(conv3x3_x3_kernel, dim3(tiles), dim3(512), X3_LDS, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
