@@ -31,6 +31,7 @@
 // 66.0.  What is left per k-tile is the fragment-read phase in front of the MFMAs (both waves of a SIMD are in the same phase)
 // and the prologue / epilogue of a one-workgroup-per-CU, non-persistent tile.
 #include "gemm_device.hpp"
+#include <cstdlib>
 
 namespace advgrpo {
 
@@ -47,6 +48,9 @@ constexpr int X3_WPIECE = X3_BN * X3_BK * 2;         // 16 KiB: 128 output chann
 constexpr int X3_WSTAGE = 2 * X3_WPIECE;             // w_hi, w_lo
 constexpr int X3_LDS = X3_XSTAGE + 3 * X3_WSTAGE;    // 146 KiB: a ring of three weight stages (the tap index IS the ring slot)
 
+// DBG (experiments build only, scripts/probes/x3_decompose.sh): 1 = no DMA after the prologue, 2 = no MFMAs, 3 = fragments read
+// once -- WRONG results, used to price the three activities of the k loop against each other
+template <int DBG = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) {
     constexpr int NW = X3_WM * X3_WN, TM = X3_BM / X3_WM, TN = X3_BN / X3_WN, FM = TM / 16, FN = TN / 16;
     constexpr int XI = (X3_XINST + NW - 1) / NW;     // pixel-piece DMA instructions per wave: 3 (the last one on 5 waves only)
@@ -206,26 +210,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
             // so that the closing vmcnt(4) covers them.
             bf16x8_t ah0[FM], al0[FM], bh0[FN], bl0[FN], ah1[FM], al1[FM], bh1[FN], bl1[FN];
             const bool more = kt + 2 < nk;                   // (then group g + 1 exists as well when dxi == 2)
-            load_frags(0, ah0, al0, bh0, bl0);
+            if (DBG != 3 || kt == 0) load_frags(0, ah0, al0, bh0, bl0);
             __builtin_amdgcn_sched_barrier(0);
-            if (dxi < 2 && more) stage_w((dxi + 2) % 3, dxi == 0 ? g : g + 1, (dxi + 2) % 3);
+            if (dxi < 2 && more && DBG != 1) stage_w((dxi + 2) % 3, dxi == 0 ? g : g + 1, (dxi + 2) % 3);
             __builtin_amdgcn_sched_barrier(0);
-            load_frags(1, ah1, al1, bh1, bl1);
+            if (DBG != 3 || kt == 0) load_frags(1, ah1, al1, bh1, bl1);
             __builtin_amdgcn_sched_barrier(0);
             if (dxi == 2) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if (g + 1 < ngroups) {
+                if (g + 1 < ngroups && DBG != 1) {
                     stage_x(g + 1);
                     stage_w(1, g + 1, 1);                    // k-tile kt + 2 = (g + 1, tap 1)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            mask(ah0, al0);
-            products(ah0, al0, bh0, bl0);
-            __builtin_amdgcn_sched_barrier(0);
-            mask(ah1, al1);
-            products(ah1, al1, bh1, bl1);
+            if (DBG != 2) {
+                mask(ah0, al0);
+                products(ah0, al0, bh0, bl0);
+                __builtin_amdgcn_sched_barrier(0);
+                mask(ah1, al1);
+                products(ah1, al1, bh1, bl1);
+            } else {
+                acc[0][0] += __builtin_bit_cast(f32x4, ah0[0]) + __builtin_bit_cast(f32x4, bl1[FN - 1]) +
+                             __builtin_bit_cast(f32x4, al1[FM - 1]) + __builtin_bit_cast(f32x4, bh0[0]);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -243,13 +252,25 @@ int conv3x3_x3_launch(const GemmParams& p, hipStream_t s) {
                   "conv3x3_x3: bad parameter block");
     static bool attr_set = false;
     if (!attr_set) {
-        ADVGRPO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel),
+        ADVGRPO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) == hipSuccess,
                       "conv3x3_x3: %d bytes of LDS refused", X3_LDS);
         attr_set = true;
     }
     const int tiles = ((p.M + X3_BM - 1) / X3_BM) * ((p.N + X3_BN - 1) / X3_BN);
-    hipLaunchKernelGGL(conv3x3_x3_kernel, dim3(tiles), dim3(512), X3_LDS, s, p);
+#ifdef ADVGRPO_EXPERIMENTS
+    static const int dbg = getenv("ADVGRPO_X3_DBG") ? atoi(getenv("ADVGRPO_X3_DBG")) : 0;
+    if (dbg) {
+        const void* k = dbg == 1 ? (const void*)conv3x3_x3_kernel<1> : dbg == 2 ? (const void*)conv3x3_x3_kernel<2> : (const void*)conv3x3_x3_kernel<3>;
+        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+        if (dbg == 1) hipLaunchKernelGGL(conv3x3_x3_kernel<1>, dim3(tiles), dim3(512), X3_LDS, s, p);
+        else if (dbg == 2) hipLaunchKernelGGL(conv3x3_x3_kernel<2>, dim3(tiles), dim3(512), X3_LDS, s, p);
+        else hipLaunchKernelGGL(conv3x3_x3_kernel<3>, dim3(tiles), dim3(512), X3_LDS, s, p);
+        ADVGRPO_LAUNCH_CHECK();
+        return 0;
+    }
+#endif
+    hipLaunchKernelGGL(conv3x3_x3_kernel<0>, dim3(tiles), dim3(512), X3_LDS, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
