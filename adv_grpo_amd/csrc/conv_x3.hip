@@ -28,8 +28,9 @@
 // Measured (8 x 512^2 decode, same box): round-2 form 83.9 ms; one stage per tap, 128-pixel tile 73.6; 192-pixel tile 69.9
 // (the kernel pays a fixed latency per k-tile -- DMA round trip, fragment reads in front of the first MFMA, barrier -- so
 // more MFMAs per k-tile pay, fewer bytes alone do not: the shared pixel stage with two weight stages gave 0.6 ms); weight ring
-// 66.0.  What is left per k-tile is the fragment-read phase in front of the MFMAs (both waves of a SIMD are in the same phase)
-// and the prologue / epilogue of a one-workgroup-per-CU, non-persistent tile.
+// 66.0; fragment reads issued and waited for by hand, seven at a time in the order the products consume them, 65.5 (hipcc
+// had put all 28 reads of a k-tile in front of its first MFMA).  What is left: both waves of a SIMD run the same phase at the
+// same time, and a one-workgroup-per-CU, non-persistent tile exposes its prologue and epilogue.
 #include "gemm_device.hpp"
 #include <cstdlib>
 
@@ -47,6 +48,32 @@ constexpr int X3_XSTAGE = 2 * X3_XPIECE;             // x_hi, x_lo: ONE stage, r
 constexpr int X3_WPIECE = X3_BN * X3_BK * 2;         // 16 KiB: 128 output channels x 64 input channels of one tap
 constexpr int X3_WSTAGE = 2 * X3_WPIECE;             // w_hi, w_lo
 constexpr int X3_LDS = X3_XSTAGE + 3 * X3_WSTAGE;    // 146 KiB: a ring of three weight stages (the tap index IS the ring slot)
+
+// Fragment reads are issued and waited for by hand: hipcc puts s_waitcnt lgkmcnt(0) in front of the first MFMA that consumes an
+// LDS read, i.e. every read of a k-tile in front of its first MFMA.  The wait statement takes the registers it releases as
+// in/out operands, so nothing that uses them can be scheduled above it (LDS returns data in order; lgkmcnt has 4 bits: at
+// most 15 reads are left in flight).
+template <int OFF>
+__device__ __forceinline__ void x3_lds_read(bf16x8_t& d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int CNT>
+__device__ __forceinline__ void x3_release(bf16x8_t (&a)[3], bf16x8_t (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%7)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 : "n"(CNT));
+}
+template <int CNT>
+__device__ __forceinline__ void x3_release_x(bf16x8_t (&a)[3], bf16x8_t (&b)[3], bf16x8_t (&c)[3], bf16x8_t (&d)[3]) {
+    asm volatile("s_waitcnt lgkmcnt(%12)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]),
+                   "+v"(d[0]), "+v"(d[1]), "+v"(d[2])
+                 : "n"(CNT));
+}
+template <int CNT>
+__device__ __forceinline__ void x3_release_w(bf16x8_t (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(CNT));
+}
 
 // DBG (experiments build only, scripts/probes/x3_decompose.sh): 1 = no DMA after the prologue, 2 = no MFMAs, 3 = fragments read
 // once -- WRONG results, used to price the three activities of the k loop against each other
@@ -157,83 +184,114 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
     stage_w(1, 0, 1);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // the three products of one 32-deep step; small terms first, the hi * hi product last
-    auto products = [&](const bf16x8_t (&ah)[FM], const bf16x8_t (&al)[FM], const bf16x8_t (&bh)[FN], const bf16x8_t (&bl)[FN])
-                        __attribute__((always_inline)) {
+    static_assert(FM == 3 && FN == 4, "the hand-counted fragment waits are written for a 48 x 64 wave tile");
+    auto product = [&](const bf16x8_t (&a)[FM], const bf16x8_t (&b)[FN]) __attribute__((always_inline)) {
+        if constexpr (DBG != 2) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        } else {
+            acc[0][0] += __builtin_bit_cast(f32x4, a[0]) + __builtin_bit_cast(f32x4, b[FN - 1]);
+        }
     };
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+    uint32_t xa[3][2], wa[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        wa[ks] = lds0 + X3_XSTAGE + wn * TN * 128 + off_w[ks];
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi) xa[dxi][ks] = lds0 + wm * TM * 128 + off_x[dxi][ks];
+    }
     for (int g = 0; g < ngroups; ++g) {
-        const char* ta = smem + wm * TM * 128;
         static_for<3>([&](auto dxi_c) {
             constexpr int dxi = decltype(dxi_c)::value;      // k-tile kt = 3g + dxi reads weight slot dxi
             const int kt = 3 * g + dxi;
-            const char* tb = smem + X3_XSTAGE + dxi * X3_WSTAGE + wn * TN * 128;
-            auto load_frags = [&](int ks, bf16x8_t (&ah)[FM], bf16x8_t (&al)[FM], bf16x8_t (&bh)[FN], bf16x8_t (&bl)[FN])
-                                  __attribute__((always_inline)) {
-#pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    ah[i] = *reinterpret_cast<const bf16x8_t*>(ta + i * 2048 + off_x[dxi][ks]);
-                    al[i] = *reinterpret_cast<const bf16x8_t*>(ta + X3_XPIECE + i * 2048 + off_x[dxi][ks]);
-                }
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    bh[j] = *reinterpret_cast<const bf16x8_t*>(tb + j * 2048 + off_w[ks]);
-                    bl[j] = *reinterpret_cast<const bf16x8_t*>(tb + X3_WPIECE + j * 2048 + off_w[ks]);
-                }
+            const uint32_t wb0 = wa[0] + dxi * X3_WSTAGE, wb1 = wa[1] + dxi * X3_WSTAGE;
+            auto read_x = [&](uint32_t a, bf16x8_t (&h)[FM], bf16x8_t (&l)[FM], bool hi, bool lo) __attribute__((always_inline)) {
+                if (hi) { x3_lds_read<0>(h[0], a); x3_lds_read<2048>(h[1], a); x3_lds_read<4096>(h[2], a); }
+                if (lo) { x3_lds_read<X3_XPIECE>(l[0], a); x3_lds_read<X3_XPIECE + 2048>(l[1], a); x3_lds_read<X3_XPIECE + 4096>(l[2], a); }
             };
-            auto mask = [&](bf16x8_t (&ah)[FM], bf16x8_t (&al)[FM]) __attribute__((always_inline)) {
+            auto read_wh = [&](uint32_t a, bf16x8_t (&b)[FN]) __attribute__((always_inline)) {
+                x3_lds_read<0>(b[0], a); x3_lds_read<2048>(b[1], a); x3_lds_read<4096>(b[2], a); x3_lds_read<6144>(b[3], a);
+            };
+            auto read_wl = [&](uint32_t a, bf16x8_t (&b)[FN]) __attribute__((always_inline)) {
+                x3_lds_read<X3_WPIECE>(b[0], a); x3_lds_read<X3_WPIECE + 2048>(b[1], a);
+                x3_lds_read<X3_WPIECE + 4096>(b[2], a); x3_lds_read<X3_WPIECE + 6144>(b[3], a);
+            };
+            auto mask = [&](bf16x8_t (&f)[FM]) __attribute__((always_inline)) {
                 if constexpr (dxi != 1) {
                     const uint32_t bits = dxi == 0 ? no_left : no_right;
 #pragma unroll
                     for (int i = 0; i < FM; ++i) {
                         const bool z = (bits >> i) & 1u;
                         const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
-                        ah[i] = z ? zero : ah[i];
-                        al[i] = z ? zero : al[i];
+                        f[i] = z ? zero : f[i];
                     }
                 }
             };
-            // order (pinned): fragments of step 0 | weights of k-tile kt + 2 into the slot k-tile kt - 1 read | fragments of
-            // step 1 | products.  On the last tap of a group every wave is done with the pixel stage once its fragments have
-            // arrived: a barrier there frees it for the next group's pixels, requested BEFORE that k-tile's weight prefetch
-            // so that the closing vmcnt(4) covers them.
             bf16x8_t ah0[FM], al0[FM], bh0[FN], bl0[FN], ah1[FM], al1[FM], bh1[FN], bl1[FN];
             const bool more = kt + 2 < nk;                   // (then group g + 1 exists as well when dxi == 2)
-            if (DBG != 3 || kt == 0) load_frags(0, ah0, al0, bh0, bl0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (dxi < 2 && more && DBG != 1) stage_w((dxi + 2) % 3, dxi == 0 ? g : g + 1, (dxi + 2) % 3);
-            __builtin_amdgcn_sched_barrier(0);
-            if (DBG != 3 || kt == 0) load_frags(1, ah1, al1, bh1, bl1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (dxi == 2) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const bool rd = DBG != 3 || kt == 0;
+            if constexpr (dxi < 2) {
+                // reads in the order the products need them, seven at a time, the next seven requested before the wait that
+                // releases the previous ones; the weights of k-tile kt + 2 go into the slot k-tile kt - 1 read
+                if (rd) { read_x(xa[dxi][0], ah0, al0, true, false); read_wl(wb0, bl0); }
+                if (rd) { read_x(xa[dxi][0], ah0, al0, false, true); read_wh(wb0, bh0); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && DBG != 1) stage_w((dxi + 2) % 3, dxi == 0 ? g : g + 1, (dxi + 2) % 3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) x3_release<7>(ah0, bl0);
+                mask(ah0);
+                product(ah0, bl0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) { read_x(xa[dxi][1], ah1, al1, true, false); read_wl(wb1, bl1); }
+                if (rd) x3_release<7>(al0, bh0);
+                mask(al0);
+                product(al0, bh0);
+                product(ah0, bh0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) { read_x(xa[dxi][1], ah1, al1, false, true); read_wh(wb1, bh1); }
+                if (rd) x3_release<7>(ah1, bl1);
+                mask(ah1);
+                product(ah1, bl1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) x3_release<0>(al1, bh1);
+                mask(al1);
+                product(al1, bh1);
+                product(ah1, bh1);
+            } else {
+                // last tap of a group: the twelve pixel reads first -- once they have arrived on every wave (barrier) the
+                // single pixel stage is free for the next group's pixels, requested BEFORE this k-tile's weight prefetch so
+                // that the closing vmcnt(4) covers them
+                if (rd) { read_x(xa[dxi][0], ah0, al0, true, true); read_x(xa[dxi][1], ah1, al1, true, true); }
+                if (rd) read_wl(wb0, bl0);                    // (a 16th read: the hardware holds it until the first returns)
+                if (rd) x3_release_x<4>(ah0, al0, ah1, al1);
                 __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
                 if (g + 1 < ngroups && DBG != 1) {
                     stage_x(g + 1);
                     stage_w(1, g + 1, 1);                    // k-tile kt + 2 = (g + 1, tap 1)
                 }
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            if (DBG != 2) {
-                mask(ah0, al0);
-                products(ah0, al0, bh0, bl0);
+                if (rd) { read_wh(wb0, bh0); read_wl(wb1, bl1); read_wh(wb1, bh1); }
+                if (rd) x3_release_w<12>(bl0);
+                mask(ah0);
+                product(ah0, bl0);
                 __builtin_amdgcn_sched_barrier(0);
-                mask(ah1, al1);
-                products(ah1, al1, bh1, bl1);
-            } else {
-                acc[0][0] += __builtin_bit_cast(f32x4, ah0[0]) + __builtin_bit_cast(f32x4, bl1[FN - 1]) +
-                             __builtin_bit_cast(f32x4, al1[FM - 1]) + __builtin_bit_cast(f32x4, bh0[0]);
+                if (rd) x3_release_w<8>(bh0);
+                mask(al0);
+                product(al0, bh0);
+                product(ah0, bh0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) x3_release_w<4>(bl1);
+                mask(ah1);
+                product(ah1, bl1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) x3_release_w<0>(bh1);
+                mask(al1);
+                product(al1, bh1);
+                product(ah1, bh1);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
