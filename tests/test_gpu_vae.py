@@ -11,7 +11,10 @@ def test_conv3x3_implicit_gemm_matches_fp32_conv():
     # Cout >= 128 runs on the dedicated kernel (192-pixel tiles: 768 = 4 x 192 pixels, 1600 is ragged), below it on the
     # generic one over the tripled contraction axis
     for (B, H, W, Ci, Co, up) in [(2, 16, 24, 64, 96, False), (1, 8, 8, 128, 64, True), (2, 32, 32, 128, 3, False),
-                                  (2, 16, 24, 64, 128, False), (1, 20, 20, 128, 256, True), (1, 13, 11, 192, 384, False)]:
+                                  (2, 16, 24, 64, 128, False), (1, 20, 20, 128, 256, True), (1, 13, 11, 192, 384, False),
+                                  # degenerate rows / columns: every pixel is at both image-row edges (W = 1), one image row
+                                  # (H = 1), tiles that straddle images (3 x 65 pixels), an odd upsampled width
+                                  (2, 7, 1, 64, 128, False), (3, 1, 65, 64, 128, False), (5, 3, 3, 64, 128, True)]:
         x = torch.randn(B, H, W, Ci, device="cuda", generator=g).to(torch.bfloat16)
         wt = (torch.randn(Co, Ci, 3, 3, device="cuda", generator=g) / (3 * Ci ** 0.5)).to(torch.bfloat16)
         bias = torch.randn(Co, device="cuda", generator=g).to(torch.bfloat16)
@@ -91,7 +94,10 @@ def test_split_bf16x3_kernels_vs_fp32():
     # Cout >= 128 runs on the dedicated kernel (192-pixel tiles: 768 = 4 x 192 pixels, 1600 is ragged), below it on the
     # generic one over the tripled contraction axis
     for (B, H, W, Ci, Co, up) in [(2, 16, 24, 64, 96, False), (1, 8, 8, 128, 64, True), (2, 32, 32, 128, 3, False),
-                                  (2, 16, 24, 64, 128, False), (1, 20, 20, 128, 256, True), (1, 13, 11, 192, 384, False)]:
+                                  (2, 16, 24, 64, 128, False), (1, 20, 20, 128, 256, True), (1, 13, 11, 192, 384, False),
+                                  # degenerate rows / columns: every pixel is at both image-row edges (W = 1), one image row
+                                  # (H = 1), tiles that straddle images (3 x 65 pixels), an odd upsampled width
+                                  (2, 7, 1, 64, 128, False), (3, 1, 65, 64, 128, False), (5, 3, 3, 64, 128, True)]:
         x = torch.randn(B, H, W, Ci, device="cuda", generator=g)
         wt = torch.randn(Co, Ci, 3, 3, device="cuda", generator=g) / (3 * Ci ** 0.5)
         bias = torch.randn(Co, device="cuda", generator=g)
