@@ -41,7 +41,11 @@ namespace {
 typedef __attribute__((address_space(3))) void* x3_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* x3_gptr_t;
 
-constexpr int X3_BM = 192, X3_BN = 128, X3_WM = 4, X3_WN = 2, X3_BK = 64;
+constexpr int X3_BM = 192, X3_BN = 128, X3_BK = 64;
+#ifndef X3_GRID_M
+#define X3_GRID_M 4
+#define X3_GRID_N 2
+#endif
 constexpr int X3_XINST = (X3_BM + 2 + 7) / 8;        // 25 DMA instructions (8 pixel rows each) per pixel piece: pixels m0-1 .. m0+198
 constexpr int X3_XPIECE = X3_XINST * 1024;           // 25 KiB: the tile's pixels and one halo pixel on each side, 64 channels
 constexpr int X3_XSTAGE = 2 * X3_XPIECE;             // x_hi, x_lo: ONE stage, reloaded once per three k-tiles
@@ -58,30 +62,23 @@ __device__ __forceinline__ void x3_lds_read(bf16x8_t& d, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
 template <int CNT>
-__device__ __forceinline__ void x3_release(bf16x8_t (&a)[3], bf16x8_t (&b)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(%7)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
-                 : "n"(CNT));
+__device__ __forceinline__ void x3_wait_reads() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(CNT));
 }
-template <int CNT>
-__device__ __forceinline__ void x3_release_x(bf16x8_t (&a)[3], bf16x8_t (&b)[3], bf16x8_t (&c)[3], bf16x8_t (&d)[3]) {
-    asm volatile("s_waitcnt lgkmcnt(%12)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]),
-                   "+v"(d[0]), "+v"(d[1]), "+v"(d[2])
-                 : "n"(CNT));
-}
-template <int CNT>
-__device__ __forceinline__ void x3_release_w(bf16x8_t (&b)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(CNT));
+// (volatile statements keep their order: a register tied here cannot be used above the wait in front of it)
+template <int N>
+__device__ __forceinline__ void x3_tie(bf16x8_t (&a)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a[i]));
 }
 
 // DBG (experiments build only, scripts/probes/x3_decompose.sh): 1 = no DMA after the prologue, 2 = no MFMAs, 3 = fragments read
 // once -- WRONG results, used to price the three activities of the k loop against each other
-template <int DBG = 0>
-__global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) {
+template <int X3_WM, int X3_WN, int DBG = 0>
+__global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const GemmParams p) {
     constexpr int NW = X3_WM * X3_WN, TM = X3_BM / X3_WM, TN = X3_BN / X3_WN, FM = TM / 16, FN = TN / 16;
-    constexpr int XI = (X3_XINST + NW - 1) / NW;     // pixel-piece DMA instructions per wave: 3 (the last one on 5 waves only)
-    constexpr int WI = X3_BN / 8 / NW;               // weight-piece DMA instructions per wave: 2
+    constexpr int XI = (X3_XINST + NW - 1) / NW;     // pixel-piece DMA instructions per wave (the last one on some waves only)
+    constexpr int WI = X3_BN / 8 / NW;               // weight-piece DMA instructions per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,9 +179,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
     stage_x(0);
     stage_w(0, 0, 0);
     stage_w(1, 0, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * WI) : "memory");
     __builtin_amdgcn_s_barrier();
-    static_assert(FM == 3 && FN == 4, "the hand-counted fragment waits are written for a 48 x 64 wave tile");
+    static_assert(FM + FN <= 15 && 3 * FN <= 15, "lgkmcnt counts at most 15 reads in flight");
     auto product = [&](const bf16x8_t (&a)[FM], const bf16x8_t (&b)[FN]) __attribute__((always_inline)) {
         if constexpr (DBG != 2) {
 #pragma unroll
@@ -209,15 +206,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
             const int kt = 3 * g + dxi;
             const uint32_t wb0 = wa[0] + dxi * X3_WSTAGE, wb1 = wa[1] + dxi * X3_WSTAGE;
             auto read_x = [&](uint32_t a, bf16x8_t (&h)[FM], bf16x8_t (&l)[FM], bool hi, bool lo) __attribute__((always_inline)) {
-                if (hi) { x3_lds_read<0>(h[0], a); x3_lds_read<2048>(h[1], a); x3_lds_read<4096>(h[2], a); }
-                if (lo) { x3_lds_read<X3_XPIECE>(l[0], a); x3_lds_read<X3_XPIECE + 2048>(l[1], a); x3_lds_read<X3_XPIECE + 4096>(l[2], a); }
+                if (hi) static_for<FM>([&](auto i) { x3_lds_read<decltype(i)::value * 2048>(h[decltype(i)::value], a); });
+                if (lo) static_for<FM>([&](auto i) { x3_lds_read<X3_XPIECE + decltype(i)::value * 2048>(l[decltype(i)::value], a); });
             };
             auto read_wh = [&](uint32_t a, bf16x8_t (&b)[FN]) __attribute__((always_inline)) {
-                x3_lds_read<0>(b[0], a); x3_lds_read<2048>(b[1], a); x3_lds_read<4096>(b[2], a); x3_lds_read<6144>(b[3], a);
+                static_for<FN>([&](auto j) { x3_lds_read<decltype(j)::value * 2048>(b[decltype(j)::value], a); });
             };
             auto read_wl = [&](uint32_t a, bf16x8_t (&b)[FN]) __attribute__((always_inline)) {
-                x3_lds_read<X3_WPIECE>(b[0], a); x3_lds_read<X3_WPIECE + 2048>(b[1], a);
-                x3_lds_read<X3_WPIECE + 4096>(b[2], a); x3_lds_read<X3_WPIECE + 6144>(b[3], a);
+                static_for<FN>([&](auto j) { x3_lds_read<X3_WPIECE + decltype(j)::value * 2048>(b[decltype(j)::value], a); });
             };
             auto mask = [&](bf16x8_t (&f)[FM]) __attribute__((always_inline)) {
                 if constexpr (dxi != 1) {
@@ -241,22 +237,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
                 __builtin_amdgcn_sched_barrier(0);
                 if (more && DBG != 1) stage_w((dxi + 2) % 3, dxi == 0 ? g : g + 1, (dxi + 2) % 3);
                 __builtin_amdgcn_sched_barrier(0);
-                if (rd) x3_release<7>(ah0, bl0);
+                if (rd) { x3_wait_reads<FM + FN>(); x3_tie(ah0); x3_tie(bl0); }
                 mask(ah0);
                 product(ah0, bl0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (rd) { read_x(xa[dxi][1], ah1, al1, true, false); read_wl(wb1, bl1); }
-                if (rd) x3_release<7>(al0, bh0);
+                if (rd) { x3_wait_reads<FM + FN>(); x3_tie(al0); x3_tie(bh0); }
                 mask(al0);
                 product(al0, bh0);
                 product(ah0, bh0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (rd) { read_x(xa[dxi][1], ah1, al1, false, true); read_wh(wb1, bh1); }
-                if (rd) x3_release<7>(ah1, bl1);
+                if (rd) { x3_wait_reads<FM + FN>(); x3_tie(ah1); x3_tie(bl1); }
                 mask(ah1);
                 product(ah1, bl1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (rd) x3_release<0>(al1, bh1);
+                if (rd) { x3_wait_reads<0>(); x3_tie(al1); x3_tie(bh1); }
                 mask(al1);
                 product(al1, bh1);
                 product(ah1, bh1);
@@ -265,8 +261,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
                 // single pixel stage is free for the next group's pixels, requested BEFORE this k-tile's weight prefetch so
                 // that the closing vmcnt(4) covers them
                 if (rd) { read_x(xa[dxi][0], ah0, al0, true, true); read_x(xa[dxi][1], ah1, al1, true, true); }
-                if (rd) read_wl(wb0, bl0);                    // (a 16th read: the hardware holds it until the first returns)
-                if (rd) x3_release_x<4>(ah0, al0, ah1, al1);
+                if (rd) read_wl(wb0, bl0);                    // (more than 15 reads: the hardware holds the rest back until the first return)
+                if (rd) { x3_wait_reads<FN>(); x3_tie(ah0); x3_tie(al0); x3_tie(ah1); x3_tie(al1); }
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 if (g + 1 < ngroups && DBG != 1) {
@@ -275,26 +271,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (rd) { read_wh(wb0, bh0); read_wl(wb1, bl1); read_wh(wb1, bh1); }
-                if (rd) x3_release_w<12>(bl0);
+                if (rd) { x3_wait_reads<3 * FN>(); x3_tie(bl0); }
                 mask(ah0);
                 product(ah0, bl0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (rd) x3_release_w<8>(bh0);
+                if (rd) { x3_wait_reads<2 * FN>(); x3_tie(bh0); }
                 mask(al0);
                 product(al0, bh0);
                 product(ah0, bh0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (rd) x3_release_w<4>(bl1);
+                if (rd) { x3_wait_reads<FN>(); x3_tie(bl1); }
                 mask(ah1);
                 product(ah1, bl1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (rd) x3_release_w<0>(bh1);
+                if (rd) { x3_wait_reads<0>(); x3_tie(bh1); }
                 mask(al1);
                 product(al1, bh1);
                 product(ah1, bh1);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * WI) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         });
@@ -308,27 +304,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x3_kernel(const GemmParams p) 
 int conv3x3_x3_launch(const GemmParams& p, hipStream_t s) {
     ADVGRPO_CHECK(p.conv && p.f32_io && p.Cin % 192 == 0 && p.zero_page && p.batch == 1 && p.splitk == 1,
                   "conv3x3_x3: bad parameter block");
+    constexpr int WM = X3_GRID_M, WN = X3_GRID_N;
     static bool attr_set = false;
     if (!attr_set) {
-        ADVGRPO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<0>),
+        ADVGRPO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<WM, WN, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) == hipSuccess,
                       "conv3x3_x3: %d bytes of LDS refused", X3_LDS);
         attr_set = true;
     }
     const int tiles = ((p.M + X3_BM - 1) / X3_BM) * ((p.N + X3_BN - 1) / X3_BN);
+    const dim3 block(64 * WM * WN);
 #ifdef ADVGRPO_EXPERIMENTS
     static const int dbg = getenv("ADVGRPO_X3_DBG") ? atoi(getenv("ADVGRPO_X3_DBG")) : 0;
     if (dbg) {
-        const void* k = dbg == 1 ? (const void*)conv3x3_x3_kernel<1> : dbg == 2 ? (const void*)conv3x3_x3_kernel<2> : (const void*)conv3x3_x3_kernel<3>;
+        const void* k = dbg == 1 ? (const void*)conv3x3_x3_kernel<WM, WN, 1> : dbg == 2 ? (const void*)conv3x3_x3_kernel<WM, WN, 2>
+                                                                                        : (const void*)conv3x3_x3_kernel<WM, WN, 3>;
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
-        if (dbg == 1) hipLaunchKernelGGL(conv3x3_x3_kernel<1>, dim3(tiles), dim3(512), X3_LDS, s, p);
-        else if (dbg == 2) hipLaunchKernelGGL(conv3x3_x3_kernel<2>, dim3(tiles), dim3(512), X3_LDS, s, p);
-        else hipLaunchKernelGGL(conv3x3_x3_kernel<3>, dim3(tiles), dim3(512), X3_LDS, s, p);
+        if (dbg == 1) hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 1>), dim3(tiles), block, X3_LDS, s, p);
+        else if (dbg == 2) hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 2>), dim3(tiles), block, X3_LDS, s, p);
+        else hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 3>), dim3(tiles), block, X3_LDS, s, p);
         ADVGRPO_LAUNCH_CHECK();
         return 0;
     }
 #endif
-    hipLaunchKernelGGL(conv3x3_x3_kernel<0>, dim3(tiles), dim3(512), X3_LDS, s, p);
+    hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0>), dim3(tiles), block, X3_LDS, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
