@@ -19,6 +19,8 @@ whole rollout.  Two modes:
                  faster, image within 2.3e-2); bench.py prices it next to the default.
 Measured tolerances of both in tests/test_gpu_vae.py.
 """
+import threading
+
 import torch
 
 from . import ops
@@ -34,6 +36,9 @@ class AutoencoderKLDecoder:
         self.dtype = torch.float32          # what the reference's vae.dtype says (PF:668 casts latents to it)
         self.device = torch.device(device)
         self.G = cfg.norm_num_groups
+        self.two_streams = True             # bf16x3 mode: decode a batch as two half batches on two streams
+        self.n_streams = 2
+        self._side, self._side_lock = {}, threading.Lock()
         self.w = {}
         bf = lambda t: t.to(device=self.device, dtype=torch.bfloat16).contiguous()
         if mode == "bf16x3":
@@ -143,7 +148,7 @@ class AutoencoderKLDecoder:
         y = ops.gemm(o3, w[f"{p}.to_out.0.weight"], out_dtype=f32)
         return ops.add_rows_f32(y, x.view(B * T, C), bias=w[f"{p}.to_out.0.bias"]).view(B, H, W, C)
 
-    def _decode_x3(self, latents):
+    def _decode_x3_chain(self, latents):
         cfg = self.cfg
         x = self._conv3("decoder.conv_in", ops.latents_to_nhwc_x3(latents, 64, cfg.scaling_factor, cfg.shift_factor))
         x = self._res3("decoder.mid_block.resnets.0", x)
@@ -158,6 +163,34 @@ class AutoencoderKLDecoder:
                 x = self._conv3(name, ops.split_x3(x, order=2 if self.w[name + ".weight"].shape[0] >= 128 else 0), upsample=True)
         y = self._conv3("decoder.conv_out", self._gn3("decoder.conv_norm_out", x, True))
         return ops.image_postprocess(y)
+
+    def _decode_x3(self, latents):
+        """The decoder is one serial chain in which MFMA-bound convolutions (one workgroup per CU, all of its LDS) alternate with
+        HBM-bound GroupNorm / split passes that need no LDS at all.  A batch of two or more images is decoded as two half
+        batches on two HIP streams: the hardware runs one half's streaming kernels beside the other half's convolutions
+        (the images do not interact and every kernel sums in a fixed order: each image is bit-identical to its single-stream
+        decode, tests/test_gpu_vae.py)."""
+        B = latents.shape[0]
+        n = min(B, self.n_streams) if self.two_streams else 1
+        if n < 2:
+            return self._decode_x3_chain(latents)
+        main = torch.cuda.current_stream(self.device)
+        with self._side_lock:                                    # side streams per calling stream (rollout threads have their own)
+            sides = self._side.setdefault(main.cuda_stream, [])
+            while len(sides) < n - 1:
+                sides.append(torch.cuda.Stream(device=self.device))
+        parts, outs = latents.tensor_split(n), [None] * n
+        for k in range(1, n):
+            side = sides[k - 1]
+            side.wait_stream(main)                               # the latents are complete on the calling stream
+            latents.record_stream(side)
+            with torch.cuda.stream(side):
+                outs[k] = self._decode_x3_chain(parts[k])
+        outs[0] = self._decode_x3_chain(parts[0])
+        for k in range(1, n):
+            main.wait_stream(sides[k - 1])
+            outs[k].record_stream(main)
+        return torch.cat(outs)
 
     @torch.no_grad()
     def decode_to_image(self, latents):

@@ -12,8 +12,11 @@ W = synthetic.vae_decoder_weights(cfg, 4321)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 hw = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 lat = torch.randn(B, 16, hw, hw, device="cuda").to(torch.bfloat16)
-for mode in ("bf16", "bf16x3"):
-    dec = AutoencoderKLDecoder(W, cfg, "cuda", mode=mode)
+for mode in ("bf16", "bf16x3", "bf16x3 one stream", "bf16x3 3 streams", "bf16x3 4 streams"):
+    dec = AutoencoderKLDecoder(W, cfg, "cuda", mode=mode.split()[0])
+    dec.two_streams = "one" not in mode
+    if "streams" in mode:
+        dec.n_streams = int(mode.split()[1])
     for _ in range(2):
         dec.decode_to_image(lat)
     torch.cuda.synchronize()

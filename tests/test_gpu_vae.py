@@ -140,6 +140,26 @@ def test_split_bf16x3_kernels_vs_fp32():
     assert torch.equal(ops.add_rows_f32(a, c, bias), a + c + bias)
 
 
+def test_vae_decode_two_streams_is_bit_identical():
+    """mode="bf16x3" decodes a batch as two half batches on two HIP streams (vae.py: _decode_x3); every image must come out
+    bit for bit as from the single-stream chain, for even and odd batches."""
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.model_configs import VaeConfig
+    from adv_grpo_amd.vae import AutoencoderKLDecoder
+    cfg = VaeConfig()
+    dec = AutoencoderKLDecoder(synthetic.vae_decoder_weights(cfg, 99), cfg, "cuda", mode="bf16x3")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for B in (2, 3, 8):
+        lat = torch.randn(B, 16, 16, 16, device="cuda", generator=g).to(torch.bfloat16)
+        dec.two_streams = True
+        two = dec.decode_to_image(lat)
+        again = dec.decode_to_image(lat)
+        dec.two_streams = False
+        one = dec.decode_to_image(lat)
+        torch.cuda.synchronize()
+        assert two.shape == one.shape and torch.equal(two, one) and torch.equal(again, one)
+
+
 @pytest.mark.parametrize("B,hw", [(2, 16), (1, 64)])
 def test_vae_decode_bf16x3_mode_vs_fp32_oracle(B, hw):
     """mode="bf16x3": f32 weights (NOT rounded to bf16 -- the mode exists to reproduce the reference's fp32 decode,
