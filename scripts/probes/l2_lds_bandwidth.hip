@@ -15,7 +15,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int DEPTH, int INST>
+template <int DEPTH, int INST, int AUX = 0>
 __global__ __launch_bounds__(512, 2) void pull(const char* __restrict__ buf, size_t set_bytes, int pitch, int stages, float* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(512, 2) void pull(const char* __restrict__ buf, siz
         for (int it = 0; it < INST; ++it) {
             size_t r = (row0 + (size_t)s * (INST * 64) + (wave * INST + it) * 8 + (lane >> 3)) % rows_in_set;
             const char* src = buf + r * pitch + (lane & 7) * 16;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(dst + it * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(dst + it * 1024), 16, 0, AUX);
         }
     };
     for (int s = 0; s < DEPTH - 1; ++s) issue(s);
@@ -80,22 +80,22 @@ static void run_regs(const char* buf, size_t set_bytes, int pitch, float* sink) 
            set_bytes / 1048576.0, pitch, bytes / ms / 1e9, bytes / ms / 1e9 * 1e12 / 256 / 2.4e9);
 }
 
-template <int DEPTH, int INST>
+template <int DEPTH, int INST, int AUX = 0>
 static void run(const char* buf, size_t set_bytes, int pitch, float* sink) {
     const int stages = 4096;
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pull<DEPTH, INST>), hipFuncAttributeMaxDynamicSharedMemorySize, DEPTH * INST * 8192));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pull<DEPTH, INST, AUX>), hipFuncAttributeMaxDynamicSharedMemorySize, DEPTH * INST * 8192));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((pull<DEPTH, INST>), dim3(256), dim3(512), DEPTH * INST * 8192, 0, buf, set_bytes, pitch, 64, sink);
+    hipLaunchKernelGGL((pull<DEPTH, INST, AUX>), dim3(256), dim3(512), DEPTH * INST * 8192, 0, buf, set_bytes, pitch, 64, sink);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((pull<DEPTH, INST>), dim3(256), dim3(512), DEPTH * INST * 8192, 0, buf, set_bytes, pitch, stages, sink);
+    hipLaunchKernelGGL((pull<DEPTH, INST, AUX>), dim3(256), dim3(512), DEPTH * INST * 8192, 0, buf, set_bytes, pitch, stages, sink);
     CHECK(hipEventRecord(e1));
     CHECK(hipDeviceSynchronize());
     float ms;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
     const double bytes = 256.0 * stages * INST * 8192;
-    printf("  set %7.1f MiB  pitch %5d B  %3d KiB in flight per CU (%d stages of %d KiB): %6.2f TB/s  (%.1f B/clk/CU at 2.4 GHz)\n", set_bytes / 1048576.0, pitch,
+    printf("  cpol %2d  set %7.1f MiB  pitch %5d B  %3d KiB in flight per CU (%d stages of %d KiB): %6.2f TB/s  (%.1f B/clk/CU at 2.4 GHz)\n", AUX, set_bytes / 1048576.0, pitch,
            (DEPTH - 1) * INST * 8, DEPTH - 1, INST * 8, bytes / ms / 1e9, bytes / ms / 1e9 * 1e12 / 256 / 2.4e9);
 }
 
@@ -112,5 +112,14 @@ int main() {
             run<8, 2>(buf, mb << 20, pitch, sink);      // 112 KiB in flight
             run_regs(buf, mb << 20, pitch, sink);
         }
+    // cache-policy bits of the DMA instruction (1 = sc0, 2 = nt, 16 = sc1): does any of them move the ceiling?
+    printf("cache policy of the DMA instruction, 16 MiB set, pitch 3072, 96 KiB in flight:\n");
+    run<4, 4, 0>(buf, (size_t)16 << 20, 3072, sink);
+    run<4, 4, 1>(buf, (size_t)16 << 20, 3072, sink);
+    run<4, 4, 2>(buf, (size_t)16 << 20, 3072, sink);
+    run<4, 4, 3>(buf, (size_t)16 << 20, 3072, sink);
+    run<4, 4, 16>(buf, (size_t)16 << 20, 3072, sink);
+    run<4, 4, 17>(buf, (size_t)16 << 20, 3072, sink);
+    run<4, 4, 18>(buf, (size_t)16 << 20, 3072, sink);
     return 0;
 }
