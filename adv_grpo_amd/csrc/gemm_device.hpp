@@ -405,7 +405,8 @@ __device__ __forceinline__ void gemm_epilogue_f32io(const GemmParams& p, f32x4 (
                 const float4 r4 = *reinterpret_cast<const float4*>(res + (int64_t)m * p.ldr + n);
                 v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
             }
-            *reinterpret_cast<float4*>(out + (int64_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            // streaming store: up to 1 GiB of output that the next kernel reads only after it has left every cache
+            __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(out + (int64_t)m * p.ldc + n));
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
