@@ -140,9 +140,32 @@ class SD3Transformer2DModel:
         return ops.cached(self._pos_cache, (B, hh, ww), make)
 
     # ------------------------------------------------------------------ forward
+    def _temb(self, timestep, pooled_projections):
+        """time_text_embed: timestep_embedder(t) + text_embedder(pooled) -> [B, D] bf16."""
+        w, bf16 = self.w, torch.bfloat16
+        t1 = "time_text_embed.timestep_embedder.linear_1"; t2 = "time_text_embed.timestep_embedder.linear_2"
+        p1 = "time_text_embed.text_embedder.linear_1"; p2 = "time_text_embed.text_embedder.linear_2"
+        te = ops.gemm(ops.gemm(ops.timestep_embedding(timestep), w[t1 + ".w"], bias=w[t1 + ".b"], act="silu"),
+                      w[t2 + ".w"], bias=w[t2 + ".b"])
+        return ops.gemm(ops.gemm(pooled_projections.to(bf16).contiguous(), w[p1 + ".w"], bias=w[p1 + ".b"], act="silu"),
+                        w[p2 + ".w"], bias=w[p2 + ".b"], residual=te)
+
+    @torch.no_grad()
+    def precompute_mods(self, timesteps, pooled_projections):
+        """The adaLN modulation rows of a whole rollout in one GEMM.  They depend on (timestep, pooled projections) only, both
+        known before the first denoise step, and the concatenated modulation matrix is 1.5 GB: streamed once per ROLLOUT here
+        instead of once per forward.  timesteps [T], pooled [B, P] -> [T, B, n_mod]; row (i, b) is bit for bit what
+        __call__ computes for timestep i (every row of a GEMM is independent of the others and of the tile shape:
+        tests/test_gpu_mmdit.py).  Pass mods=result[i] to __call__."""
+        T, B = timesteps.shape[0], pooled_projections.shape[0]
+        temb = self._temb(timesteps.reshape(T, 1).expand(T, B).reshape(T * B),
+                          pooled_projections.unsqueeze(0).expand(T, B, -1).reshape(T * B, -1))
+        mods = ops.gemm(ops.unary(temb, "silu"), self.w["mod.w"], bias=self.w["mod.b"])
+        return mods.view(T, B, -1)
+
     @torch.no_grad()
     def __call__(self, hidden_states, timestep, encoder_hidden_states, pooled_projections,
-                 joint_attention_kwargs=None, return_dict=False, out_dtype=None, return_intermediates=False):
+                 joint_attention_kwargs=None, return_dict=False, out_dtype=None, return_intermediates=False, mods=None):
         cfg, w = self.cfg, self.w
         D, H = cfg.dim, cfg.num_heads
         B, C, h, wd = hidden_states.shape
@@ -155,13 +178,11 @@ class SD3Transformer2DModel:
 
         x = ops.gemm(ops.patchify(hidden_states.contiguous()), w["patch.w"], bias=w["patch.b"],
                      residual=self._pos(B, hh, ww))
-        t1 = "time_text_embed.timestep_embedder.linear_1"; t2 = "time_text_embed.timestep_embedder.linear_2"
-        p1 = "time_text_embed.text_embedder.linear_1"; p2 = "time_text_embed.text_embedder.linear_2"
-        te = ops.gemm(ops.gemm(ops.timestep_embedding(timestep), w[t1 + ".w"], bias=w[t1 + ".b"], act="silu"),
-                      w[t2 + ".w"], bias=w[t2 + ".b"])
-        temb = ops.gemm(ops.gemm(pooled_projections.to(bf16).contiguous(), w[p1 + ".w"], bias=w[p1 + ".b"], act="silu"),
-                        w[p2 + ".w"], bias=w[p2 + ".b"], residual=te)
-        mods = ops.gemm(ops.unary(temb, "silu"), w["mod.w"], bias=w["mod.b"])           # [B, n_mod]
+        temb = None
+        if mods is None or return_intermediates:
+            temb = self._temb(timestep, pooled_projections)
+        if mods is None:
+            mods = ops.gemm(ops.unary(temb, "silu"), w["mod.w"], bias=w["mod.b"])       # [B, n_mod]
         c = ops.gemm(encoder_hidden_states.to(bf16).reshape(B * Nt, -1).contiguous(), w["context_embedder.w"],
                      bias=w["context_embedder.b"])
         if return_intermediates:

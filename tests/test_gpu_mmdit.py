@@ -117,3 +117,29 @@ def test_mmdit_sd35_large_full_depth_at_1024():
     assert e_hip < max(2 * e_torch, 2e-2), (e_hip, e_torch)
     for k in ("x1", "x19", "x38"):
         assert _rel(inter[k], rinter[k]) < 6e-2, (k, _rel(inter[k], rinter[k]))
+
+
+def test_precomputed_modulation_rows_are_bit_identical():
+    """precompute_mods: the adaLN rows of all timesteps of a rollout from one GEMM (M = T * B rows, another tile shape than the
+    per-forward M = B launch) must equal the per-forward rows bit for bit, and a forward fed with them must equal the plain
+    forward bit for bit -- the rollout relies on it (log-prob ratio exactly 1 at the first inner epoch).  Real width (D = 1536,
+    the 2048-wide pooled projection), 4 blocks, CFG batch 16, 10 timesteps."""
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.mmdit import SD3Transformer2DModel
+    from oracle.mmdit import MMDiTConfig
+    cfg = MMDiTConfig(num_layers=4, dual_attention_layers=(0, 1))
+    W = {k: v.to(torch.bfloat16) for k, v in synthetic.mmdit_weights(cfg, 5).items()}
+    model = SD3Transformer2DModel(W, cfg, "cuda")
+    g = torch.Generator(device="cuda").manual_seed(6)
+    B, T = 16, 10
+    lat = torch.randn(B, 16, 32, 32, device="cuda", generator=g).to(torch.bfloat16)
+    ctx = torch.randn(B, 77, cfg.joint_attention_dim, device="cuda", generator=g).to(torch.bfloat16)
+    pooled = torch.randn(B, cfg.pooled_projection_dim, device="cuda", generator=g).to(torch.bfloat16)
+    ts = torch.linspace(1000.0, 37.5, T, device="cuda")
+    mods_all = model.precompute_mods(ts, pooled)
+    assert mods_all.shape[:2] == (T, B)
+    for i in (0, 3, T - 1):
+        t = ts[i].expand(B)
+        plain = model(lat, t, ctx, pooled)[0]
+        fed = model(lat, t, ctx, pooled, mods=mods_all[i])[0]
+        assert torch.equal(plain, fed), i
