@@ -77,6 +77,8 @@ def pipeline_with_logprob_random(self, prompt=None, prompt_2=None, prompt_3=None
     # bit for bit the rows the per-forward GEMM gives; rollout step 412.8 -> 409.6 ms on one box)
     pre = getattr(self.transformer, "precompute_mods", None)
     mods_all = pre(timesteps, tem_ppe) if pre is not None else None
+    emb = getattr(self.transformer, "embed_context", None)
+    ctx_rows = emb(tem_pe) if emb is not None else None                        # the context embedder is timestep-free as well
     for i in range(len(timesteps)):
         t = timesteps[i]
         if i == random_timestep:                                               # PF:606-623
@@ -89,7 +91,8 @@ def pipeline_with_logprob_random(self, prompt=None, prompt_2=None, prompt_3=None
         inp = torch.cat([latents] * 2) if do_cfg else latents                  # PF:625
         v = self.transformer(hidden_states=inp, timestep=t.expand(inp.shape[0]), encoder_hidden_states=tem_pe,
                              pooled_projections=tem_ppe, joint_attention_kwargs=joint_attention_kwargs,
-                             return_dict=False, **({} if mods_all is None else {"mods": mods_all[i]}))[0]                             # PF:630-637
+                             return_dict=False, **({} if mods_all is None else {"mods": mods_all[i]}),
+                             **({} if ctx_rows is None else {"context": ctx_rows}))[0]                             # PF:630-637
         vu, vt = (v[:B], v[B:]) if do_cfg else (v, None)
         want_f32 = dtype == torch.float32
         nxt, cast, log_prob, _, _ = sde_step_cfg(                              # PF:640-655 fused

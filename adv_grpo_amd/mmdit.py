@@ -151,6 +151,14 @@ class SD3Transformer2DModel:
                         w[p2 + ".w"], bias=w[p2 + ".b"], residual=te)
 
     @torch.no_grad()
+    def embed_context(self, encoder_hidden_states):
+        """context_embedder over the prompt embeddings [B, Nt, 4096] -> [B * Nt, D]: does not depend on the timestep, so a
+        rollout computes it once and passes context= to every forward."""
+        B, Nt = encoder_hidden_states.shape[:2]
+        return ops.gemm(encoder_hidden_states.to(torch.bfloat16).reshape(B * Nt, -1).contiguous(), self.w["context_embedder.w"],
+                        bias=self.w["context_embedder.b"])
+
+    @torch.no_grad()
     def precompute_mods(self, timesteps, pooled_projections):
         """The adaLN modulation rows of a whole rollout in one GEMM.  They depend on (timestep, pooled projections) only, both
         known before the first denoise step, and the concatenated modulation matrix is 1.5 GB: streamed once per ROLLOUT here
@@ -165,7 +173,7 @@ class SD3Transformer2DModel:
 
     @torch.no_grad()
     def __call__(self, hidden_states, timestep, encoder_hidden_states, pooled_projections,
-                 joint_attention_kwargs=None, return_dict=False, out_dtype=None, return_intermediates=False, mods=None):
+                 joint_attention_kwargs=None, return_dict=False, out_dtype=None, return_intermediates=False, mods=None, context=None):
         cfg, w = self.cfg, self.w
         D, H = cfg.dim, cfg.num_heads
         B, C, h, wd = hidden_states.shape
@@ -183,8 +191,10 @@ class SD3Transformer2DModel:
             temb = self._temb(timestep, pooled_projections)
         if mods is None:
             mods = ops.gemm(ops.unary(temb, "silu"), w["mod.w"], bias=w["mod.b"])       # [B, n_mod]
-        c = ops.gemm(encoder_hidden_states.to(bf16).reshape(B * Nt, -1).contiguous(), w["context_embedder.w"],
-                     bias=w["context_embedder.b"])
+        if context is not None:                          # embed_context(): the same rows for every denoise step of a rollout
+            c = context.clone()                          # (the text stream is updated in place by the blocks)
+        else:
+            c = self.embed_context(encoder_hidden_states)
         if return_intermediates:
             inter.update(x0=x.view(B, Ni, D).clone(), c0=c.view(B, Nt, D).clone(), temb=temb.clone())
 

@@ -143,3 +143,8 @@ def test_precomputed_modulation_rows_are_bit_identical():
         plain = model(lat, t, ctx, pooled)[0]
         fed = model(lat, t, ctx, pooled, mods=mods_all[i])[0]
         assert torch.equal(plain, fed), i
+    rows = model.embed_context(ctx)                     # the timestep-free context embedder, hoisted out of the denoise loop
+    keep = rows.clone()
+    t = ts[1].expand(B)
+    assert torch.equal(model(lat, t, ctx, pooled, mods=mods_all[1], context=rows)[0], model(lat, t, ctx, pooled)[0])
+    assert torch.equal(rows, keep)                      # the forward works on a copy: the rows serve the next step unchanged
