@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256, ATT_WGS) void attention_fwd_glds_kernel(const 
 
 int attention_fwd(const AttnParams& p_in, int B, int head_dim, hipStream_t s) {
     AttnParams p = p_in;
-    ADVGRPO_CHECK(head_dim == 64 || head_dim == 80, "attention: head_dim %d not supported (64, 80)", head_dim);
+    ADVGRPO_CHECK(head_dim == 64 || head_dim == 80 || head_dim == 128, "attention: head_dim %d not supported (64, 80, 128)", head_dim);
     ADVGRPO_CHECK(p.q && p.k && p.v && p.o, "attention: null pointer");
     ADVGRPO_CHECK(p.Sq > 0 && p.Skv > 0 && p.H > 0 && B > 0, "attention: bad shape");
     ADVGRPO_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0,
@@ -512,6 +512,10 @@ int attention_fwd(const AttnParams& p_in, int B, int head_dim, hipStream_t s) {
     p.xcd_local = xcd_local;
     dim3 grid((unsigned)nwg);
     const bool o16 = p.ldo % 8 == 0 && p.bso % 8 == 0 && (reinterpret_cast<uintptr_t>(p.o) & 15) == 0;   // 16-byte row stores
+    if (head_dim == 128) {      // the Qwen-Image MMDiT's joint attention (attention_d128.hip)
+        ADVGRPO_CHECK(o16 && !p.bias && !p.causal, "attention: head dim 128 is implemented without mask / bias and for 16-byte aligned output rows");
+        return attention_fwd_d128_launch(p, B, s);
+    }
     ADVGRPO_CHECK(!p.bias || (use_glds && o16), "attention: the score bias needs the LDS-DMA kernel (16-byte aligned output rows)");
     // plain head-dim-64 attention (MMDiT joint / second attention, DINOv2): the software-pipelined kernel of attention_pipe.hip
     if (head_dim == 64 && use_glds && o16 && !p.bias && !p.causal && use_pipe) return attention_fwd_pipe_launch(p, s);

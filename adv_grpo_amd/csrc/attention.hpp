@@ -44,5 +44,7 @@ __device__ __forceinline__ void att_dma16(const void* src, const char* lds) {
 
 // the software-pipelined head-dim-64 forward (attention_pipe.hip): non-causal, no score bias, 16-byte aligned output rows
 int attention_fwd_pipe_launch(const AttnParams& p, hipStream_t s);
+// head dim 128 (attention_d128.hip): 8-wave workgroups of 256 queries, non-causal, no score bias, 16-byte aligned output rows
+int attention_fwd_d128_launch(const AttnParams& p, int B, hipStream_t s);
 
 }  // namespace advgrpo

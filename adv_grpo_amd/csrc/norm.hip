@@ -204,6 +204,62 @@ __global__ __launch_bounds__(256) void rmsnorm_heads_kernel(bf16_t* __restrict__
     }
 }
 
+
+// Per-head RMSNorm (affine) + rotary embedding, in place, on the q | k column range of a packed joint QKV buffer: the
+// attn.norm_q / norm_k / norm_added_q / norm_added_k + apply_rotary_emb_qwen steps of diffusers' QwenDoubleStreamAttnProcessor2_0
+// (the Qwen-Image MMDiT of BASELINE config 5; head dim 128 -- a head spans two wave tiles of the eight-phase GEMM, so its
+// QK-norm epilogue class, which owns one 64-wide head per wave tile, does not apply).  One wave per token row, HD / 8 lanes per
+// head; the token's rotary row (cos, sin interleaved, f32) is loaded once and serves all of its heads.  Arithmetic in the
+// reference's order: bf16(bf16(x * rsqrt(mean x^2 + eps)) * w), then the complex product with (cos + i sin) on adjacent
+// (even, odd) pairs in f32, one bf16 rounding.
+template <int HD>
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ buf, int64_t ld, int rows, int S, int n_first,
+                                                           int col0, int nheads, const bf16_t* __restrict__ w_first,
+                                                           const bf16_t* __restrict__ w_rest, int heads_per_weight, float eps,
+                                                           const float* __restrict__ rope, float* __restrict__ rs_out) {
+    constexpr int LPH = HD / 8, HPP = 64 / LPH;          // lanes per head, heads per pass
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int s = row % S;
+    const bf16_t* w = s < n_first ? w_first : w_rest;
+    bf16_t* r = buf + (int64_t)row * ld + col0;
+    const int sub = lane % LPH;
+    float cs[8];                                          // (cos, sin) of this lane's four pairs
+    if (rope) {
+        const float4 a = *reinterpret_cast<const float4*>(rope + (int64_t)s * HD + sub * 8);
+        const float4 b = *reinterpret_cast<const float4*>(rope + (int64_t)s * HD + sub * 8 + 4);
+        cs[0] = a.x; cs[1] = a.y; cs[2] = a.z; cs[3] = a.w; cs[4] = b.x; cs[5] = b.y; cs[6] = b.z; cs[7] = b.w;
+    }
+    for (int h0 = 0; h0 < nheads; h0 += HPP) {
+        const int hh = h0 + lane / LPH;
+        if (hh >= nheads) break;
+        float v[8], ww[8];
+        unpack8(*reinterpret_cast<const uint4*>(r + hh * HD + sub * 8), v);
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sq += v[k] * v[k];
+        sq = group8_sum(sq);
+        if (LPH == 16) {                                  // the other half of the 16-lane row (DPP row_mirror)
+            sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x140, 0xf, 0xf, true));
+        }
+        const float rs = rsqrtf(sq * (1.0f / HD) + eps);
+        if (rs_out && sub == 0) rs_out[(int64_t)row * nheads + hh] = rs;
+        unpack8(*reinterpret_cast<const uint4*>(w + (hh / heads_per_weight) * HD + sub * 8), ww);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = round_bf16(round_bf16(v[k] * rs) * ww[k]);
+        if (rope) {
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                const float a = v[k], b = v[k + 1];
+                v[k] = a * cs[k] - b * cs[k + 1];
+                v[k + 1] = a * cs[k + 1] + b * cs[k];
+            }
+        }
+        *reinterpret_cast<uint4*>(r + hh * HD + sub * 8) = pack8(v);
+    }
+}
+
 // sinusoidal timestep embedding, diffusers get_timestep_embedding(t, 256, flip_sin_to_cos=True,
 // downscale_freq_shift=0): [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(1e4) i / 128); optional SiLU-free.
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, int B, int dim) {
@@ -332,6 +388,25 @@ extern "C" int advgrpo_rmsnorm_heads(void* buf, int64_t ld, int M, int col0, int
     ADVGRPO_CHECK(ld % 8 == 0 && col0 % 8 == 0, "rmsnorm_heads: pitch/offset must be multiples of 8");
     hipLaunchKernelGGL(rmsnorm_heads_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), (bf16_t*)buf, ld, M,
                        col0, nheads, (const bf16_t*)weight, heads_per_weight, eps, seg_rows, seg_stride, seg_off, rs_out);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+
+extern "C" int advgrpo_qk_norm_rope(void* buf, int64_t ld, int rows, int S, int n_first, int col0, int nheads, int head_dim,
+                                    const void* w_first, const void* w_rest, int heads_per_weight, float eps,
+                                    const float* rope, float* rs_out, void* stream) {
+    ADVGRPO_CHECK(buf && w_first && w_rest && rows > 0 && S > 0 && nheads > 0 && heads_per_weight > 0, "qk_norm_rope: bad argument");
+    ADVGRPO_CHECK(head_dim == 64 || head_dim == 128, "qk_norm_rope: head_dim %d not supported (64, 128)", head_dim);
+    ADVGRPO_CHECK(ld % 8 == 0 && col0 % 8 == 0, "qk_norm_rope: pitch/offset must be multiples of 8");
+    ADVGRPO_CHECK(!rope || (reinterpret_cast<uintptr_t>(rope) & 15) == 0, "qk_norm_rope: the rotary table must be 16-byte aligned");
+    const dim3 grid((rows + 3) / 4);
+    if (head_dim == 128)
+        hipLaunchKernelGGL(qk_norm_rope_kernel<128>, grid, dim3(256), 0, as_stream(stream), (bf16_t*)buf, ld, rows, S, n_first, col0,
+                           nheads, (const bf16_t*)w_first, (const bf16_t*)w_rest, heads_per_weight, eps, rope, rs_out);
+    else
+        hipLaunchKernelGGL(qk_norm_rope_kernel<64>, grid, dim3(256), 0, as_stream(stream), (bf16_t*)buf, ld, rows, S, n_first, col0,
+                           nheads, (const bf16_t*)w_first, (const bf16_t*)w_rest, heads_per_weight, eps, rope, rs_out);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

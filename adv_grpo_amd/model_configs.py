@@ -58,3 +58,21 @@ class DinoConfig:  # timm vit_base_patch14_dinov2.lvd142m
     mlp: int = 3072
     image_size: int = 518
     patch: int = 14
+
+
+@dataclass
+class QwenMMDiTConfig:  # Qwen/Qwen-Image transformer (diffusers QwenImageTransformer2DModel; BASELINE config 5)
+    num_layers: int = 60
+    num_heads: int = 24
+    head_dim: int = 128
+    in_channels: int = 64           # 2x2-packed latents of the 16-channel VAE
+    out_channels: int = 16
+    patch_size: int = 2
+    joint_attention_dim: int = 3584
+    axes_dims_rope: tuple = (16, 56, 56)
+    rope_theta: float = 10000.0
+    scale_rope: bool = True
+
+    @property
+    def dim(self):
+        return self.num_heads * self.head_dim

@@ -341,6 +341,21 @@ def rmsnorm_heads(buf, col0, nheads, weight, heads_per_weight, eps=1e-6, seg=Non
     return buf
 
 
+def qk_norm_rope(buf, S, n_first, nheads, head_dim, w_first, w_rest, heads_per_weight, rope=None, eps=1e-6, col0=0, rs_out=None):
+    """In place on the joint QKV buffer buf [B * S, ld] bf16: per-head RMSNorm (weights w_first for the first n_first token
+    rows of every sample, w_rest for the others; [nheads / heads_per_weight, head_dim] bf16 each) of the nheads heads at
+    columns [col0, col0 + nheads * head_dim), then the rotary embedding rope [S, head_dim] f32 ((cos, sin) pairs; None: none)."""
+    lib = _lib.load()
+    assert buf.dtype == torch.bfloat16 and buf.dim() == 2 and buf.stride(1) == 1 and buf.shape[0] % S == 0
+    assert w_first.is_contiguous() and w_rest.is_contiguous() and w_first.dtype == torch.bfloat16 and w_rest.dtype == torch.bfloat16
+    assert rope is None or (rope.dtype == torch.float32 and rope.is_contiguous() and tuple(rope.shape) == (S, head_dim))
+    _lib.check(lib.advgrpo_qk_norm_rope(buf.data_ptr(), buf.stride(0), buf.shape[0], int(S), int(n_first), int(col0), int(nheads),
+                                        int(head_dim), w_first.data_ptr(), w_rest.data_ptr(), int(heads_per_weight), float(eps),
+                                        rope.data_ptr() if rope is not None else None,
+                                        rs_out.data_ptr() if rs_out is not None else None, _lib.stream_ptr()))
+    return buf
+
+
 def timestep_embedding(t, dim=256):
     lib = _lib.load()
     t = t.float().contiguous()

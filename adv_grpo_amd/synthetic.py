@@ -100,6 +100,40 @@ def mmdit_weights(cfg, seed=1234):
     return W
 
 
+def qwen_mmdit_weights(cfg, seed=4242, dtype=None):
+    """Weights dict keyed like diffusers QwenImageTransformer2DModel.state_dict() (Qwen/Qwen-Image: 60 blocks of two-stream
+    attention + MLP, 20 B parameters at full size).  dtype: cast every tensor as it is drawn (bf16 at full size: an fp32 copy
+    of the whole model is 82 GB); values are the bf16 rounding of the same fp32 stream either way."""
+    g = _gen(seed)
+    D, W = cfg.dim, {}
+    cast = (lambda t: t) if dtype is None else (lambda t: t.to(dtype))
+
+    def lin(name, out_f, in_f, std=None):
+        tmp = {}
+        linear_(tmp, name, out_f, in_f, g, std=std)
+        for k, v in tmp.items():
+            W[k] = cast(v)
+    lin("img_in", D, cfg.in_channels)
+    lin("txt_in", D, cfg.joint_attention_dim)
+    W["txt_norm.weight"] = cast(1 + 0.1 * _randn(cfg.joint_attention_dim, generator=g))
+    lin("time_text_embed.timestep_embedder.linear_1", D, 256)
+    lin("time_text_embed.timestep_embedder.linear_2", D, D)
+    for i in range(cfg.num_layers):
+        p = f"transformer_blocks.{i}"
+        lin(f"{p}.img_mod.1", 6 * D, D, std=0.5 / math.sqrt(D))
+        lin(f"{p}.txt_mod.1", 6 * D, D, std=0.5 / math.sqrt(D))
+        for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0", "to_add_out"):
+            lin(f"{p}.attn.{n}", D, D)
+        for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+            W[f"{p}.attn.{n}.weight"] = cast(1 + 0.1 * _randn(cfg.head_dim, generator=g))
+        for s in ("img_mlp", "txt_mlp"):
+            lin(f"{p}.{s}.net.0.proj", 4 * D, D)
+            lin(f"{p}.{s}.net.2", D, 4 * D)
+    lin("norm_out.linear", 2 * D, D, std=0.5 / math.sqrt(D))
+    lin("proj_out", cfg.patch_size * cfg.patch_size * cfg.out_channels, D)
+    return W
+
+
 def prompt_embeddings(seed=7, n_tokens=205, ctx_dim=4096, pooled_dim=2048):
     """Synthetic prompt: (prompt_embeds [1,205,4096], pooled [1,2048], negative ..., negative pooled ...)."""
     g = torch.Generator().manual_seed(seed)   # inputs always come from the CPU stream

@@ -166,6 +166,18 @@ int advgrpo_rmsnorm_heads(void* buf, int64_t ld, int M, int col0, int nheads, co
                           int heads_per_weight, float eps, int seg_rows, int64_t seg_stride,
                           int64_t seg_off, float* rs_out /* optional f32 [rows, nheads]: 1/rms, for the backward */,
                           void* stream);
+/* Per-head RMSNorm (affine, eps) + rotary position embedding, in place, on the q | k heads of a packed JOINT QKV buffer
+ * buf[rows = B * S, ld]: heads of head_dim (64 or 128) at columns [col0, col0 + nheads * head_dim).  Token row m is position
+ * s = m % S of its sample; rows with s < n_first (image tokens) use w_first [nheads / heads_per_weight, head_dim], the others
+ * (text tokens) w_rest.  rope [S, head_dim] f32 holds (cos, sin) of pair i of position s at [s, 2i], [s, 2i + 1] (NULL: norm only):
+ *     y = bf16(bf16(x * rsqrt(mean x^2 + eps)) * w);   out[2i] = y[2i] cos - y[2i+1] sin,  out[2i+1] = y[2i] sin + y[2i+1] cos.
+ * Replaces attn.norm_q / norm_k / norm_added_q / norm_added_k + apply_rotary_emb_qwen of diffusers' Qwen-Image attention
+ * processor (BASELINE config 5's model; no code in the reference beyond README.md:75, config/grpo.py:324,330), as reached
+ * through the transformer call of adv_grpo/diffusers_patch/sd3_pipeline_with_logprob_fast.py:630-637.
+ * rs_out (optional, f32 [rows, nheads]): 1/rms per head, for the backward. */
+int advgrpo_qk_norm_rope(void* buf, int64_t ld, int rows, int S, int n_first, int col0, int nheads, int head_dim,
+                         const void* w_first, const void* w_rest, int heads_per_weight, float eps,
+                         const float* rope, float* rs_out, void* stream);
 /* diffusers Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0): t f32 [B] -> bf16 [B, dim]. */
 int advgrpo_timestep_embedding(const float* t, void* out, int B, int dim, void* stream);
 /* y = act(x [+ x2]) on bf16, n % 8 == 0 (act 0 none, 3 SiLU). */
@@ -180,7 +192,7 @@ int advgrpo_unpatchify(const void* tokens, void* out, int out_dtype, int B, int 
  * (sd3_pipeline_with_logprob_fast.py:630-637; adv_grpo/rewards.py:397; pickscore_scorer.py:40-44).
  * q/k/v/o are [B, S, H*head_dim]-shaped VIEWS: element (b, s, h, d) at
  * ptr + b*bs + s*ld + h*head_dim + d, so packed QKV GEMM outputs are consumed in place.
- * head_dim: 64 or 80.  ld{q,k,v} % 8 == 0, ldo % 4 == 0.
+ * head_dim: 64, 80 or 128 (128: the Qwen-Image MMDiT; non-causal, 16-byte aligned output rows).  ld{q,k,v} % 8 == 0, ldo % 4 == 0.
  * lse (optional, f32 [B,H,Sq]): base-2 log-sum-exp of the scaled scores, consumed by the backward. */
 int advgrpo_attention_fwd(const void* q, const void* k, const void* v, void* o,
                           int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
