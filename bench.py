@@ -45,8 +45,9 @@ def parse():
                     help="HIP events around every Nth launch of each GEMM kernel in the timed steps (1 = every launch).  The roofline's "
                          "per-launch average is then a 1-in-N sample; a prime N walks through the 4 / 6 launches of a block.  Events "
                          "around all ~1220 GEMM launches of a step cost 1.7 %% of the step (measured, DESIGN.md 6)")
-    ap.add_argument("--config", default="c2", choices=["c2", "c4"],
-                    help="c2 = the headline (BASELINE config 2); c4 = secondary line, SD3.5-large 1024^2 G=4 (BASELINE config 4 shapes)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"],
+                    help="c2 = the headline (BASELINE config 2); c4 = secondary line, SD3.5-large 1024^2 G=4 (BASELINE config 4 shapes); "
+                         "c5 = secondary line, Qwen-Image MMDiT 1024^2 G=8, DINO reward, fp8 Linears (BASELINE config 5 shapes)")
     ap.add_argument("--no-pricing", action="store_true",
                     help="skip the untimed legs that price the alternative modes (split-bf16 VAE, LoRA side path): profiling runs, "
                          "so that the rocprof summary holds the timed configuration only")
@@ -101,6 +102,27 @@ class PowerSampler:
                 "note": "rocm-smi every 0.5 s during the timed steps (rank 0's GPU); nominal peak assumes 2400 MHz"}
 
 
+C5_TEXT_TOKENS = 128      # synthetic prompt length of the config-5 line (Qwen-Image prompts are variable-length Qwen2.5-VL states)
+
+
+def build_c5(device, vae_mode="bf16x3"):
+    """BASELINE config 5's model set: the Qwen-Image MMDiT (60 blocks, 24 x 128, fp8 Linears), the SD3 VAE decoder standing in
+    for Qwen-Image's own (Wan-style) VAE -- said so in config.workload -- and the DINOv2-B/14 patch scorer + head."""
+    from adv_grpo_amd import synthetic, vit
+    from adv_grpo_amd.model_configs import DinoConfig, QwenMMDiTConfig, VaeConfig
+    from adv_grpo_amd.pipeline import SD3Pipeline
+    from adv_grpo_amd.qwen_mmdit import QwenImageTransformer2DModel
+    from adv_grpo_amd.vae import AutoencoderKLDecoder
+    qcfg, vcfg, dcfg = QwenMMDiTConfig(), VaeConfig(), DinoConfig()
+    with synthetic.on_device(device):
+        tr = QwenImageTransformer2DModel(synthetic.qwen_mmdit_weights(qcfg, 4242, dtype=torch.bfloat16), qcfg, device)
+        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(vcfg, 4321), vcfg, device, mode=vae_mode)
+        dino = vit.DinoV2(synthetic.dino_weights(dcfg, 888), dcfg, device)
+        head = vit.DinoHead(synthetic.dino_head_weights(dcfg.hidden, 512, 999), device)
+    tr.enable_fp8()
+    return SD3Pipeline(tr, vae, device), (dino, head)
+
+
 def build(device, large=False, vae_mode="bf16x3"):
     from adv_grpo_amd import synthetic, vit
     from adv_grpo_amd.mmdit import SD3Transformer2DModel
@@ -125,8 +147,8 @@ def pmc_traffic(kernel, config="c2"):
     WRITE_SIZE in separate runs of this same command, scripts/pmc_traffic.py: (2*FETCH_SIZE + WRITE_SIZE)*1024, the factor 2
     being the gfx950 correction of MI355X_MICROARCH.md); None when no pass of that config is committed."""
     root = os.path.dirname(os.path.abspath(__file__))
-    files = (f"profiles/r3_pmc_traffic_{config}.json",) + (("profiles/r2_pmc_traffic.json", "profiles/r1_pmc_traffic.json")
-                                                          if config == "c2" else ())
+    files = (f"profiles/r4_pmc_traffic_{config}.json", f"profiles/r3_pmc_traffic_{config}.json") + \
+        (("profiles/r2_pmc_traffic.json", "profiles/r1_pmc_traffic.json") if config == "c2" else ())
     for rel in files:
         path = os.path.join(root, rel)
         if not os.path.exists(path):
@@ -313,12 +335,22 @@ def main():
     from adv_grpo_amd.sampler import DistributedKRepeatSampler
     from adv_grpo_amd.trainer import rollout_seed
 
-    c4 = args.config == "c4"
-    pipe, clip = build(device, large=c4, vae_mode=args.vae_mode)
-    G, STEPS, T, RES = (4, 10, 2, 1024) if c4 else (8, 10, 2, 512)
+    c4, c5 = args.config == "c4", args.config == "c5"
+    if c5:
+        pipe, (dino, dino_head) = build_c5(device, vae_mode=args.vae_mode)
+        clip = None
+        from adv_grpo_amd import rewards
+        dino_score = rewards.dino_patch_cotrain_score(device)
+    else:
+        pipe, clip = build(device, large=c4, vae_mode=args.vae_mode)
+    G, STEPS, T, RES = (4, 10, 2, 1024) if c4 else ((8, 10, 2, 1024) if c5 else (8, 10, 2, 512))
     sampler = DistributedKRepeatSampler(range(25432), 1, 1, world, rank, seed=42)   # k = 1: one group per rank
     # synthetic prompts: one embedding set per dataset index is not needed for timing; a fixed set per rank
-    pe, ppe, npe, nppe = (t.to(device=device, dtype=torch.bfloat16) for t in synthetic.prompt_embeddings(7 + rank))
+    if c5:     # Qwen-Image: 3584-wide text states, no pooled vector (a dummy one travels through the rollout's signature)
+        pe, ppe, npe, nppe = (t.to(device=device, dtype=torch.bfloat16)
+                              for t in synthetic.prompt_embeddings(7 + rank, n_tokens=C5_TEXT_TOKENS, ctx_dim=3584, pooled_dim=8))
+    else:
+        pe, ppe, npe, nppe = (t.to(device=device, dtype=torch.bfloat16) for t in synthetic.prompt_embeddings(7 + rank))
     ids = synthetic.clip_input_ids(G, 3 + rank).to(device)
 
     def step(it):
@@ -329,7 +361,9 @@ def main():
             negative_pooled_prompt_embeds=nppe, num_inference_steps=STEPS, guidance_scale=4.5, output_type="pt",
             height=RES, width=RES, noise_level=0.8, mini_num_image_per_prompt=G, train_num_steps=T,
             process_index=rank, sample_num_steps=STEPS, random_timestep=0, seed=rollout_seed(42, it, rank))
-        if c4:      # fp32 scorer (RW:561-574)
+        if c5:      # the co-trained DINOv2 patch scorer (RW:375-434): bicubic 1024 -> 518, ViT-B/14, 64 random patches, head
+            scores, _ = dino_score(dino, dino_head, image.to(torch.bfloat16), None, None)
+        elif c4:    # fp32 scorer (RW:561-574)
             from adv_grpo_amd import vit_x3
             scores = vit_x3.pickscore_scores_f32(clip.get_image_features(images=image.float()), clip.get_text_features(ids),
                                                  clip.logit_scale)
@@ -375,8 +409,9 @@ def main():
         achieved = fl / tsec / 1e12
         traffic, traffic_src = pmc_traffic(dom, args.config)
         stride = max(1, args.event_stride)
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": BF16_DENSE_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+        kpeak = FP8_DENSE_PEAK_TFLOPS if dom.endswith("_fp8") else BF16_DENSE_PEAK_TFLOPS     # the dense MFMA peak of the kernel's operand type
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": kpeak,
+                    "unit": "TFLOP/s", "frac": round(achieved / kpeak, 4), "traffic": traffic,
                     "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
                     "launches": n * stride, "launches_timed": n, "event_stride": stride,
                     "avg_launch_us": round(tsec / n * 1e6, 2),
@@ -386,6 +421,15 @@ def main():
         # algorithmic FLOPs per sampled+scored image: 10*2*2.219 + 2.51 + 0.38 TFLOP at config 2;
         # SD3.5-large 1024^2 (config 4 shapes): 30.02 TFLOP per sample-forward, VAE x4 pixels
         per_image_tflop = (10 * 2 * 30.02 + 4 * 2.51 + 0.38) if c4 else (10 * 2 * 2.219 + 2.51 + 0.38)
+        mixed_peak_s = None
+        if c5:      # Qwen-Image at 1024^2: 4096 packed positions + the text tokens; Linears on the fp8 MFMA, attention / VAE / DINO on bf16
+            from adv_grpo_amd.qwen_mmdit import flops_per_sample_forward
+            qc, n_img = pipe.transformer.cfg, (RES // 16) ** 2
+            f_fwd = flops_per_sample_forward(qc, n_img, C5_TEXT_TOKENS) / 1e12
+            f_attn = 4.0 * qc.dim * (n_img + C5_TEXT_TOKENS) ** 2 * qc.num_layers / 1e12
+            per_image_tflop = 10 * 2 * f_fwd + 4 * 2.51 + 0.30
+            # seconds per image at the peaks of the units the work runs on: what "1.0 of the roofline" would be for this mix
+            mixed_peak_s = (10 * 2 * (f_fwd - f_attn)) / FP8_DENSE_PEAK_TFLOPS + (10 * 2 * f_attn + 4 * 2.51 + 0.30) / BF16_DENSE_PEAK_TFLOPS
         # the decoder on its own (bf16 MFMA / f32 accumulate; the reference decodes in fp32, TP:481 -- DESIGN 3 deviation 1)
         # and the fp32-equivalent split-bf16 mode (3 bf16 MFMA products per f32 product, f32 between the kernels) beside it
         from adv_grpo_amd import synthetic
@@ -412,7 +456,7 @@ def main():
         # the rollout with PEFT's LoRA arithmetic (side path as a K-extension of the adapted Linears, mmdit_train.py) instead
         # of LoRA merged into the bf16 weights: same step, other transformer object
         lora_ms = {"merged": round(step_ms, 2)}
-        if not c4 and world == 1 and not args.no_pricing:
+        if not c4 and not c5 and world == 1 and not args.no_pricing:
             from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
             merged_tr = pipe.transformer
             with synthetic.on_device(device):
@@ -429,7 +473,19 @@ def main():
         # the same step with the block Linears of the MMDiT on fp8 e4m3 operands (BASELINE config 5's "fp8 MFMA path";
         # quantize.hip + gemm8p_fp8.hip).  Priced, not the headline: the reference has no fp8 arithmetic to match.
         fp8 = None
-        if world == 1 and not args.no_pricing:
+        bf16_linears = None
+        if c5 and world == 1 and not args.no_pricing:     # config 5 is timed WITH the fp8 Linears it names; the bf16 Linears priced beside it
+            keep8, pipe.transformer.fp8 = pipe.transformer.fp8, None
+            step(0)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            step(1)
+            torch.cuda.synchronize()
+            b_ms = (time.perf_counter() - tb) * 1e3
+            pipe.transformer.fp8 = keep8
+            bf16_linears = {"ms_per_step": round(b_ms, 2), "value": round(G / (b_ms * 1e-3), 3), "fp8_speedup_over_bf16_step": round(b_ms / step_ms, 3),
+                            "note": "the same step with the block Linears on bf16 operands (the eight-phase bf16 kernel): what the fp8 MFMA path buys"}
+        if not c5 and world == 1 and not args.no_pricing:
             pipe.transformer.enable_fp8()
             step(0)
             torch.cuda.synchronize()
@@ -456,7 +512,7 @@ def main():
         # launch's HIP-event duration includes the other stream's kernels, so the per-kernel roofline is only defined for
         # the serial schedule above.
         overlap = None
-        if not c4 and world == 1 and not args.no_pricing:
+        if not c4 and not c5 and world == 1 and not args.no_pricing:
             streams = [torch.cuda.Stream(), torch.cuda.Stream()]
             from concurrent.futures import ThreadPoolExecutor
             pool = ThreadPoolExecutor(2)
@@ -485,19 +541,29 @@ def main():
                        "note": "two independent prompt groups on two HIP streams, one host thread each; same kernels, same results"}
         res = {
             "metric": "sampled+scored images/sec (whole node), SD3.5-large 1024^2 10-step G=4 (secondary line, BASELINE config 4 shapes)"
-            if c4 else "sampled+scored images/sec (whole node), SD3-med 512^2 10-step G=8 GRPO",
+            if c4 else ("sampled+scored images/sec (whole node), Qwen-Image MMDiT 1024^2 10-step G=8, DINO reward, fp8 Linears (secondary line, "
+                        "BASELINE config 5 shapes)" if c5 else "sampled+scored images/sec (whole node), SD3-med 512^2 10-step G=8 GRPO"),
             "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("BASELINE config 4 shapes: SD3.5-large (38 blocks, D=2432) LoRA-merged 1024x1024, 10 steps, CFG 4.5, "
+            "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if c5 else "bf16", "data": "synthetic",
+            "config": {"workload": ("BASELINE config 5 shapes: Qwen-Image MMDiT (60 blocks, 24 heads x 128, D=3072; block Linears on fp8 e4m3 operands, "
+                                    "per-token x per-channel scales, f32 accumulation; attention / norms / embedders bf16) 1024x1024 = 4096 packed "
+                                    f"latent positions + {C5_TEXT_TOKENS} synthetic text tokens (3584-wide), 10 steps, CFG 4.5 as u + s (t - u) "
+                                    "(the rollout function's combine, PF:640-642, not QwenImagePipeline's norm-rescaled one), G=8, SDE window 2 @ noise 0.8 on "
+                                    "the SD3 sigma table (shift 3), VAE decode (" + pipe.vae.mode + ") with the SD3 16-channel decoder standing in for "
+                                    "Qwen-Image's own VAE (not built), DINOv2-B/14 patch reward + head (RW:375-434), reward all-gather + group advantage")
+                                   if c5 else (("BASELINE config 4 shapes: SD3.5-large (38 blocks, D=2432) LoRA-merged 1024x1024, 10 steps, CFG 4.5, "
                                     "G=4, SDE window 2 @ noise 0.8, VAE decode (" + pipe.vae.mode + "), fp32-equivalent PickScore reward (the OCR half of the reward is a "
                                     "host plugin outside the timed path), reward all-gather + group advantage") if c4 else
                                    ("BASELINE config 2: SD3.5-medium LoRA-merged 512x512, 10 steps, CFG 4.5, G=8, "
                                     "SDE window 2 @ noise 0.8, VAE decode (" + pipe.vae.mode + "), PickScore (CLIP ViT-H/14) reward, "
-                                    "reward all-gather + group advantage"), "global_batch": world * G,
+                                    "reward all-gather + group advantage")), "global_batch": world * G,
                        "transformer_batch_per_gpu": 2 * G, "parallelism": f"dp{world} (prompt groups sharded)"},
             "effective_tflops_per_gpu": round(per_image_tflop * images / dt / world, 1),
             "frac_of_bf16_mfma_peak": round(per_image_tflop * images / dt / world / BF16_DENSE_PEAK_TFLOPS, 4),
+            **({"frac_of_mixed_mfma_peak": round(mixed_peak_s * images / dt / world, 4),
+                "mixed_peak_is": "Linear FLOPs priced at the dense fp8 peak (5 PFLOP/s), attention / VAE / DINO FLOPs at the dense bf16 peak (2.5 PFLOP/s): "
+                                 "time at those peaks / measured time"} if c5 else {}),
             "roofline": roofline,
             "vae": {"mode": pipe.vae.mode,
                     "modes": {"bf16": "bf16 operands and activations, f32 accumulate",
@@ -513,7 +579,8 @@ def main():
             "clock_and_power": power.summary(),
             "overlap": overlap,
             "fp8_linears": fp8,
-            "lora": {"mode": "merged",
+            **({"bf16_linears": bf16_linears} if c5 else {}),
+            "lora": None if c5 else {"mode": "merged",
                      "modes": {"merged": "W_eff = bf16(W + s B A) in the rollout and training forward (the timed configuration)",
                                "side": "PEFT's y = W x + s B (A x) as K + 192 / K + 64 extra columns of the adapted Linears: the "
                                        "product's log-prob change after the first AdamW step is within 0.2 % of the exact one "
@@ -521,7 +588,7 @@ def main():
                      "ms_per_step": lora_ms,
                      "value_if_side": round(world * G / (lora_ms["side"] * 1e-3), 3) if "side" in lora_ms else None},
         }
-    run_epoch = not c4 and not args.no_epoch       # at every N: for N > 1 this is the leg with the LoRA-gradient all-reduce (TP:1165)
+    run_epoch = not c4 and not c5 and not args.no_epoch       # at every N: for N > 1 this is the leg with the LoRA-gradient all-reduce (TP:1165)
     if run_epoch:                                   # every rank takes part (LoRA-gradient all-reduce, reward gather)
         del pipe, clip
         torch.cuda.empty_cache()
@@ -529,7 +596,7 @@ def main():
         if rank == 0:
             res["epoch"] = ep
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and not c4:
+        if world == 1 and not args.no_cpu_baseline and not c4 and not c5:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
     if dist is not None:
