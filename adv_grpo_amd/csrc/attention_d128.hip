@@ -9,24 +9,41 @@
 // built around the matrix pipe, the way MI355X_MICROARCH.md "Two waves per SIMD" describes:
 //   * workgroup = 8 waves = 256 queries of one (batch, head), ONE workgroup per CU: a 64-key K or V tile is 16 KiB and is
 //     shared by eight waves (0.004 L2->LDS bytes per flop, half of what 4-wave workgroups would move);
-//   * a tile is two PHASES per wave, one barrier each:
-//       P1(j)  softmax of tile j on the VALU, in the shadow of the 16 P V MFMAs of tile j - 1
-//       P2(j)  the 16 K Q^T MFMAs of tile j + 1 (nothing else)
-//     and the two wave groups (waves w and w + 4 share a SIMD) run ONE PHASE APART: while a wave is in its VALU-heavy
-//     P1 its SIMD partner is in the MFMA-only P2, so each SIMD's matrix pipe always has 32 MFMAs to issue per phase slot
-//     and the softmax never stands alone.  One score buffer (P2(j) overwrites what P1(j) consumed), two probability
-//     buffers by name (the loop body is unrolled twice);
+//   * a tile is 32 MFMA slots per wave and ONE barrier:
+//       slots  0..15  the P V products of tile j - 1, with the softmax of tile j on the VALU in their shadow
+//       slots 16..31  the K Q^T products of tile j + 1, with the four LDS-DMA requests of the wave in their shadow
+//     one score buffer (the second half overwrites what the first consumed), two probability buffers by name.  (Built and
+//     measured as well, D128_VAR bit 1: the two wave groups -- waves w and w + 4 share a SIMD -- ONE HALF APART, a barrier per
+//     half, so that a wave in its VALU-heavy half sits beside a partner in the MFMA-only one: 2 % slower than lock-step,
+//     3.31 vs 3.25 ms at B = 16, 24 heads, S = 4224; as were s_setprio around the MFMA-only half, static priority for the second
+//     group, operand reads 3 or 4 slots ahead and an unpinned first half: all within 1 % -- DESIGN.md section 6, round 4.)
+//   * everything that addresses LDS is a compile-time constant: the tile loop is unrolled over the ring period (4), so a
+//     fragment read is "per-lane base + immediate" and the DMA destinations are literals (the first version computed the
+//     ring slot at run time: 150 VALU + 61 SALU instructions per 32 MFMAs, 47 spilled SGPRs; the instruction stream of the
+//     two waves of a SIMD, not the matrix pipe, set the pace);
+//   * the LDS operand of slot s + 2 is read in slot s, across the half boundary (the K tile landed before the tile began);
 //   * K and V tiles arrive by hand-written LDS-DMA (SGPR base + 32-bit lane offset) into two 4-slot rings; the bundle
-//     {K(t+1), V(t)} is requested two tiles ahead and waited for (counted vmcnt, then the phase barrier) one phase before
-//     its first reader -- with the groups a phase apart that is the latest point that covers both;
+//     {K(t+1), V(t)} is requested in the second half of tile t - 2 and waited for (counted vmcnt, then the barrier) at
+//     the end of tile t - 1;
 //   * layouts as in attention_pipe.hip: S^T = K Q^T so a lane holds 32 scores of ONE query; P stays in registers as the
 //     B operand of P V; V^T through ds_read_b64_tr_b16; softmax scale in f32; probabilities relative to the row maximum
 //     of the first tile, never rescaled, with the same overflow-detecting fallback (running maximum per tile);
 //   * LDS images (256-byte rows): K chunk c of row r at slot c ^ (r & 15) -- the 16 rows of a ds_read_b128 service
 //     group cover all sixteen 16-byte slots; V 64-byte quarter q of row r at q ^ (r & 3) -- the 4 key rows of a
-//     transposed read land on the four quarters of the bank row.
+//     transposed read land on the four quarters of the bank row (PMC: 0.8 % bank-conflict cycles).
 #include "attention.hpp"
 #include "gemm_device.hpp"
+
+// timing experiments (scripts/ablate_d128.sh builds one library per value; the product build has 0): 1 = wave groups one half
+// apart (a barrier per half), 2 = s_setprio 1 around the K Q^T half, 4 = static priority for the second wave group,
+// 8 = first half left to the compiler's scheduler (no slot pins), 128 = DMA requests in a clump at the top of the tile;
+// results WRONG with: 16 = no DMA, 32 = no LDS fragment reads
+#ifndef D128_VAR
+#define D128_VAR 0
+#endif
+#ifndef D128_AHEAD
+#define D128_AHEAD 2          // the LDS operand of MFMA slot s + D128_AHEAD is read in slot s
+#endif
 
 namespace advgrpo {
 
@@ -38,7 +55,9 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 constexpr int D128_QB = 256;                  // queries per workgroup
 constexpr int D128_TILE = ATT_KB * 256;       // 16 KiB per K or V tile
 constexpr int D128_SLOTS = 4;
+constexpr int D128_VRING = D128_SLOTS * D128_TILE;          // byte offset of the V ring
 constexpr int D128_LDS = 2 * D128_SLOTS * D128_TILE + 64;   // 128 KiB + the fallback flags
+constexpr bool D128_STAGGER = (D128_VAR & 1) != 0;
 
 __device__ __forceinline__ float d128_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 // (through the compiler, not inline asm: see attention_pipe.hip -- the hazard recogniser only pads instructions it knows)
@@ -48,9 +67,17 @@ __device__ __forceinline__ uint32_t d128_cvt_pk(float lo, float hi) {
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+#if (D128_VAR & 8)
+#define D128_SB()
+#define D128_PIN(x)
+#else
 #define D128_SB() __builtin_amdgcn_sched_barrier(0)
 #define D128_PIN(x) asm volatile("" : "+v"(x))
+#endif
 #define D128_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+template <int N>
+using d128_int = std::integral_constant<int, N>;
 
 }  // namespace
 
@@ -60,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d128_kernel(const AttnPa
     int* const wg_flag = reinterpret_cast<int*>(smem + 2 * D128_SLOTS * D128_TILE);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;                                         // wave group: group 1 runs one phase behind
+    const int grp = wave >> 2;                                         // wave group (experiment D128_VAR & 1: group 1 runs one half behind)
     const int ql = lane & 31, hi = lane >> 5;
     int qblk, h, b;
     xcd_local_bh(p.nqb, p.H, p.nwg, p.xcd_local, qblk, h, b);
@@ -68,6 +95,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d128_kernel(const AttnPa
     const bf16_t* qp = p.q + (int64_t)b * p.bsq + h * HD;
     const bf16_t* kp = p.k + (int64_t)b * p.bsk + h * HD;
     const bf16_t* vp = p.v + (int64_t)b * p.bsv + h * HD;
+    const int nt = (p.Skv + ATT_KB - 1) / ATT_KB;
 
     // ---- Q fragments (B operand of K Q^T: lane = query, 8 consecutive d at ks*16 + hi*8)
     bf16x8_t qf[8];
@@ -79,65 +107,57 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d128_kernel(const AttnPa
             qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + (int64_t)qr * p.ldq + ks * 16 + hi * 8);
     }
 
-    // ---- DMA sources.  Instruction jj (0..15) of a tile fills LDS rows 4 jj .. 4 jj + 3 (1 KiB); this wave issues jj = wave, wave + 8.
+    // ---- DMA sources.  Instruction jj (0..15) of a tile fills LDS rows 4 jj .. 4 jj + 3 (1 KiB); this wave issues jj = wave and
+    // wave + 8.  Per-lane byte offsets inside a tile: interior tiles, and the (possibly ragged) LAST tile, whose rows past the
+    // end of the sequence are clamped to its last row (their scores are masked) -- the only ragged tile there is, so its
+    // offsets are known up front and a request picks between the two sets with a wave-uniform select.
     const int lrow = lane >> 4, slot16 = lane & 15;
-    uint32_t k_lo[2], v_lo[2];
+    uint32_t k_lo[2], v_lo[2], k_last[2], v_last[2];
+    {
+        const int rmax = p.Skv - 1 - (nt - 1) * ATT_KB;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int R = (wave + 8 * i) * 4 + lrow;
-        k_lo[i] = (uint32_t)R * (uint32_t)(p.ldk * 2) + (uint32_t)((slot16 ^ (R & 15)) * 16);
-        v_lo[i] = (uint32_t)R * (uint32_t)(p.ldv * 2) + (uint32_t)((((((slot16 >> 2) ^ (R & 3))) << 2) | (slot16 & 3)) * 16);
+        for (int i = 0; i < 2; ++i) {
+            const int R = (wave + 8 * i) * 4 + lrow;
+            const int r = min(R, rmax);
+            const uint32_t kc = (uint32_t)((slot16 ^ (R & 15)) * 16);
+            const uint32_t vc = (uint32_t)((((((slot16 >> 2) ^ (R & 3))) << 2) | (slot16 & 3)) * 16);
+            k_lo[i] = (uint32_t)R * (uint32_t)(p.ldk * 2) + kc;
+            v_lo[i] = (uint32_t)R * (uint32_t)(p.ldv * 2) + vc;
+            k_last[i] = (uint32_t)r * (uint32_t)(p.ldk * 2) + kc;
+            v_last[i] = (uint32_t)r * (uint32_t)(p.ldv * 2) + vc;
+        }
     }
     const int64_t k_step = (int64_t)ATT_KB * p.ldk * 2, v_step = (int64_t)ATT_KB * p.ldv * 2;
-    const uint32_t k_lds = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)(smem)) + wave * 1024;
-    const uint32_t v_lds = k_lds + D128_SLOTS * D128_TILE;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)(smem)) + wave * 1024;
     auto dma = [&](const char* base, uint32_t off, uint32_t lds) __attribute__((always_inline)) {
+        if constexpr ((D128_VAR & 16) != 0) return;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
     };
-    // a ragged last tile clamps the rows past the end of the sequence to its last row (their scores are masked)
-    auto stage_k = [&](int t, int slot) __attribute__((always_inline)) {
+    // piece i (0, 1) of K tile t into ring slot `slot` / of V tile t into its own slot; slot: compile-time
+    auto dma_k = [&](int t, auto slot_tag, auto i_tag) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slot_tag)::value & (D128_SLOTS - 1), i = decltype(i_tag)::value;
         const char* base = reinterpret_cast<const char*>(kp) + (int64_t)t * k_step;
-        const uint32_t lds = k_lds + (slot & (D128_SLOTS - 1)) * D128_TILE;
-        if ((t + 1) * ATT_KB > p.Skv) {
-            asm volatile("; ragged K tile" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int R = (wave + 8 * i) * 4 + lrow;
-                const int r = min(R, p.Skv - 1 - t * ATT_KB);
-                dma(base, (uint32_t)r * (uint32_t)(p.ldk * 2) + (uint32_t)((slot16 ^ (R & 15)) * 16), lds + i * 8192);
-            }
-        } else {
-            dma(base, k_lo[0], lds);
-            dma(base, k_lo[1], lds + 8192);
-        }
+        dma(base, t == nt - 1 ? k_last[i] : k_lo[i], lds0 + slot * D128_TILE + i * 8192);
     };
-    auto stage_v = [&](int t) __attribute__((always_inline)) {
+    auto dma_v = [&](int t, auto slot_tag, auto i_tag) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slot_tag)::value & (D128_SLOTS - 1), i = decltype(i_tag)::value;
         const char* base = reinterpret_cast<const char*>(vp) + (int64_t)t * v_step;
-        const uint32_t lds = v_lds + (t & (D128_SLOTS - 1)) * D128_TILE;
-        if ((t + 1) * ATT_KB > p.Skv) {
-            asm volatile("; ragged V tile" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int R = (wave + 8 * i) * 4 + lrow;
-                const int r = min(R, p.Skv - 1 - t * ATT_KB);
-                dma(base, (uint32_t)r * (uint32_t)(p.ldv * 2) + (uint32_t)((((((slot16 >> 2) ^ (R & 3))) << 2) | (slot16 & 3)) * 16),
-                    lds + i * 8192);
-            }
-        } else {
-            dma(base, v_lo[0], lds);
-            dma(base, v_lo[1], lds + 8192);
-        }
+        dma(base, t == nt - 1 ? v_last[i] : v_lo[i], lds0 + D128_VRING + slot * D128_TILE + i * 8192);
     };
-    const int nt = (p.Skv + ATT_KB - 1) / ATT_KB;
-    // bundle t = {K(t+1), V(t)}: always 4 DMA instructions per wave, so the counted waits are constants: the bundle of the last
-    // tile requests that tile's K rows once more, into the slot K(nt) would have used (dead: K(nt-4) was last read five phases
-    // ago) -- never read
-    auto stage_bundle = [&](int t) __attribute__((always_inline)) {
-        stage_k(min(t + 1, nt - 1), t + 1);
-        stage_v(t);
+    // bundle t = {K(t+1), V(t)}, t = T4 (mod 4): always 4 DMA instructions per wave, so the counted waits are constants -- the
+    // bundle of the last tile requests that tile's K rows once more, into the slot K(nt) would have used (dead), never read.
+    // piece = 0..3: K piece 0, K piece 1, V piece 0, V piece 1
+    auto bundle_piece = [&](int t, auto t4_tag, auto piece_tag) __attribute__((always_inline)) {
+        constexpr int T4 = decltype(t4_tag)::value & 3, piece = decltype(piece_tag)::value;
+        if constexpr (piece < 2) dma_k(min(t + 1, nt - 1), d128_int<T4 + 1>{}, d128_int<piece>{});
+        else dma_v(t, d128_int<T4>{}, d128_int<piece - 2>{});
+    };
+    auto bundle = [&](int t, auto t4_tag) __attribute__((always_inline)) {
+        bundle_piece(t, t4_tag, d128_int<0>{}); bundle_piece(t, t4_tag, d128_int<1>{});
+        bundle_piece(t, t4_tag, d128_int<2>{}); bundle_piece(t, t4_tag, d128_int<3>{});
     };
 
-    // ---- fragment read offsets (bytes inside a tile)
+    // ---- fragment read bases (bytes inside a tile; the ring slot and the block inside the tile are immediates)
     //   K: key row kb*32 + ql, 16-byte chunk 2 ks + hi at slot ^ (row & 15)
     //   V^T: 16-lane group g16 reads the 4 (keys 4 hi ..) x 16 (d) block of d half g16 & 1; lane l16 supplies key row l16 >> 2,
     //        4 consecutive d at (l16 & 3) * 4; the 64-byte quarter db of a row sits at db ^ (row & 3)
@@ -147,16 +167,17 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d128_kernel(const AttnPa
     const int vrow = 4 * hi + ((lane & 15) >> 2);
     int v_off[4];
 #pragma unroll
-    for (int db = 0; db < 4; ++db) v_off[db] = vrow * 256 + ((db ^ (vrow & 3)) << 6) + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+    for (int db = 0; db < 4; ++db)      // (the V ring's base is part of the per-lane offset: the immediates then stay below the 64 KiB of a DS offset field)
+        v_off[db] = D128_VRING + vrow * 256 + ((db ^ (vrow & 3)) << 6) + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
 
     typedef __attribute__((ext_vector_type(8))) short s16x8;
-    const char* const Kr = smem;
-    const char* const Vr = smem + D128_SLOTS * D128_TILE;
-    auto kfrag = [&](const char* tile, int kb, int ks) __attribute__((always_inline)) {
-        return *reinterpret_cast<const bf16x8_t*>(tile + kb * 8192 + k_off[ks]);
+    auto kfrag = [&](int imm, int ks) __attribute__((always_inline)) {          // imm = slot * TILE + kb * 8192
+        if constexpr ((D128_VAR & 32) != 0) return qf[ks];
+        return *reinterpret_cast<const bf16x8_t*>(smem + k_off[ks] + imm);
     };
-    auto vfrag = [&](const char* tile, int kk, int db) __attribute__((always_inline)) {
-        const char* a0 = tile + kk * 4096 + v_off[db];
+    auto vfrag = [&](int imm, int db) __attribute__((always_inline)) {          // imm = slot * TILE + kk * 4096
+        if constexpr ((D128_VAR & 32) != 0) return qf[db];
+        const char* a0 = smem + v_off[db] + imm;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
         const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 2048));
         const s16x8 both = __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -177,21 +198,19 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d128_kernel(const AttnPa
     for (int ks = 0; ks < 8; ++ks) asm volatile("" ::"v"(qf[ks]));
 
     // ---- prologue: K(0) | bundle 0 = {K(1), V(0)} | bundle 1 = {K(2), V(1)} ; S(0) = K(0) Q^T ; reference maximum
-    stage_k(0, 0);
-    stage_bundle(0);
-    if (nt > 1) stage_bundle(1);
+    dma_k(0, d128_int<0>{}, d128_int<0>{});
+    dma_k(0, d128_int<0>{}, d128_int<1>{});
+    bundle(0, d128_int<0>{});
+    if (nt > 1) bundle(1, d128_int<1>{});
     if (nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     f32x16 s[2];
     u32x4 pA[4], pB[4];
-    auto qk_tile = [&](const char* tile) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
+    for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) s[kb] = D128_MFMA(kfrag(tile, kb, ks), qf[ks], ks == 0 ? zero16 : s[kb]);
-    };
-    qk_tile(Kr);
+        for (int kb = 0; kb < 2; ++kb) s[kb] = D128_MFMA(kfrag(kb * 8192, ks), qf[ks], ks == 0 ? zero16 : s[kb]);
     auto row_max = [&](const f32x16 (&sc)[2]) __attribute__((always_inline)) {
         float m0 = d128_max3(sc[0][0], sc[0][1], sc[0][2]);
         float m1 = d128_max3(sc[0][3], sc[0][4], sc[0][5]);
@@ -226,11 +245,12 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d128_kernel(const AttnPa
     if (nt == 1) mask_tail(s, 0);
     m_ref = row_max(s) * p.scale_log2e;       // (tile 0 always holds a real key: finite)
     nm2 = f32x2{-m_ref, -m_ref};
-    // the bundle that P1(1) / P2(0) read must have landed before the barrier that closes "P2(-1)"
+    // bundle 0 (read from the next half on) must have landed before the barrier that closes this "second half of tile -1"
     if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();      // stagger: group 1 runs one phase behind
+    if (D128_STAGGER && grp == 1) __builtin_amdgcn_s_barrier();      // stagger: group 1 runs one half behind
+    if ((D128_VAR & 4) != 0 && grp == 1) __builtin_amdgcn_s_setprio(1);
 
     auto pair_x = [&](int i) __attribute__((always_inline)) {
         const f32x2 s2 = {s[i >> 3][(2 * i) & 15], s[i >> 3][((2 * i) & 15) + 1]};
@@ -242,26 +262,53 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d128_kernel(const AttnPa
         e[1] = __builtin_amdgcn_exp2f(x[1]);
         return e;
     };
-    // One tile j.  P1: probabilities of tile j (scores s -> pn) beside the P V products of tile j - 1 (probabilities pp,
-    // V(j-1)); P2: the scores of tile j + 1.  Slot sl of P1: MFMA (key step sl >> 2, d block sl & 3); score pair i: multiply-add
-    // in slot i, exponentials in slot i + 1, bf16 pack + row sum in slot i + 2; the LDS operand of slot sl + 2 is read in slot sl.
-    auto tile = [&](auto first_tag, int j, const u32x4 (&pp)[4], u32x4 (&pn)[4]) __attribute__((always_inline)) {
+    // One tile j = J4 (mod 4).  Slots 0..15: P V of tile j - 1 (probabilities pp, V ring slot J4 - 1: key step sl >> 2, d block
+    // sl & 3) beside the softmax of tile j (scores s -> pn; pair i: multiply-add in slot i, exponentials in slot i + 1, bf16 pack
+    // + row sum in slot i + 2).  Slots 16..31: K Q^T of tile j + 1 (K ring slot J4 + 1: key block sl & 1, d step (sl - 16) >> 1)
+    // beside the four DMA requests of bundle j + 2 (after slots 18, 22, 26, 30).  The LDS operand of slot sl + 2 is read in slot sl.
+    auto tile = [&](auto j4_tag, auto first_tag, int j, const u32x4 (&pp)[4], u32x4 (&pn)[4]) __attribute__((always_inline)) {
+        constexpr int J4 = decltype(j4_tag)::value & 3;
         constexpr bool HAVE_PV = !decltype(first_tag)::value;
-        if (j + 2 < nt) stage_bundle(j + 2);
+        constexpr int VRD = ((J4 + 3) & 3) * D128_TILE, KRD = ((J4 + 1) & 3) * D128_TILE;
+        const bool more_dma = j + 2 < nt;       // (the last tile still multiplies a K tile: bundle nt - 1's copy of K(nt - 1), result unused)
+        if ((D128_VAR & 128) != 0 && more_dma) bundle(j + 2, d128_int<J4 + 2>{});
         if (j == nt - 1) mask_tail(s, j * ATT_KB);
-        const char* vt = Vr + ((j - 1) & (D128_SLOTS - 1)) * D128_TILE;
-        bf16x8_t a[3];
-        if constexpr (HAVE_PV) {
-            a[0] = vfrag(vt, 0, 0);
-            a[1] = vfrag(vt, 0, 1);
-        }
+        auto operand = [&](auto s_tag) __attribute__((always_inline)) {
+            constexpr int sl = decltype(s_tag)::value;
+            if constexpr (sl < 16) return vfrag(VRD + (sl >> 2) * 4096, sl & 3);
+            else return kfrag(KRD + (sl & 1) * 8192, (sl - 16) >> 1);
+        };
+        auto has_operand = [](int sl) constexpr { return (sl >= 16 && sl < 32) || (HAVE_PV && sl >= 0 && sl < 16); };
+        constexpr int AH = D128_AHEAD, NA = D128_AHEAD + 1;
+        bf16x8_t a[NA];
+        static_for<AH>([&](auto i_tag) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_tag)::value;
+            if constexpr (has_operand(i)) a[i] = operand(d128_int<i>{});
+        });
         f32x2 x[2], e[2];
         auto slot = [&](auto s_tag) __attribute__((always_inline)) {
             constexpr int sl = decltype(s_tag)::value;
+            if constexpr (sl == 16) {                                   // ---- end of the first half
+                D128_SB();
+                if constexpr (D128_STAGGER) {
+                    __builtin_amdgcn_s_barrier();
+                    // (staggered groups: the other group confirms the arrival of ITS pieces of this K tile only at this barrier,
+                    // so the first two operands cannot be read ahead of it)
+                    static_for<AH>([&](auto i_tag) __attribute__((always_inline)) {
+                        constexpr int i = 16 + decltype(i_tag)::value;
+                        a[i % NA] = operand(d128_int<i>{});
+                    });
+                }
+                if constexpr ((D128_VAR & 2) != 0) __builtin_amdgcn_s_setprio(1);
+            }
             D128_SB();
-            if constexpr (HAVE_PV && sl < 16) {
-                o[sl & 3] = D128_MFMA(a[sl % 3], __builtin_bit_cast(bf16x8_t, pp[sl >> 2]), o[sl & 3]);
-                if constexpr (sl + 2 < 16) a[(sl + 2) % 3] = vfrag(vt, (sl + 2) >> 2, (sl + 2) & 3);
+            if constexpr (sl < 16) {
+                if constexpr (HAVE_PV) o[sl & 3] = D128_MFMA(a[sl % NA], __builtin_bit_cast(bf16x8_t, pp[sl >> 2]), o[sl & 3]);
+            } else if constexpr (sl < 32) {
+                s[sl & 1] = D128_MFMA(a[sl % NA], qf[(sl - 16) >> 1], sl < 18 ? zero16 : s[sl & 1]);
+            }
+            if constexpr (has_operand(sl + AH) && !(D128_STAGGER && sl < 16 && sl + AH >= 16)) {
+                a[(sl + AH) % NA] = operand(d128_int<(sl + AH) % 32>{});
             }
             if constexpr (sl >= 2 && sl - 2 < 16) {
                 pn[(sl - 2) >> 2][(sl - 2) & 3] = d128_cvt_pk(e[sl & 1][0], e[sl & 1][1]);
@@ -271,41 +318,49 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d128_kernel(const AttnPa
             }
             if constexpr (sl >= 1 && sl - 1 < 16) { e[(sl - 1) & 1] = pair_exp(x[(sl - 1) & 1]); D128_PIN(e[(sl - 1) & 1]); }
             if constexpr (sl < 16) { x[sl & 1] = pair_x(sl); D128_PIN(x[sl & 1]); }
+            if constexpr ((D128_VAR & 128) == 0 && sl >= 18 && sl < 32 && ((sl - 18) & 3) == 0) {
+                if (more_dma) bundle_piece(j + 2, d128_int<J4 + 2>{}, d128_int<(sl - 18) / 4>{});
+            }
         };
-        static_for<18>(slot);
-        D128_SB();
-        __builtin_amdgcn_s_barrier();                                  // ---- end of P1(j)
-        if (j + 1 < nt) qk_tile(Kr + ((j + 1) & (D128_SLOTS - 1)) * D128_TILE);
-        // bundle j + 1 (read from the next phase on) must have landed: everything but the bundle requested in this tile
-        if (j + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        static_for<32>(slot);
+        if constexpr ((D128_VAR & 2) != 0) __builtin_amdgcn_s_setprio(0);
+        // bundle j + 1 (read from the next half on) must have landed: everything but the bundle requested in this tile
+        if (more_dma) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         D128_SB();
-        __builtin_amdgcn_s_barrier();                                  // ---- end of P2(j)
+        __builtin_amdgcn_s_barrier();                                  // ---- end of the tile
     };
-    auto tile_pv = [&](const char* vt, const u32x4 (&pp)[4]) __attribute__((always_inline)) {
+    auto tile_pv = [&](int imm, const u32x4 (&pp)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pp[kk]);
 #pragma unroll
-            for (int db = 0; db < 4; ++db) o[db] = D128_MFMA(vfrag(vt, kk, db), pb, o[db]);
+            for (int db = 0; db < 4; ++db) o[db] = D128_MFMA(vfrag(imm + kk * 4096, db), pb, o[db]);
         }
     };
     typedef std::integral_constant<bool, true> first_t;
     typedef std::integral_constant<bool, false> steady_t;
-    // P(j) lives in pA for even j, pB for odd j
-    tile(first_t{}, 0, pB, pA);
+    // P(j) lives in pA for even j, pB for odd j; the body is unrolled over the ring period
+    tile(d128_int<0>{}, first_t{}, 0, pB, pA);
     int j = 1;
-    for (; j + 2 <= nt; j += 2) {
-        tile(steady_t{}, j, pA, pB);
-        tile(steady_t{}, j + 1, pB, pA);
+    for (; j + 4 <= nt; j += 4) {
+        tile(d128_int<1>{}, steady_t{}, j, pA, pB);
+        tile(d128_int<2>{}, steady_t{}, j + 1, pB, pA);
+        tile(d128_int<3>{}, steady_t{}, j + 2, pA, pB);
+        tile(d128_int<0>{}, steady_t{}, j + 3, pB, pA);
     }
-    if (j < nt) {
-        tile(steady_t{}, j, pA, pB);
-        tile_pv(Vr + ((nt - 1) & (D128_SLOTS - 1)) * D128_TILE, pB);
-    } else {
-        tile_pv(Vr + ((nt - 1) & (D128_SLOTS - 1)) * D128_TILE, pA);
+    if (j < nt) { tile(d128_int<1>{}, steady_t{}, j, pA, pB); ++j; }
+    if (j < nt) { tile(d128_int<2>{}, steady_t{}, j, pB, pA); ++j; }
+    if (j < nt) { tile(d128_int<3>{}, steady_t{}, j, pA, pB); ++j; }
+    // the last tile's P V (its probabilities: pA for an even tile index, pB for an odd one; V ring slot (nt - 1) & 3)
+    switch ((nt - 1) & 3) {
+        case 0: tile_pv(0 * D128_TILE, pA); break;
+        case 1: tile_pv(1 * D128_TILE, pB); break;
+        case 2: tile_pv(2 * D128_TILE, pA); break;
+        default: tile_pv(3 * D128_TILE, pB); break;
     }
-    if (grp == 0) __builtin_amdgcn_s_barrier();      // matches group 1's stagger barrier
+    if (D128_STAGGER && grp == 0) __builtin_amdgcn_s_barrier();      // matches group 1's stagger barrier
+    if ((D128_VAR & 4) != 0) __builtin_amdgcn_s_setprio(0);
 
     // ---- the window check (attention_pipe.hip): a row sum that is zero, huge or not finite sends the workgroup through
     // the classic running-maximum loop
@@ -325,11 +380,14 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d128_kernel(const AttnPa
             float m_run = -INFINITY, l_run = 0.f;
             for (int t = 0; t < nt; ++t) {
                 __builtin_amdgcn_s_barrier();
-                stage_k(t, t);
-                stage_v(t);
+                dma_k(t, d128_int<0>{}, d128_int<0>{}); dma_k(t, d128_int<0>{}, d128_int<1>{});
+                dma_v(t, d128_int<0>{}, d128_int<0>{}); dma_v(t, d128_int<0>{}, d128_int<1>{});
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                qk_tile(Kr + (t & (D128_SLOTS - 1)) * D128_TILE);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) s[kb] = D128_MFMA(kfrag(kb * 8192, ks), qf[ks], ks == 0 ? zero16 : s[kb]);
                 mask_tail(s, t * ATT_KB);
                 const float m_new = fmaxf(m_run, row_max(s) * p.scale_log2e);
                 const float f = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -347,7 +405,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d128_kernel(const AttnPa
                     pA[i >> 2][i & 3] = d128_cvt_pk(e[0], e[1]);
                     lsum[i & 1] += e;
                 }
-                tile_pv(Vr + (t & (D128_SLOTS - 1)) * D128_TILE, pA);
+                tile_pv(0, pA);
                 l_run += xor32_add((lsum[0][0] + lsum[0][1]) + (lsum[1][0] + lsum[1][1]));
             }
             m_ref = m_run;
