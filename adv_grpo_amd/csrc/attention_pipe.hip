@@ -17,14 +17,16 @@
 // What keeps the VALU share small:
 //   * v_mfma_f32_32x32x16_bf16 with S^T = K Q^T: a lane holds 32 scores of ONE query (query = lane & 31), the other
 //     half-wave the other 32 keys: row max = 16 v_max3 + one half-wave swap, no per-16-row bookkeeping twice.
-//   * Q is pre-multiplied by scale * log2(e) once per workgroup and the score accumulators START at -m (the running
-//     reference maximum, broadcast in a 16-register tuple used as the MFMA's C operand): the MFMA delivers
-//     s * scale * log2e - m and the probability is ONE v_exp_f32, no multiply-add in front of it.
-//   * the reference maximum only moves when a row maximum exceeds it by more than 2^THR (deferred rescale): the common
-//     tile takes no rescale and no branch body; the rare one subtracts the step from the tile's scores at once and
-//     applies the factor to O and to the next tile's scores at the END of the iteration, after the P V products of the
-//     previous tile (still at the old scale) have been issued.  The first tile always takes that path, so a row whose
-//     scores are all far below zero is safe.
+//   * the softmax scale is applied in f32: score pair -> s * (scale * log2e) - m as ONE packed multiply-add in front of the two
+//     v_exp_f32 (a first version folded scale * log2e into a bf16 copy of Q: 3.9e-2 max error on a 6x-scaled-keys case);
+//   * NO per-tile maximum and NO rescale: m is fixed to the row maximum of tile 0 (the first 64 keys) and every probability
+//     of every later tile is taken relative to it.  Mathematically the same softmax (any reference cancels in O / l), and
+//     numerically the same to the bf16 rounding of P as long as no 2^(s - m) leaves the f32 exponent range.  What detects
+//     that it did: the final row sum -- a row whose l is zero, larger than 1e30 or not finite (scores more than ~100 octaves
+//     above or below tile 0's maximum) makes the WHOLE WORKGROUP redo its 128 queries with the classic per-tile running
+//     maximum (the "fallback" loop at the end of the kernel: one tile at a time, no overlap -- several times slower, and
+//     taken silently; tests/test_gpu_attention.py::test_attention_scores_far_outside_the_first_tiles_window forces it and
+//     checks o and lse against the reference, DESIGN.md deviation 10 states how often trained-model-like scores take it);
 //   * P stays in registers as the B operand of P V (the key order inside a 16-deep MFMA step is permuted consistently
 //     on the P side and on the V side, which a sum over keys does not see); V^T fragments by ds_read_b64_tr_b16.
 //

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const LnParams p) {
             uint8_t* q = h ? p.q1 : p.q0;
             if (!q) continue;
             const float amax = wave_allreduce(bf2f((bf16_t)(h ? amax1 : amax0)), [](float a, float b) { return fmaxf(a, b); });
-            const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+            const float scale = amax > 0.f ? fmaxf(amax * (1.0f / 448.0f), 1.17549435e-38f) : 1.0f;   // (never subnormal / zero: 1 / scale stays finite)
             const float inv = 1.0f / scale;
             if (lane == 0) (h ? p.qs1 : p.qs0)[row] = scale;
 #pragma unroll

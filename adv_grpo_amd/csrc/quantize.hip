@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const QuantParams p
     }
     const float amax = wave_allreduce(bf2f((bf16_t)amax_bits), [](float a, float b) { return fmaxf(a, b); });
     // (a NaN / Inf input row gives a NaN / Inf scale and NaN codes: propagated, not hidden)
-    const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float scale = amax > 0.f ? fmaxf(amax * (1.0f / 448.0f), 1.17549435e-38f) : 1.0f;   // (never subnormal / zero: 1 / scale stays finite)
     const float inv = 1.0f / scale;
     int64_t orow = row;
     if (p.split_period > 0) {

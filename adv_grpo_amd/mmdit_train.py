@@ -217,6 +217,7 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             self.requantize()
 
     # ------------------------------------------------------------------ the adapter-free transformer (KL reference)
+    _fp8_base = None           # {(block, Linear): Fp8Rows of the BASE weight}, filled by the first fp8 reference forward
     @torch.no_grad()
     def forward_reference(self, hidden_states, timestep, encoder_hidden_states, pooled_projections):
         """The forward under PEFT's `disable_adapter()` (TP:1105-1108: the reference policy of the KL term): the rollout
@@ -229,12 +230,27 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                 b[gk + ".w"] = base
                 b.pop(gk + ".A", None)          # side mode: no side columns -> the plain [rows, D] input
         ext, self.lora_ext = self.lora_ext, (0, 0)
+        # fp8 Linears (enable_fp8): the forward reads self.fp8[(block, Linear)], the quantised MERGED weights -- the reference
+        # policy needs the quantised BASE weights of the adapted projections there (quantised once: they never change);
+        # without the swap the "reference" equals the policy and the KL term vanishes silently
+        f8_saved = {}
+        if self.fp8 is not None:
+            if self._fp8_base is None:
+                self._fp8_base = {}
+            for i, b in enumerate(self.blocks):
+                for gk, (base, _) in self._base_T[i].items():
+                    if (i, gk) not in self._fp8_base:
+                        self._fp8_base[(i, gk)] = ops.quant_fp8_rows(base)
+                    f8_saved[(i, gk)] = self.fp8[(i, gk)]
+                    self.fp8[(i, gk)] = self._fp8_base[(i, gk)]
         try:
             (v,) = SD3Transformer2DModel.__call__(self, hidden_states, timestep, encoder_hidden_states, pooled_projections)
         finally:
             self.lora_ext = ext
             for b, kv in saved:
                 b.update(kv)
+            if f8_saved:
+                self.fp8.update(f8_saved)
         return v
 
     # ------------------------------------------------------------------ forward with saved activations

@@ -7,6 +7,8 @@ shift applied on the inference grid as well.  Unlike the reference's per-sample
 ``(timesteps == t).nonzero().item()`` (one host sync per sample per step) the index is resolved
 on the host copy of the schedule; only the 11-float sigma table lives on the device.
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -23,6 +25,7 @@ class FlowMatchEulerDiscreteScheduler:
         sig = (np.float32(shift) * sig / (1 + (np.float32(shift) - 1) * sig)).astype(np.float32)
         self.sigma_max = float(sig[0])
         self.sigma_min = float(sig[-1])
+        self._lock = threading.Lock()    # first fill of a table: two rollout threads may miss at the same time
         self._tables = {}          # (n_steps, device) -> (sigmas_host, timesteps_host, sigmas, timesteps): immutable, never freed
         self._install(sig, append_zero=False)
 
@@ -44,6 +47,14 @@ class FlowMatchEulerDiscreteScheduler:
             self.device = device
         key = (int(num_inference_steps), str(self.device))
         hit = self._tables.get(key)
+        if hit is not None:
+            self._sigmas_host, self._timesteps_host, self.sigmas, self.timesteps = hit
+            return
+        with self._lock:
+            self._build(key, num_inference_steps)
+
+    def _build(self, key, num_inference_steps):
+        hit = self._tables.get(key)         # (filled by the thread that held the lock before us)
         if hit is not None:
             self._sigmas_host, self._timesteps_host, self.sigmas, self.timesteps = hit
             return

@@ -42,4 +42,62 @@ def run():
     scal, grad = losses.grpo_loss(lp, old.to(dev), torch.tensor(adv[:B, 0], dtype=torch.float32, device=dev), 5, 1e-5)
     o_loss, _ = o_losses.grpo_loss(lp.cpu(), old, torch.tensor(adv[:B, 0], dtype=torch.float32), 5, 1e-5)
     assert math.isclose(scal[0].item(), o_loss.item(), rel_tol=1e-5, abs_tol=1e-7)
+    _matrix_unit(dev, g)
     torch.cuda.synchronize()
+
+
+def _matrix_unit(dev, g):
+    """The kernels that carry the FLOPs, one small launch each, against fp32 torch arithmetic of the same operands (the
+    oracle's formulas): the eight-phase 256 x 256 GEMM as a PAIRED launch with the bias + QK-norm epilogue, the pipelined
+    head-dim-64 attention, the head-dim-128 attention, and the split-bf16 3 x 3 convolution.  A wrong MFMA operand order, a
+    broken LDS swizzle or a mis-counted DMA wait fails here."""
+    from adv_grpo_amd import _lib, ops
+    from oracle import mmdit as o_m
+    bf16 = torch.bfloat16
+    rnd = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k)
+    # ---- eight-phase GEMM, fused QKV shape in small: image rows + text rows in one launch, 16 q | k heads normalised, 8 v heads not
+    M, Mt, K, H = 8192, 512, 256, 8
+    N = 3 * H * 64
+    lib = _lib.load()
+    assert lib.advgrpo_gemm_variant(M, N, K, 1, 0) == 30, "the wide-Linear shape no longer dispatches gemm8p_kernel"
+    a, at = rnd(M, K).to(bf16), rnd(Mt, K).to(bf16)
+    w, wt = rnd(N, K, k=K ** -0.5).to(bf16), rnd(N, K, k=K ** -0.5).to(bf16)
+    b, bt = rnd(N, k=0.1).to(bf16), rnd(N, k=0.1).to(bf16)
+    rw, rwt = (1 + 0.1 * rnd(2, 64)).to(bf16), (1 + 0.1 * rnd(2, 64)).to(bf16)
+    S = M + Mt
+    out = torch.zeros(S, N, dtype=bf16, device=dev)
+    d = lambda t: t.to(dev)
+    # (a descriptor holds raw pointers: the device copies must outlive the launch)
+    da, dw, db, drw, dat, dwt, dbt, drwt = (d(t) for t in (a, w, b, rw, at, wt, bt, rwt))
+    ops.gemm_grouped([ops.gemm_desc(da, dw, bias=db, out=out, seg=(M, S, 0), rms=(drw, 2 * H, H, 1e-6, None)),
+                      ops.gemm_desc(dat, dwt, bias=dbt, out=out, seg=(Mt, S, M), rms=(drwt, 2 * H, H, 1e-6, None))])
+
+    def ref_rows(x, wm, bias, rmsw):
+        y = (x.float() @ wm.float().t() + bias.float()).to(bf16)
+        y = y.view(-1, 3, H, 64)
+        for part in range(2):
+            y[:, part] = o_m._rms(y[:, part], rmsw[part])
+        return y.reshape(-1, N)
+    ref = torch.cat([ref_rows(a, w, b, rw), ref_rows(at, wt, bt, rwt)])
+    err = (out.cpu().float() - ref.float()).abs().max().item()
+    assert err < 6e-2, f"gemm8p + QK-norm epilogue: max error {err}"
+    # ---- attention: head dim 64 (pipelined kernel) and 128 (8-wave kernel), ragged lengths
+    for hd, S_att in ((64, 300), (128, 200)):
+        Hh = 2
+        qkv = rnd(1, S_att, 3 * Hh * hd).to(bf16)
+        q, k, v = (qkv[..., i * Hh * hd:(i + 1) * Hh * hd] for i in range(3))
+        dq = d(qkv)
+        o = ops.attention(dq[..., :Hh * hd], dq[..., Hh * hd:2 * Hh * hd], dq[..., 2 * Hh * hd:], Hh)
+        heads = lambda t: t.float().view(1, S_att, Hh, hd).transpose(1, 2)
+        r = torch.nn.functional.scaled_dot_product_attention(heads(q), heads(k), heads(v)).transpose(1, 2).reshape(1, S_att, Hh * hd)
+        err = (o.cpu().float() - r).abs().max().item()
+        assert err < 2e-2, f"attention head dim {hd}: max error {err}"
+    # ---- split-bf16 ("fp32-equivalent") 3 x 3 convolution, one 16 x 24 image of 64 -> 128 channels
+    x = rnd(1, 16, 24, 64)
+    wc, bc = rnd(128, 64, 3, 3, k=(64 * 9) ** -0.5), rnd(128, k=0.1)
+    w3 = ops.split_x3(d(wc).permute(0, 2, 3, 1).contiguous(), order=1).reshape(128, -1)
+    x3, dbc = ops.split_x3(d(x)), d(bc)
+    y = ops.conv3x3_x3(x3, w3, bias=dbc)
+    r = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), wc.double(), bc.double(), padding=1).permute(0, 2, 3, 1)
+    err = (y.cpu().double() - r).abs().max().item()
+    assert err < 2e-4, f"conv3x3_x3: max error {err}"

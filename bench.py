@@ -276,6 +276,56 @@ def cpu_baseline():
                                      "pickscore": round(t_clip, 3)}}
 
 
+def scaling_diagnostics(dist, device, world, rank, G, T, dt_local, dt_max, steps, step, D):
+    """What a poor 1 -> N curve would need to name its cause, from the same run (N > 1, or --spawn at N = 1): every rank's own time
+    for the timed steps, the path's two collectives timed alone with HIP events on the launch stream (the packed reward all-gather of
+    TP:926-966 and the all-reduce of the flat 18.78 M-parameter f32 LoRA gradient, TP:1165), and a SOLO leg -- the same step
+    without the exchange, no barrier, each rank on its own -- whose rate stands in for "N = 1 in this run"."""
+    def gathered(x):
+        out = torch.zeros(world, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(out, torch.tensor([x], dtype=torch.float64, device=device))
+        return out.tolist()
+
+    def timed_ms(fn, reps):
+        fn()
+        dist.barrier()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / reps
+    per_rank_ms = [t / steps * 1e3 for t in gathered(dt_local)]
+    rw = torch.rand(G, T, device=device)
+    gi = torch.full((G,), rank, dtype=torch.int32, device=device)
+    ag_ms = timed_ms(lambda: D.gather_rewards(rw, gi), 20)
+    flat = torch.ones(18_776_064, dtype=torch.float32, device=device)          # 191 adapters x 98 304 parameters (SURVEY 2.2)
+    ar_ms = timed_ms(lambda: D.average_gradients(flat), 5)
+    del flat
+    step(0, exchange=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(2):
+        step(1 + it, exchange=False)
+    torch.cuda.synchronize()
+    solo_ms = gathered((time.perf_counter() - t0) / 2 * 1e3)
+    value = world * G * steps / dt_max
+    solo_rank0 = G / (solo_ms[0] * 1e-3)
+    return {"ms_per_step_by_rank": {"min": round(min(per_rank_ms), 2), "max": round(max(per_rank_ms), 2),
+                                    "all": [round(v, 2) for v in per_rank_ms]},
+            "reward_all_gather_ms": round(ag_ms, 4), "lora_gradient_all_reduce_ms": round(ar_ms, 3),
+            "lora_gradient_bytes": 18_776_064 * 4,
+            "solo_ms_per_step_by_rank": {"min": round(min(solo_ms), 2), "max": round(max(solo_ms), 2), "all": [round(v, 2) for v in solo_ms]},
+            "value_at_n1_same_run": round(solo_rank0, 3),
+            "value_over_n_times_n1": round(value / (world * solo_rank0), 4),
+            "value_over_sum_of_solo_rates": round(value / sum(G / (m * 1e-3) for m in solo_ms), 4),
+            "note": "solo = the same step without the exchange, every rank at the same time on its own GPU (rank 0's rate = value_at_n1_same_run); "
+                    "value / (N x that) below 1 is what the barrier + the slowest rank + the collectives cost; collectives timed alone, "
+                    "HIP events around back-to-back calls"}
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -353,7 +403,7 @@ def main():
         pe, ppe, npe, nppe = (t.to(device=device, dtype=torch.bfloat16) for t in synthetic.prompt_embeddings(7 + rank))
     ids = synthetic.clip_input_ids(G, 3 + rank).to(device)
 
-    def step(it):
+    def step(it, exchange=True):
         sampler.set_epoch(it)
         prompt_idx = next(iter(sampler))[0]
         image, lats, lps, tss = pipeline_with_logprob_random(
@@ -365,13 +415,15 @@ def main():
             scores, _ = dino_score(dino, dino_head, image.to(torch.bfloat16), None, None)
         elif c4:    # fp32 scorer (RW:561-574)
             from adv_grpo_amd import vit_x3
-            scores = vit_x3.pickscore_scores_f32(clip.get_image_features(images=image.float()), clip.get_text_features(ids),
+            scores = vit_x3.pickscore_scores_f32(clip.get_image_features(images=image.to(torch.bfloat16)), clip.get_text_features(ids),    # (TP:816: images.to(bf16) before any reward fn)
                                                  clip.logit_scale)
         else:
             scores = vit.pickscore_scores(clip.get_image_features(images=image.to(torch.bfloat16)),
                                           clip.get_text_features(ids), clip.logit_scale)
         rewards = scores.unsqueeze(1).repeat(1, T)                          # TP:926-928
         gids = torch.full((G,), prompt_idx, dtype=torch.int32, device=device)
+        if not exchange:                                                    # (the solo leg of the scaling diagnostics below)
+            return stat_tracking.group_advantage(rewards, gids, True), torch.stack(lps, 1)
         rewards, gids = D.gather_rewards(rewards, gids)                     # TP:930-966 packed into one all-gather
         adv = stat_tracking.group_advantage(rewards, gids, True)            # TP:970 (global_std)
         return D.ungather(adv, world, rank), torch.stack(lps, 1)            # TP:995-999
@@ -393,10 +445,13 @@ def main():
         dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
     assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all()
+    scaling_diag = None
     if dist is not None:
+        dt_local = dt
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
+        scaling_diag = scaling_diagnostics(dist, device, world, rank, G, T, dt_local, dt, args.steps, step, D)
 
     if rank == 0:
         # ---- roofline of the dominant kernel from the HIP events recorded around every GEMM launch
@@ -576,6 +631,7 @@ def main():
                     if "bf16x3" in vae_ms else None,
                     "value_if_bf16": round(images / (dt + args.steps * (vae_ms["bf16"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)
                     if "bf16" in vae_ms else None},
+            "scaling_diagnostics": scaling_diag,
             "clock_and_power": power.summary(),
             "overlap": overlap,
             "fp8_linears": fp8,

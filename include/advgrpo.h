@@ -343,7 +343,7 @@ int advgrpo_gemm_grouped(const advgrpo_gemm_desc* descs, int count /* 1 or 2 */,
 /* ------------------------------------------------------------------ fp8 Linears (BASELINE config 5: "fp8 MFMA path")
  * The reference has no fp8 code (config 5 changes pretrained.model / resolution only); the scheme is this
  * library's: OCP e4m3 codes, one f32 scale per token row of the activation and per output channel of the weight,
- *     x[r,k] ~= scale[r] * q[r,k],   scale[r] = max_k |x[r,k]| / 448  (1 for an all-zero row),  q = RNE(clamp(x / scale)).
+ *     x[r,k] ~= scale[r] * q[r,k],   scale[r] = max(max_k |x[r,k]| / 448, 2^-126)  (1 for an all-zero row),  q = RNE(clamp(x / scale)).
  * advgrpo_quant_fp8_rows: x [M, K] bf16 (pitch ldx) -> q [M, K] one byte per element (pitch ldq) + scale [M].
  * split_period > 0: rows of a joint [B, period, K] buffer are compacted, the first split_first rows of every period (image
  * tokens) to output rows b * split_first + s, the others behind ALL of them (B * split_first + b * (period - split_first) + ..).

@@ -293,3 +293,44 @@ def test_fp8_training_forward_replays_the_rollout_and_differentiates_straight_th
     (v_roll2,) = SD3Transformer2DModel.__call__(m8, x, t, emb, pool)
     v_train2, _ = m8.forward_train(x, t, emb, pool)
     assert torch.equal(v_roll2, v_train2) and not torch.equal(v_roll2, v_roll)
+
+
+def test_fp8_kl_reference_forward_uses_the_base_weights():
+    """train.beta > 0 with fp8 Linears: the adapter-free reference forward must run on the quantised BASE
+    weights of the adapted projections -- it equals what a model without adapters computes in fp8 mode, differs from the policy
+    forward once the adapters are non-zero, leaves the policy's quantised weights in place, and the KL term of a micro-step is
+    then non-zero."""
+    from adv_grpo_amd import g_step, synthetic
+    from adv_grpo_amd.mmdit import SD3Transformer2DModel
+    from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
+    from adv_grpo_amd.scheduler import FlowMatchEulerDiscreteScheduler
+    from oracle.mmdit import MMDiTConfig
+    cfg = MMDiTConfig(num_layers=2, num_heads=4, joint_attention_dim=128, pooled_projection_dim=64,
+                      pos_embed_max_size=96, dual_attention_layers=(0,))
+    G, Nt = 4, 19
+    W = {k: v.to(bf16) for k, v in synthetic.mmdit_weights(cfg, 7).items()}
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=gen).to(bf16)
+    m = SD3TransformerLoRA(W, cfg, "cuda", seed=5)
+    with torch.no_grad():
+        m.params.add_(0.05 * torch.randn(m.params.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9)))
+    m.refresh()
+    m.enable_fp8()
+    plain = SD3Transformer2DModel(W, cfg, "cuda")           # no adapters at all
+    plain.enable_fp8()
+    x, emb, pool = rnd(2 * G, 16, 16, 16), rnd(2 * G, Nt, 128), rnd(2 * G, 64)
+    t = torch.full((2 * G,), 913.3488, device="cuda")
+    q_before = m.fp8[(0, "qkv")].q.clone()
+    v_ref = m.forward_reference(x, t, emb, pool)
+    (v_pol,) = SD3Transformer2DModel.__call__(m, x, t, emb, pool)
+    (v_plain,) = plain(x, t, emb, pool)
+    assert torch.equal(v_ref, v_plain)
+    assert not torch.equal(v_ref, v_pol)
+    assert torch.equal(m.fp8[(0, "qkv")].q, q_before)        # the policy's quantised weights are back
+    sch = FlowMatchEulerDiscreteScheduler(device="cuda"); sch.set_timesteps(10)
+    lat = rnd(G, 16, 16, 16)
+    nxt = (lat.float() * 0.95 + 0.3 * torch.randn(G, 16, 16, 16, device="cuda", generator=gen)).to(bf16)
+    sample = {"latents": lat[:, None], "next_latents": nxt[:, None], "timesteps": sch.timesteps[1].repeat(G)[:, None]}
+    info = g_step.micro_step(m, sch, sample, 0, emb, pool, torch.zeros(G, device="cuda"), torch.randn(G, device="cuda", generator=gen),
+                             guidance_scale=4.5, noise_level=0.8, adv_clip_max=5, clip_range=1e-4, beta=0.04)
+    assert float(info["kl_loss"]) > 1e-6, float(info["kl_loss"])

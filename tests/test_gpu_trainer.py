@@ -362,6 +362,11 @@ def test_bench_self_spawn_path_at_world_1():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["value"] > 0
+    # the fields that make a SCALE run diagnosable from its one line (per-rank times, the two collectives, the solo leg)
+    sd = line["scaling_diagnostics"]
+    assert len(sd["ms_per_step_by_rank"]["all"]) == 1 and sd["ms_per_step_by_rank"]["max"] > 0
+    assert sd["reward_all_gather_ms"] >= 0 and sd["lora_gradient_all_reduce_ms"] >= 0 and sd["lora_gradient_bytes"] == 18_776_064 * 4
+    assert sd["value_at_n1_same_run"] > 0 and 0.8 < sd["value_over_n_times_n1"] < 1.25
 
 
 def test_full_size_epoch_config2(tmp_path):
