@@ -124,6 +124,7 @@ SIGNATURES = {
     "advgrpo_dino_head_combine": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     "advgrpo_pickscore_pairs": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P]),
     "advgrpo_attention_fwd": (c_int, [_P, _P, _P, _P] + [c_int64] * 8 + [c_int] * 5 + [c_float, c_int, _P, _P]),
+    "advgrpo_attention_fallback_count": (c_int, [POINTER(ctypes.c_longlong), c_int]),
     "advgrpo_attention_bwd": (c_int, [_P] * 10 + [c_int64] * 12 + [c_int] * 5 + [c_float, _P]),
 }
 

@@ -546,6 +546,15 @@ extern "C" int advgrpo_attention_fwd(const void* q, const void* k, const void* v
     return attention_fwd(p, B, head_dim, as_stream(stream));
 }
 
+extern "C" int advgrpo_attention_fallback_count(long long* count_host, int reset) {
+    ADVGRPO_CHECK(count_host, "attention_fallback_count: null pointer");
+    unsigned long long a = 0, b = 0;
+    ADVGRPO_CHECK(hipDeviceSynchronize() == hipSuccess && attention_pipe_fallbacks(&a, reset) == 0 && attention_d128_fallbacks(&b, reset) == 0,
+                  "attention_fallback_count: cannot read the device counters");
+    *count_host = (long long)(a + b);
+    return 0;
+}
+
 /* same + additive score bias [H,Sq,Skv] f32 shared by the batch: softmax(q k^T * scale + bias) v (T5's relative position
  * bias; T5 itself uses scale = 1).  Text encoders of encode_prompt, train_dreambooth_lora_sd3.py:98-144. */
 extern "C" int advgrpo_attention_fwd_bias(const void* q, const void* k, const void* v, void* o, int64_t ldq, int64_t ldk,

@@ -46,5 +46,8 @@ __device__ __forceinline__ void att_dma16(const void* src, const char* lds) {
 int attention_fwd_pipe_launch(const AttnParams& p, hipStream_t s);
 // head dim 128 (attention_d128.hip): 8-wave workgroups of 256 queries, non-causal, no score bias, 16-byte aligned output rows
 int attention_fwd_d128_launch(const AttnParams& p, int B, hipStream_t s);
+// workgroups of the two kernels above that took their running-maximum fallback since the last reset (host call, synchronises)
+int attention_pipe_fallbacks(unsigned long long* out, int reset);
+int attention_d128_fallbacks(unsigned long long* out, int reset);
 
 }  // namespace advgrpo

@@ -47,6 +47,8 @@
 
 namespace advgrpo {
 
+__device__ unsigned long long g_d128_fallbacks = 0;     // workgroups that took the running-maximum fallback (see attention_pipe.hip)
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -375,6 +377,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d128_kernel(const AttnPa
         for (int w = 0; w < 8; ++w) any_bad |= wg_flag[w];
         if (any_bad) {
             asm volatile("; fallback: running maximum per tile" ::: "memory");
+            if (tid == 0) atomicAdd(&g_d128_fallbacks, 1ull);
 #pragma unroll
             for (int db = 0; db < 4; ++db) o[db] = zero16;
             float m_run = -INFINITY, l_run = 0.f;
@@ -438,6 +441,14 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d128_kernel(const AttnPa
         const int qo = q0 + r;
         if (qo < p.Sq) *reinterpret_cast<uint4*>(p.o + (int64_t)b * p.bso + (int64_t)qo * p.ldo + h * HD + c * 8) = v;
     }
+}
+
+int attention_d128_fallbacks(unsigned long long* out, int reset) {
+    unsigned long long v = 0, z = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_d128_fallbacks), sizeof(v)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_d128_fallbacks), &z, sizeof(z)) != hipSuccess) return -1;
+    *out = v;
+    return 0;
 }
 
 int attention_fwd_d128_launch(const AttnParams& p_in, int B, hipStream_t s) {

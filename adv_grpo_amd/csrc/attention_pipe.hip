@@ -45,6 +45,10 @@
 
 namespace advgrpo {
 
+// workgroups that took the running-maximum fallback since the last reset (advgrpo_attention_fallback_count): the slow path is
+// otherwise silent
+__device__ unsigned long long g_pipe_fallbacks = 0;
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -393,6 +397,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_pipe_kernel(const AttnPa
         const int any_bad = wg_flag[0] | wg_flag[1] | wg_flag[2] | wg_flag[3];
         if ((ATT_ABL & 128) == 0 && any_bad) {
             asm volatile("; fallback: running maximum per tile" ::: "memory");
+            if (tid == 0) atomicAdd(&g_pipe_fallbacks, 1ull);
             o[0] = zero16; o[1] = zero16;
             float m_run = -INFINITY, l_run = 0.f;
             for (int t = 0; t < nt; ++t) {
@@ -456,6 +461,14 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_pipe_kernel(const AttnPa
         const int qo = q0 + r;
         if (qo < p.Sq) *reinterpret_cast<uint4*>(p.o + (int64_t)b * p.bso + (int64_t)qo * p.ldo + h * HD + c * 8) = v;
     }
+}
+
+int attention_pipe_fallbacks(unsigned long long* out, int reset) {
+    unsigned long long v = 0, z = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_pipe_fallbacks), sizeof(v)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_fallbacks), &z, sizeof(z)) != hipSuccess) return -1;
+    *out = v;
+    return 0;
 }
 
 int attention_fwd_pipe_launch(const AttnParams& p, hipStream_t s) {

@@ -257,6 +257,14 @@ def attention(q, k, v, num_heads, scale=None, causal=False, out=None, lse=None):
     return out
 
 
+def attention_fallback_count(reset=True):
+    """Workgroups of the pipelined attention forwards that took the running-maximum fallback since the last reset (synchronises)."""
+    import ctypes
+    n = ctypes.c_longlong(0)
+    _lib.check(_lib.load().advgrpo_attention_fallback_count(ctypes.byref(n), int(reset)))
+    return n.value
+
+
 def attention_bwd(q, k, v, o, d_o, lse, num_heads, dq, dk, dv, scale=None):
     """Gradients of ops.attention.  q,k,v,o,d_o: [B,S,H*64] bf16 views; lse f32 [B,H,Sq] from the forward;
     dq/dk/dv: bf16 views of ONE packed buffer (same row / batch pitch)."""

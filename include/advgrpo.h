@@ -200,6 +200,12 @@ int advgrpo_attention_fwd(const void* q, const void* k, const void* v, void* o,
                           int B, int H, int Sq, int Skv, int head_dim, float scale, int causal,
                           float* lse, void* stream);
 
+/* Diagnostic (HOST call; the one entry point that synchronises the device): the softmax of the pipelined forward kernels
+ * (head dim 64 without mask / bias, head dim 128) takes every probability relative to the row maximum of the FIRST key tile
+ * and never rescales; a workgroup whose row sums leave (1e-30, 1e30) redoes its queries with a per-tile running maximum.
+ * count_host receives the number of workgroups that took that slow path on the current device since the last reset. */
+int advgrpo_attention_fallback_count(long long* count_host, int reset);
+
 /* advgrpo_attention_fwd + an additive score bias [H,Sq,Skv] f32 shared over the batch: softmax(q k^T scale + bias) v.
  * T5 self-attention (relative position bias, scale = 1) inside encode_prompt, train_dreambooth_lora_sd3.py:98-144. */
 int advgrpo_attention_fwd_bias(const void* q, const void* k, const void* v, void* o, int64_t ldq, int64_t ldk,

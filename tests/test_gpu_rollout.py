@@ -67,9 +67,12 @@ def test_rollout_matches_reference_trajectory(case, dtype):
         assert np.allclose(lpj.cpu().numpy(), g["replay_log_probs"][:, j], rtol=2e-2 if dtype == torch.bfloat16 else 1e-4)
 
 
-def test_end_to_end_sample_decode_score_small_stack():
+@pytest.mark.parametrize("qk_scale", [1.0, 3.0])
+def test_end_to_end_sample_decode_score_small_stack(qk_scale):
     """Whole hot path (MMDiT rollout -> VAE decode -> PickScore) on a reduced-depth stack, HIP vs the fp32
-    oracle driven with the same injected noise: log-probs, image and rewards."""
+    oracle driven with the same injected noise: log-probs, image and rewards.  qk_scale = 3: the q / k RMSNorm weights of every
+    attention x 3, i.e. attention logits with a standard deviation of ~9 instead of the ~1 random weights give -- the peaked
+    softmax rows of a trained MMDiT -- under the SAME tolerances."""
     from adv_grpo_amd import synthetic, vit
     from adv_grpo_amd.diffusers_patch.sd3_pipeline_with_logprob_fast import pipeline_with_logprob_random
     from adv_grpo_amd.mmdit import SD3Transformer2DModel
@@ -86,7 +89,8 @@ def test_end_to_end_sample_decode_score_small_stack():
                            pos_embed_max_size=96, dual_attention_layers=(0, 1))
     vcfg = o_v.VaeConfig()
     ccfg = o_t.ClipConfig(v_layers=2, t_layers=2)
-    Wm = {k: v.to(torch.bfloat16) for k, v in synthetic.mmdit_weights(mcfg, 21).items()}
+    Wm = {k: ((v * qk_scale) if (".norm_q." in k or ".norm_k." in k or ".norm_added_" in k) else v).to(torch.bfloat16)
+          for k, v in synthetic.mmdit_weights(mcfg, 21).items()}
     Wv = {k: v.to(torch.bfloat16) for k, v in synthetic.vae_decoder_weights(vcfg, 22).items()}
     Wc = {k: v.to(torch.bfloat16) for k, v in synthetic.clip_weights(ccfg, 23).items()}
     pipe = SD3Pipeline(SD3Transformer2DModel(Wm, mcfg, "cuda"), AutoencoderKLDecoder(Wv, vcfg, "cuda"), "cuda")
