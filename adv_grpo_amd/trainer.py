@@ -529,6 +529,17 @@ class Trainer:
         self.pipe.scheduler.set_timesteps(c.sample.num_steps, device=self.device)
         agg = {}
         n_acc = 0
+        # HIP-event pairs around every micro-step / optimizer step of this G-step (events on the launch stream: no host sync, no
+        # cost): bench.py's epoch leg reads them after its final synchronize -- the in-situ micro-step time, not an isolated one
+        ev = self.gstep_events = []
+
+        def timed(kind, fn):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn()
+            e1.record()
+            ev.append((kind, e0, e1))
+            return out
         for inner in range(c.train.num_inner_epochs):
             for i in range(nb):
                 sl = slice(i * G, (i + 1) * G)
@@ -537,20 +548,20 @@ class Trainer:
                 embeds = torch.cat([neg_pe.repeat(G, 1, 1), s["prompt_embeds"]])            # TP:1084-1091
                 pooled = torch.cat([neg_ppe.repeat(G, 1), s["pooled_prompt_embeds"]])
                 for j in range(T):
-                    info = g_step.micro_step(model, self.pipe.scheduler, s, j, embeds, pooled, s["log_probs"][:, j],
-                                             s["advantages"][:, j], guidance_scale=c.sample.guidance_scale,
-                                             noise_level=c.sample.noise_level, adv_clip_max=c.train.adv_clip_max,
-                                             clip_range=c.train.clip_range, loss_scale=1.0 / (GA * T),
-                                             step_index=samples["first_step_index"][i] + j, beta=c.train.beta)
+                    info = timed("micro_step", lambda: g_step.micro_step(
+                        model, self.pipe.scheduler, s, j, embeds, pooled, s["log_probs"][:, j], s["advantages"][:, j],
+                        guidance_scale=c.sample.guidance_scale, noise_level=c.sample.noise_level, adv_clip_max=c.train.adv_clip_max,
+                        clip_range=c.train.clip_range, loss_scale=1.0 / (GA * T), step_index=samples["first_step_index"][i] + j,
+                        beta=c.train.beta))
                     for k in ("loss", "approx_kl", "clipfrac", "clipfrac_gt_one", "clipfrac_lt_one", "policy_loss") + \
                             (("kl_loss",) if c.train.beta > 0 else ()):                     # TP:1158-1160
                         agg[k] = agg.get(k, 0) + info[k]
                     n_acc += 1
                 if (i + 1) % GA == 0:                                                       # sync_gradients, TP:1166-1185
-                    D.average_gradients(model.grads)                                       # TP:1165 (DeepSpeed / DDP)
-                    model.optimizer_step(lr=c.train.learning_rate, betas=(c.train.adam_beta1, c.train.adam_beta2),
-                                         eps=c.train.adam_epsilon, weight_decay=c.train.adam_weight_decay,
-                                         max_grad_norm=c.train.max_grad_norm)
+                    timed("grad_all_reduce", lambda: D.average_gradients(model.grads))     # TP:1165 (DeepSpeed / DDP)
+                    timed("optimizer_step", lambda: model.optimizer_step(
+                        lr=c.train.learning_rate, betas=(c.train.adam_beta1, c.train.adam_beta2), eps=c.train.adam_epsilon,
+                        weight_decay=c.train.adam_weight_decay, max_grad_norm=c.train.max_grad_norm))
                     out = {k: v / n_acc for k, v in agg.items()}
                     out.update({"epoch": self.epoch, "inner_epoch": inner})
                     self.logger.log(out, self.global_step)

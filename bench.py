@@ -202,6 +202,12 @@ def full_epoch(device, world=1, rank=0):
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
+    # the G-step from the inside: HIP events the trainer recorded around every micro-step / gradient all-reduce / optimizer step
+    g_inside = {}
+    for kind, e0, e1 in getattr(trainer, "gstep_events", []):
+        g_inside.setdefault(kind, []).append(e0.elapsed_time(e1))
+    g_inside = {k: {"n": len(v), "mean_ms": round(sum(v) / len(v), 2), "min_ms": round(min(v), 2), "max_ms": round(max(v), 2)}
+                for k, v in g_inside.items()}
     phases = dict(trainer.timers)
     if world > 1:                              # slowest rank per phase (every rank walks the phases in the same order)
         keys = sorted(phases)
@@ -211,6 +217,8 @@ def full_epoch(device, world=1, rank=0):
     images = world * cfg.sample.num_batches_per_epoch * cfg.sample.mini_num_image_per_prompt
     return {"images": images, "seconds": round(dt, 3), "images_per_s_full_epoch": round(images / dt, 3),
             "phases_s": {k: round(v, 4) for k, v in phases.items()}, "phases_are": "max over ranks" if world > 1 else "rank 0",
+            "g_step_inside": g_inside, "g_step_inside_is": "HIP events on the launch stream around each call, this rank, in situ (after the "
+                                                           "sampling phase of the same epoch)",
             "exchanges": "reward all-gather once per epoch; all-reduce of the flat LoRA gradient before each optimizer step (TP:1165)",
             "note": "sample = rollout + VAE decode; score = PickScore of generated AND reference images; g_step = "
                     "2 groups x 2 SDE timesteps fwd+bwd at CFG batch 16 + 2 clip+AdamW steps + EMA (+ for N > 1 the all-reduce of "
