@@ -88,7 +88,9 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
         # adapter-gradient launches run on this stream beside the main chain (one stream for the model: the token-contracted
         # GEMMs share a workspace, and micro-steps issued from two host threads must not each make their own)
         self.overlap_wgrad = True
-        self._wgrad_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == "cuda" and torch.cuda.is_available() else None
+        # the adapter-gradient side stream: one that is measured to run beside the current stream (ops.concurrent_stream: with
+        # HIP's few hardware queues a plain torch.cuda.Stream() may share the main stream's queue and overlap nothing)
+        self._wgrad_stream = ops.concurrent_stream(dev)
         self._prepare_transposes()
         self.refresh()
 

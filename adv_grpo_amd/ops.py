@@ -410,6 +410,55 @@ def cached(cache, key, make):
     return t
 
 
+# ---- side streams that really run beside their partners.  HIP maps streams onto a few hardware queues (4 by default,
+# GPU_MAX_HW_QUEUES) in the order of their first use, round-robin: whether a side stream shares a queue with the stream it is
+# meant to overlap -- and is then simply serialised behind it -- depends on how many streams the process used before.
+# Measured (round 4): bench.py's epoch leg ran its G-step micro-steps in 105 ms where a fresh process took 94 ms, because the
+# rollout leg in front had used one more stream and the adapter-gradient stream landed on the main stream's queue.
+
+def _overlaps(a, b, dev):
+    """Do single-workgroup kernels on streams a and b run at the same time?  (group-advantage launches: ~0.15 ms each, one CU)"""
+    from . import stat_tracking
+    r = torch.rand(768, 2, device=dev)
+    g = (torch.arange(768, device=dev) // 8).to(torch.int32)
+    n = 6
+
+    def burst(streams):
+        torch.cuda.synchronize(dev)
+        t0 = torch.cuda.Event(enable_timing=True)
+        ends = []
+        t0.record(torch.cuda.current_stream(dev))
+        for st in streams:
+            st.wait_event(t0)
+            with torch.cuda.stream(st):
+                for _ in range(n):
+                    stat_tracking.group_advantage(r, g, True)
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(st)
+                ends.append(e)
+        torch.cuda.synchronize(dev)
+        return max(t0.elapsed_time(e) for e in ends)
+    burst([a, b])                                   # first use of both streams (queue assignment), code load
+    one, both = min(burst([a]) for _ in range(2)), min(burst([a, b]) for _ in range(2))
+    return both < 1.5 * one
+
+
+def concurrent_stream(device, partners=()):
+    """A torch stream on `device` that is MEASURED to run concurrently with every stream in `partners` (default: the current
+    stream): candidates from torch's pool are tried until one does (at most 8; the last one is returned regardless).  With
+    more live streams than hardware queues not every pair can be concurrent -- name the partners that matter."""
+    dev = torch.device(device)
+    if dev.type != "cuda" or not torch.cuda.is_available():
+        return None
+    partners = list(partners or ()) or [torch.cuda.current_stream(dev)]
+    cand = None
+    for _ in range(8):
+        cand = torch.cuda.Stream(device=dev)
+        if all(_overlaps(p, cand, dev) for p in partners):
+            break
+    return cand
+
+
 _ZERO_PAGE = {}
 
 

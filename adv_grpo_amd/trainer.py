@@ -18,7 +18,7 @@ import time
 import torch
 
 from . import distributed as D
-from . import g_step, rewards, stat_tracking
+from . import g_step, ops, rewards, stat_tracking
 from .d_step import train_dino
 from .d_step_pickscore import ClipLastLayerTrainable, train_pickscore
 from .diffusers_patch.sd3_pipeline_with_logprob_fast import pipeline_with_logprob_random
@@ -296,7 +296,9 @@ class Trainer:
                 self._rollout_pool = ThreadPoolExecutor(max_workers=in_flight, thread_name_prefix="advgrpo-rollout")
                 d = torch.device(self.device)
                 self._rollout_dev = d.index if d.index is not None else torch.cuda.current_device()
-                self._rollout_streams = [torch.cuda.Stream(device=self._rollout_dev) for _ in range(in_flight)]
+                self._rollout_streams = []           # pairwise concurrent by measurement (ops.concurrent_stream: hardware queues)
+                for _ in range(in_flight):
+                    self._rollout_streams.append(ops.concurrent_stream(d, list(self._rollout_streams) or None))
                 import threading
                 self._rollout_tls, self._rollout_lock = threading.local(), threading.Lock()
             main = torch.cuda.current_stream()

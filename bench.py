@@ -22,6 +22,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")    # before the HIP runtime starts: see adv_grpo_amd/__init__.py (stream -> hardware queue map)
 
 import torch  # noqa: E402
 
@@ -45,8 +46,9 @@ def parse():
                     help="HIP events around every Nth launch of each GEMM kernel in the timed steps (1 = every launch).  The roofline's "
                          "per-launch average is then a 1-in-N sample; a prime N walks through the 4 / 6 launches of a block.  Events "
                          "around all ~1220 GEMM launches of a step cost 1.7 %% of the step (measured, DESIGN.md 6)")
-    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"],
-                    help="c2 = the headline (BASELINE config 2); c4 = secondary line, SD3.5-large 1024^2 G=4 (BASELINE config 4 shapes); "
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
+                    help="c2 = the headline (BASELINE config 2); c3 = BASELINE config 3's rank-local work (config 2's rollout with the co-trained "
+                         "DINOv2-patch discriminator as reward; its epoch leg runs one D epoch and one G epoch); c4 = secondary line, SD3.5-large 1024^2 G=4 (BASELINE config 4 shapes); "
                          "c5 = secondary line, Qwen-Image MMDiT 1024^2 G=8, DINO reward, fp8 Linears (BASELINE config 5 shapes)")
     ap.add_argument("--no-pricing", action="store_true",
                     help="skip the untimed legs that price the alternative modes (split-bf16 VAE, LoRA side path): profiling runs, "
@@ -164,10 +166,12 @@ def pmc_traffic(kernel, config="c2"):
     return None, None
 
 
-def full_epoch(device, world=1, rank=0):
+def full_epoch(device, world=1, rank=0, adversarial=False):
     """the whole sample -> score -> gather -> advantage -> G-step loop and its phases, outside the timed
     region of the headline metric: config 2 (pickscore_cotrain_sd3_fast preset, 8 images per prompt so that one rank
-    holds whole groups), 2 prompt groups per epoch = 16 images, 2 optimizer steps; the second epoch is reported."""
+    holds whole groups), 2 prompt groups per epoch = 16 images, 2 optimizer steps; the second epoch is reported.
+    adversarial (config 3): the dino_cotrain_sd3_patch_fast preset with its DINOv2-B/14 + head discriminator (TD:156-232,
+    1091-1115), d_times = 2 here so that a D epoch and a G epoch alternate: after a warm-up pair, one of each is timed."""
     from adv_grpo_amd import synthetic
     from adv_grpo_amd.config.experiments import get_config
     from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
@@ -176,27 +180,43 @@ def full_epoch(device, world=1, rank=0):
     from adv_grpo_amd.pipeline import SD3Pipeline
     from adv_grpo_amd.trainer import SyntheticData, Trainer
     from adv_grpo_amd.vae import AutoencoderKLDecoder
-    cfg = get_config("pickscore_cotrain_sd3_fast", gpu_number=world)
+    cfg = get_config("dino_cotrain_sd3_patch_fast" if adversarial else "pickscore_cotrain_sd3_fast", gpu_number=world)
     cfg.sample.num_image_per_prompt = 8
     cfg.sample.num_batches_per_epoch = 2
     cfg.train.gradient_accumulation_steps = 1
-    cfg.train_d = False                      # G epochs only (the D/G gate depends on random rewards here)
+    if adversarial:
+        cfg.d_times = 2                      # D epoch, G epoch, D epoch, ... (the shipped preset: 9 D epochs per G epoch, TD:1097)
+    else:
+        cfg.train_d = False                  # G epochs only (the D/G gate depends on random rewards here)
     mcfg = MMDiTConfig()
+    head = None
     with synthetic.on_device(device):
         tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, device, seed=cfg.seed)
         vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321), VaeConfig(), device)
-        scorer = PickScoreScorer(device, dtype=torch.bfloat16, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
+        if adversarial:
+            from adv_grpo_amd import vit
+            from adv_grpo_amd.d_step import DinoHeadTrainable
+            from adv_grpo_amd.model_configs import DinoConfig
+            scorer = vit.DinoV2(synthetic.dino_weights(DinoConfig(), 888), DinoConfig(), device)
+            head = DinoHeadTrainable(device=device, seed=0)
+        else:
+            scorer = PickScoreScorer(device, dtype=torch.bfloat16, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
     trainer = Trainer(cfg, SD3Pipeline(tr, vae, device), SyntheticData(resolution=cfg.resolution, device=device), scorer,
-                      None, rank, world, log_path=None)
-    trainer.run_epoch()                      # warm-up epoch
+                      head, rank, world, log_path=None)
+    for _ in range(2 if adversarial else 1):
+        trainer.run_epoch()                  # warm-up: one epoch (config 2) / a D epoch and a G epoch (config 3)
     trainer.timers.clear()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
+    epoch_s = []
     t0 = time.perf_counter()
-    trainer.run_epoch()
-    torch.cuda.synchronize()
+    for _ in range(2 if adversarial else 1):
+        te = time.perf_counter()
+        out = trainer.run_epoch()
+        torch.cuda.synchronize()
+        epoch_s.append((out["phase"], time.perf_counter() - te))
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -214,8 +234,17 @@ def full_epoch(device, world=1, rank=0):
         pm = torch.tensor([phases[k] for k in keys], dtype=torch.float64, device=device)
         dist.all_reduce(pm, op=dist.ReduceOp.MAX)
         phases = dict(zip(keys, pm.tolist()))
-    images = world * cfg.sample.num_batches_per_epoch * cfg.sample.mini_num_image_per_prompt
-    return {"images": images, "seconds": round(dt, 3), "images_per_s_full_epoch": round(images / dt, 3),
+    images = world * cfg.sample.num_batches_per_epoch * cfg.sample.mini_num_image_per_prompt * len(epoch_s)
+    adv = {}
+    if adversarial:      # the shipped preset runs 9 D epochs per G epoch (d_times = 10): the blended rate of this rank's timings
+        d_s = next(t for ph, t in epoch_s if ph == "D")
+        g_s = next(t for ph, t in epoch_s if ph == "G")
+        adv = {"epochs_timed": [ph for ph, _ in epoch_s], "d_epoch_s": round(d_s, 3), "g_epoch_s": round(g_s, 3),
+               "images_per_s_at_d_times_10": round(world * 16 * 10 / (9 * d_s + g_s), 3),
+               "adversarial_note": "D epoch = sample + score (generated and reference images through DINOv2-B/14 @ 518 + head) + train_dino "
+                                   "(hinge on CLS + 0.3 x hinge on 64 patches, 16 real + 16 generated images, Adam on the head, TD:156-232); "
+                                   "G epoch = the same sampling + the GRPO update; phases_s sums both epochs (this rank's host clock)"}
+    return {"images": images, "seconds": round(dt, 3), "images_per_s_full_epoch": round(images / dt, 3), **adv,
             "phases_s": {k: round(v, 4) for k, v in phases.items()}, "phases_are": "max over ranks" if world > 1 else "rank 0",
             "g_step_inside": g_inside, "g_step_inside_is": "HIP events on the launch stream around each call, this rank, in situ (after the "
                                                            "sampling phase of the same epoch)",
@@ -393,11 +422,21 @@ def main():
     from adv_grpo_amd.sampler import DistributedKRepeatSampler
     from adv_grpo_amd.trainer import rollout_seed
 
-    c4, c5 = args.config == "c4", args.config == "c5"
+    c3, c4, c5 = args.config == "c3", args.config == "c4", args.config == "c5"
     if c5:
         pipe, (dino, dino_head) = build_c5(device, vae_mode=args.vae_mode)
         clip = None
         from adv_grpo_amd import rewards
+        dino_score = rewards.dino_patch_cotrain_score(device)
+    elif c3:    # config 2's generator, the co-trained DINOv2-B/14 patch discriminator + head as the reward (RW:375-434)
+        pipe, _unused = build(device, large=False, vae_mode=args.vae_mode)
+        del _unused
+        clip = None
+        from adv_grpo_amd import rewards, vit as _vit
+        from adv_grpo_amd.model_configs import DinoConfig
+        with synthetic.on_device(device):
+            dino = _vit.DinoV2(synthetic.dino_weights(DinoConfig(), 888), DinoConfig(), device)
+            dino_head = _vit.DinoHead(synthetic.dino_head_weights(768, 512, 999), device)
         dino_score = rewards.dino_patch_cotrain_score(device)
     else:
         pipe, clip = build(device, large=c4, vae_mode=args.vae_mode)
@@ -419,7 +458,7 @@ def main():
             negative_pooled_prompt_embeds=nppe, num_inference_steps=STEPS, guidance_scale=4.5, output_type="pt",
             height=RES, width=RES, noise_level=0.8, mini_num_image_per_prompt=G, train_num_steps=T,
             process_index=rank, sample_num_steps=STEPS, random_timestep=0, seed=rollout_seed(42, it, rank))
-        if c5:      # the co-trained DINOv2 patch scorer (RW:375-434): bicubic 1024 -> 518, ViT-B/14, 64 random patches, head
+        if c5 or c3:    # the co-trained DINOv2 patch scorer (RW:375-434): bicubic -> 518, ViT-B/14, 64 random patches, head
             scores, _ = dino_score(dino, dino_head, image.to(torch.bfloat16), None, None)
         elif c4:    # fp32 scorer (RW:561-574)
             from adv_grpo_amd import vit_x3
@@ -483,7 +522,7 @@ def main():
         images = world * G * args.steps
         # algorithmic FLOPs per sampled+scored image: 10*2*2.219 + 2.51 + 0.38 TFLOP at config 2;
         # SD3.5-large 1024^2 (config 4 shapes): 30.02 TFLOP per sample-forward, VAE x4 pixels
-        per_image_tflop = (10 * 2 * 30.02 + 4 * 2.51 + 0.38) if c4 else (10 * 2 * 2.219 + 2.51 + 0.38)
+        per_image_tflop = (10 * 2 * 30.02 + 4 * 2.51 + 0.38) if c4 else (10 * 2 * 2.219 + 2.51 + (0.30 if c3 else 0.38))
         mixed_peak_s = None
         if c5:      # Qwen-Image at 1024^2: 4096 packed positions + the text tokens; Linears on the fp8 MFMA, attention / VAE / DINO on bf16
             from adv_grpo_amd.qwen_mmdit import flops_per_sample_forward
@@ -519,7 +558,7 @@ def main():
         # the rollout with PEFT's LoRA arithmetic (side path as a K-extension of the adapted Linears, mmdit_train.py) instead
         # of LoRA merged into the bf16 weights: same step, other transformer object
         lora_ms = {"merged": round(step_ms, 2)}
-        if not c4 and not c5 and world == 1 and not args.no_pricing:
+        if not c3 and not c4 and not c5 and world == 1 and not args.no_pricing:
             from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
             merged_tr = pipe.transformer
             with synthetic.on_device(device):
@@ -548,7 +587,7 @@ def main():
             pipe.transformer.fp8 = keep8
             bf16_linears = {"ms_per_step": round(b_ms, 2), "value": round(G / (b_ms * 1e-3), 3), "fp8_speedup_over_bf16_step": round(b_ms / step_ms, 3),
                             "note": "the same step with the block Linears on bf16 operands (the eight-phase bf16 kernel): what the fp8 MFMA path buys"}
-        if not c5 and world == 1 and not args.no_pricing:
+        if not c5 and not c3 and world == 1 and not args.no_pricing:
             pipe.transformer.enable_fp8()
             step(0)
             torch.cuda.synchronize()
@@ -575,7 +614,7 @@ def main():
         # launch's HIP-event duration includes the other stream's kernels, so the per-kernel roofline is only defined for
         # the serial schedule above.
         overlap = None
-        if not c4 and not c5 and world == 1 and not args.no_pricing:
+        if not c3 and not c4 and not c5 and world == 1 and not args.no_pricing:
             streams = [torch.cuda.Stream(), torch.cuda.Stream()]
             from concurrent.futures import ThreadPoolExecutor
             pool = ThreadPoolExecutor(2)
@@ -605,7 +644,8 @@ def main():
         res = {
             "metric": "sampled+scored images/sec (whole node), SD3.5-large 1024^2 10-step G=4 (secondary line, BASELINE config 4 shapes)"
             if c4 else ("sampled+scored images/sec (whole node), Qwen-Image MMDiT 1024^2 10-step G=8, DINO reward, fp8 Linears (secondary line, "
-                        "BASELINE config 5 shapes)" if c5 else "sampled+scored images/sec (whole node), SD3-med 512^2 10-step G=8 GRPO"),
+                        "BASELINE config 5 shapes)" if c5 else ("sampled+scored images/sec (whole node), SD3-med 512^2 10-step G=8, DINOv2-patch "
+                        "adversarial reward (BASELINE config 3, rank-local work)" if c3 else "sampled+scored images/sec (whole node), SD3-med 512^2 10-step G=8 GRPO")),
             "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if c5 else "bf16", "data": "synthetic",
@@ -618,9 +658,10 @@ def main():
                                    if c5 else (("BASELINE config 4 shapes: SD3.5-large (38 blocks, D=2432) LoRA-merged 1024x1024, 10 steps, CFG 4.5, "
                                     "G=4, SDE window 2 @ noise 0.8, VAE decode (" + pipe.vae.mode + "), fp32-equivalent PickScore reward (the OCR half of the reward is a "
                                     "host plugin outside the timed path), reward all-gather + group advantage") if c4 else
-                                   ("BASELINE config 2: SD3.5-medium LoRA-merged 512x512, 10 steps, CFG 4.5, G=8, "
-                                    "SDE window 2 @ noise 0.8, VAE decode (" + pipe.vae.mode + "), PickScore (CLIP ViT-H/14) reward, "
-                                    "reward all-gather + group advantage")), "global_batch": world * G,
+                                   ("BASELINE config " + ("3" if c3 else "2") + ": SD3.5-medium LoRA-merged 512x512, 10 steps, CFG 4.5, G=8, "
+                                    "SDE window 2 @ noise 0.8, VAE decode (" + pipe.vae.mode + "), " +
+                                    ("co-trained DINOv2 ViT-B/14 @ 518 patch discriminator + head as reward (RW:375-434)" if c3 else
+                                     "PickScore (CLIP ViT-H/14) reward") + ", reward all-gather + group advantage")), "global_batch": world * G,
                        "transformer_batch_per_gpu": 2 * G, "parallelism": f"dp{world} (prompt groups sharded)"},
             "effective_tflops_per_gpu": round(per_image_tflop * images / dt / world, 1),
             "frac_of_bf16_mfma_peak": round(per_image_tflop * images / dt / world / BF16_DENSE_PEAK_TFLOPS, 4),
@@ -654,13 +695,15 @@ def main():
         }
     run_epoch = not c4 and not c5 and not args.no_epoch       # at every N: for N > 1 this is the leg with the LoRA-gradient all-reduce (TP:1165)
     if run_epoch:                                   # every rank takes part (LoRA-gradient all-reduce, reward gather)
+        if c3:
+            del dino, dino_head
         del pipe, clip
         torch.cuda.empty_cache()
-        ep = full_epoch(device, world, rank)
+        ep = full_epoch(device, world, rank, adversarial=c3)
         if rank == 0:
             res["epoch"] = ep
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and not c4 and not c5:
+        if world == 1 and not args.no_cpu_baseline and not c3 and not c4 and not c5:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
     if dist is not None:

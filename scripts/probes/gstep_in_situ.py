@@ -20,6 +20,14 @@ from adv_grpo_amd.trainer import SyntheticData, Trainer  # noqa: E402
 from adv_grpo_amd.vae import AutoencoderKLDecoder  # noqa: E402
 
 device = torch.device("cuda", 0)
+# hypothesis check (round 4): streams created EARLIER in the process shift which hardware queue the adapter-gradient side stream
+# lands on (torch hands out pool streams round-robin; HIP maps them onto a few hardware queues)
+_dummies = [torch.cuda.Stream(device=device) for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 0)]
+for _s in _dummies:                       # really used: a pool stream only exists on the HIP side once something ran on it
+    with torch.cuda.stream(_s):
+        torch.zeros(16, device=device).add_(1)
+torch.cuda.synchronize()
+_prio = int(os.environ.get("WGRAD_PRIO", "0"))
 cfg = get_config("pickscore_cotrain_sd3_fast", gpu_number=1)
 cfg.sample.num_image_per_prompt = 8
 cfg.sample.num_batches_per_epoch = 2
@@ -30,6 +38,8 @@ with synthetic.on_device(device):
     tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, device, seed=cfg.seed)
     vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321), VaeConfig(), device)
     scorer = PickScoreScorer(device, dtype=torch.bfloat16, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
+if _prio:
+    tr._wgrad_stream = torch.cuda.Stream(device=device, priority=-1)
 trainer = Trainer(cfg, SD3Pipeline(tr, vae, device), SyntheticData(resolution=cfg.resolution, device=device), scorer, None, 0, 1, log_path=None)
 
 
@@ -49,7 +59,19 @@ def summarise(tag):
 
 trainer.run_epoch()
 stats("after warm-up epoch")
-for rep in range(2):
+if len(sys.argv) > 1:          # pre-heat: N more sampling phases (sustained rollout load, ~0.8 s each) before the measurements
+    for _ in range(int(sys.argv[1])):
+        trainer.sample_epoch()
+    torch.cuda.synchronize()
+    print("pre-heated with", sys.argv[1], "sampling phases")
+if os.environ.get("PROBE_RUN_EPOCH"):
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        trainer.run_epoch()
+        torch.cuda.synchronize()
+        summarise(f"run_epoch {rep} ({time.perf_counter() - t0:.3f} s):")
+for rep in range(1):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     samples = trainer.sample_epoch()

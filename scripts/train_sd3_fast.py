@@ -12,6 +12,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")    # before the HIP runtime starts (adv_grpo_amd/__init__.py: stream -> hardware queue map)
 import torch  # noqa: E402
 
 

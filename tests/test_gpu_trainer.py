@@ -465,3 +465,63 @@ def test_full_size_epoch_config4(tmp_path):
                                                 ("reward_avg", "zero_std_ratio", "reward_std_mean"))
     step_rec = next(r for r in recs if "approx_kl" in r)
     assert 0.0 <= step_rec["approx_kl"] < 1e-8 and torch.isfinite(torch.tensor(float(step_rec["loss"]))), step_rec
+
+
+def test_full_size_epoch_config3(tmp_path):
+    """BASELINE config 3 at FULL size on one rank: the adversarial loop the reference is named after (TD:156-232,1091-1115) --
+    `dino_cotrain_sd3_patch_fast`, SD3.5-medium (24 blocks) 512^2, 10 steps, G = 8, reward = the co-trained DINOv2 ViT-B/14 @ 518
+    patch discriminator + head (RW:375-434) -- one D epoch ((0 + 1) % d_times != 0: train_dino on 16 reference + 16 generated
+    images, hinge on CLS + 0.3 x hinge on 64 patches, Adam on the head) then one G epoch ((1 + 1) % 2 == 0).  Properties: the
+    property set of test_full_size_epoch_config2 for the G epoch; for the D epoch train/d_loss and train/acc are logged and finite,
+    the head moved and the LoRA did not; generated AND reference images are scored every epoch (reference_reward_avg)."""
+    import json
+    from adv_grpo_amd import synthetic, vit
+    from adv_grpo_amd.config.experiments import get_config
+    from adv_grpo_amd.d_step import DinoHeadTrainable
+    from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
+    from adv_grpo_amd.model_configs import DinoConfig, MMDiTConfig, VaeConfig
+    from adv_grpo_amd.pipeline import SD3Pipeline
+    from adv_grpo_amd.trainer import SyntheticData, Trainer
+    from adv_grpo_amd.vae import AutoencoderKLDecoder
+    cfg = get_config("dino_cotrain_sd3_patch_fast", gpu_number=1)
+    cfg.sample.num_image_per_prompt = 8
+    cfg.sample.num_batches_per_epoch = 2
+    cfg.train.gradient_accumulation_steps = 1
+    cfg.d_times = 2
+    mcfg, dcfg = MMDiTConfig(), DinoConfig()
+    with synthetic.on_device("cuda"):
+        tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, "cuda", seed=cfg.seed)
+        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321), VaeConfig(), "cuda")
+        scorer = vit.DinoV2(synthetic.dino_weights(dcfg, 888), dcfg, "cuda")
+    head = DinoHeadTrainable(device="cuda", seed=0)
+    log = tmp_path / "metrics.jsonl"
+    trainer = Trainer(cfg, SD3Pipeline(tr, vae, "cuda"), SyntheticData(resolution=cfg.resolution, device="cuda"), scorer, head, 0, 1,
+                      log_path=str(log))
+    assert trainer.needs_reference and trainer.variant == "dino"
+    p0, h0 = tr.params.clone(), head.params.clone()
+    a = trainer.run_epoch()
+    torch.cuda.synchronize()
+    assert a["phase"] == "D" and torch.isfinite(torch.tensor(float(a["train/d_loss"]))) and 0.0 <= float(a["train/acc"]) <= 1.0
+    assert not torch.equal(head.params, h0) and torch.isfinite(head.params).all() and torch.equal(tr.params, p0)
+    h1 = head.params.clone()
+    b = trainer.run_epoch()
+    torch.cuda.synchronize()
+    print(f"config 3 epochs: phases {trainer.timers}, d_loss {float(a['train/d_loss']):.4f}, acc {float(a['train/acc']):.3f}, "
+          f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    assert b["phase"] == "G" and trainer.epoch == 2
+    assert torch.isfinite(tr.params).all() and not torch.equal(tr.params, p0) and (tr.grads == 0).all() and torch.equal(head.params, h1)
+    recs = [json.loads(l) for l in open(log)]
+    ep = [r for r in recs if "reward_avg" in r]
+    assert len(ep) == 2
+    for r in ep:
+        for k in ("reward_avg", "reference_reward_avg", "zero_std_ratio", "reward_std_mean", "group_size", "trained_prompt_num"):
+            assert k in r and torch.isfinite(torch.tensor(float(r[k]))), (k, r)
+        assert r["group_size"] == 8
+    assert [r["trained_prompt_num"] for r in ep] == [2, 4]            # distinct prompts seen so far (stat_tracking.py:73-76)
+    d_rec = next(r for r in recs if "train/d_loss" in r)
+    assert torch.isfinite(torch.tensor(float(d_rec["train/d_loss"]))) and "train/acc" in d_rec
+    steps = [r for r in recs if "approx_kl" in r]
+    assert len(steps) == 2
+    assert 0.0 <= steps[0]["approx_kl"] < 1e-8, steps[0]                  # update 0: ratio == 1 up to the bf16 cast of the latents
+    for k in ("loss", "policy_loss", "approx_kl", "clipfrac", "clipfrac_gt_one", "clipfrac_lt_one"):
+        assert all(torch.isfinite(torch.tensor(float(s[k]))) for s in steps), k
