@@ -72,10 +72,17 @@ __device__ __forceinline__ void x3_tie(bf16x8_t (&a)[N]) {
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a[i]));
 }
 
+// F16 (round 4, "f16x2"): the same kernel for weights that are EXACT in fp16 -- the released SD3 / SD3.5 VAE is stored in fp16
+// and only upcast by vae.to(torch.float32) (TP:481), so every weight is one 16-bit piece.  Activations then travel as fp16
+// hi = f16(v), lo = f16(v - hi) (22 significant bits: more than the 16 of the bf16 pair) in the same places of the same
+// [hi | unwritten | lo] rows, weights as ONE fp16 piece per tap ([Cout, 9 C], no hi / lo), and a product is x_hi w + x_lo w on
+// v_mfma_f32_16x16x32_f16: two MFMA products instead of three, half the weight bytes through L2 -> LDS (two thirds of this
+// kernel's bytes are weights), the same pipeline.  p.alpha undoes the power-of-two pre-scale of un-normalised inputs (fp16 range).
 // DBG (experiments build only, scripts/probes/x3_decompose.sh): 1 = no DMA after the prologue, 2 = no MFMAs, 3 = fragments read
 // once -- WRONG results, used to price the three activities of the k loop against each other
-template <int X3_WM, int X3_WN, int DBG = 0>
+template <int X3_WM, int X3_WN, int DBG = 0, bool F16 = false>
 __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const GemmParams p) {
+    constexpr int WPI = F16 ? 1 : 2;                  // weight pieces per tap (DMA instructions per 8 output channels)
     constexpr int NW = X3_WM * X3_WN, TM = X3_BM / X3_WM, TN = X3_BN / X3_WN, FM = TM / 16, FN = TN / 16;
     constexpr int XI = (X3_XINST + NW - 1) / NW;     // pixel-piece DMA instructions per wave (the last one on some waves only)
     constexpr int WI = X3_BN / 8 / NW;               // weight-piece DMA instructions per wave
@@ -138,9 +145,9 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
 #pragma unroll
         for (int it = 0; it < WI; ++it) {
             char* dst = base + (wave + it * NW) * 1024;
-            const bf16_t* wh = w_src[it] + (int64_t)tap * p.Cin + c0;         // per tap [hi | lo | hi]
+            const bf16_t* wh = w_src[it] + (int64_t)tap * (F16 ? C : p.Cin) + c0;   // per tap [hi | lo | hi]; F16: one piece per tap
             __builtin_amdgcn_global_load_lds((x3_gptr_t)wh, (x3_lds_ptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((x3_gptr_t)(wh + C), (x3_lds_ptr_t)(dst + X3_WPIECE), 16, 0, 0);
+            if constexpr (!F16) __builtin_amdgcn_global_load_lds((x3_gptr_t)(wh + C), (x3_lds_ptr_t)(dst + X3_WPIECE), 16, 0, 0);
         }
     };
 
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
     stage_x(0);
     stage_w(0, 0, 0);
     stage_w(1, 0, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * WI) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WPI * WI) : "memory");
     __builtin_amdgcn_s_barrier();
     static_assert(FM + FN <= 15 && 3 * FN <= 15, "lgkmcnt counts at most 15 reads in flight");
     auto product = [&](const bf16x8_t (&a)[FM], const bf16x8_t (&b)[FN]) __attribute__((always_inline)) {
@@ -187,7 +194,15 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FN; ++j) {
+                    if constexpr (F16) {
+                        typedef _Float16 x3_f16x8 __attribute__((ext_vector_type(8)));
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(x3_f16x8, b[j]), __builtin_bit_cast(x3_f16x8, a[i]),
+                                                                           acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                    }
+                }
         } else {
             acc[0][0] += __builtin_bit_cast(f32x4, a[0]) + __builtin_bit_cast(f32x4, b[FN - 1]);
         }
@@ -229,7 +244,53 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
             bf16x8_t ah0[FM], al0[FM], bh0[FN], bl0[FN], ah1[FM], al1[FM], bh1[FN], bl1[FN];
             const bool more = kt + 2 < nk;                   // (then group g + 1 exists as well when dxi == 2)
             const bool rd = DBG != 3 || kt == 0;
-            if constexpr (dxi < 2) {
+            if constexpr (F16 && dxi < 2) {
+                // one weight piece: per 32-deep step x_hi (FM reads), w (FN), x_lo (FM); products x_hi w, x_lo w
+                if (rd) { read_x(xa[dxi][0], ah0, al0, true, false); read_wh(wb0, bh0); read_x(xa[dxi][0], ah0, al0, false, true); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && DBG != 1) stage_w((dxi + 2) % 3, dxi == 0 ? g : g + 1, (dxi + 2) % 3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) { x3_wait_reads<FM>(); x3_tie(ah0); x3_tie(bh0); }
+                mask(ah0);
+                product(ah0, bh0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) { read_x(xa[dxi][1], ah1, al1, true, false); read_wh(wb1, bh1); }
+                if (rd) { x3_wait_reads<FM + FN>(); x3_tie(al0); }
+                mask(al0);
+                product(al0, bh0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) { read_x(xa[dxi][1], ah1, al1, false, true); }
+                if (rd) { x3_wait_reads<FM>(); x3_tie(ah1); x3_tie(bh1); }
+                mask(ah1);
+                product(ah1, bh1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) { x3_wait_reads<0>(); x3_tie(al1); }
+                mask(al1);
+                product(al1, bh1);
+            } else if constexpr (F16) {
+                // last tap of a group (see below): all twelve pixel reads, barrier, the next group's pixel stage, then the weights
+                if (rd) { read_x(xa[dxi][0], ah0, al0, true, true); read_x(xa[dxi][1], ah1, al1, true, true); }
+                if (rd) { x3_wait_reads<0>(); x3_tie(ah0); x3_tie(al0); x3_tie(ah1); x3_tie(al1); }
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < ngroups && DBG != 1) {
+                    stage_x(g + 1);
+                    stage_w(1, g + 1, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) { read_wh(wb0, bh0); read_wh(wb1, bh1); }
+                if (rd) { x3_wait_reads<FN>(); x3_tie(bh0); }
+                mask(ah0);
+                product(ah0, bh0);
+                mask(al0);
+                product(al0, bh0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) { x3_wait_reads<0>(); x3_tie(bh1); }
+                mask(ah1);
+                product(ah1, bh1);
+                mask(al1);
+                product(al1, bh1);
+            } else if constexpr (dxi < 2) {
                 // reads in the order the products need them, seven at a time, the next seven requested before the wait that
                 // releases the previous ones; the weights of k-tile kt + 2 go into the slot k-tile kt - 1 read
                 if (rd) { read_x(xa[dxi][0], ah0, al0, true, false); read_wl(wb0, bl0); }
@@ -290,7 +351,7 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
                 product(ah1, bh1);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * WI) : "memory");
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WPI * WI) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         });
@@ -299,6 +360,23 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
 }
 
 }  // namespace
+
+// fp16 pair activations x one-piece fp16 weights: p as filled by advgrpo_conv3x3_nhwc_f16x2 (Cin = 3C, lda = 3C, ldw = 9C, f32_io)
+int conv3x3_f16x2_launch(const GemmParams& p, hipStream_t s) {
+    ADVGRPO_CHECK(p.conv && p.f32_io && p.Cin % 192 == 0 && p.zero_page && p.batch == 1 && p.splitk == 1, "conv3x3_f16x2: bad parameter block");
+    constexpr int WM = X3_GRID_M, WN = X3_GRID_N;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ADVGRPO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<WM, WN, 0, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) == hipSuccess,
+                      "conv3x3_f16x2: %d bytes of LDS refused", X3_LDS);
+        attr_set = true;
+    }
+    const int tiles = ((p.M + X3_BM - 1) / X3_BM) * ((p.N + X3_BN - 1) / X3_BN);
+    hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, true>), dim3(tiles), dim3(64 * WM * WN), X3_LDS, s, p);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
 
 // p as filled by advgrpo_conv3x3_nhwc_x3 (gemm.hip): Cin = 3C, K = 9 * 3C, lda = 3C, ldw = 27C, f32_io
 int conv3x3_x3_launch(const GemmParams& p, hipStream_t s) {

@@ -393,7 +393,7 @@ __device__ __forceinline__ void gemm_epilogue_f32io(const GemmParams& p, f32x4 (
         const int n = n0 + wn * TN + j * 16 + ncol;
         if (m >= p.M || n >= p.N) return;
         const f32x4 a4 = acc[i][j];
-        float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+        float v[4] = {a4[0] * p.alpha, a4[1] * p.alpha, a4[2] * p.alpha, a4[3] * p.alpha};    // (alpha = 1 everywhere but the f16x2 convolutions)
         if (vec_ok) {
             if (bias) {
                 const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
@@ -444,8 +444,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // instead of as a second, badly filled launch (M = 16 x 205 rows against 256 CUs x 2 workgroups).
 struct GemmPair { GemmParams a, b; int tiles_a; };
 
-// split-bf16 3x3 convolution of the fp32-equivalent VAE decode (conv_x3.hip)
+// split-bf16 3x3 convolution of the fp32-equivalent VAE decode (conv_x3.hip); fp16-pair activations x fp16 weights
 int conv3x3_x3_launch(const GemmParams& p, hipStream_t s);
+int conv3x3_f16x2_launch(const GemmParams& p, hipStream_t s);
 
 // 256x256 eight-phase kernel (gemm8p.hip)
 bool gemm8p_ok(const GemmParams& p);

@@ -60,6 +60,22 @@ __device__ inline void split8(const float v[8], uint4& hi, uint4& lo) {
     lo = pack8v(l);
 }
 
+// fp16 pair ("f16x2", conv_x3.hip F16): hi = f16(s v), lo = f16(s v - hi) with a power-of-two pre-scale s that keeps un-normalised
+// activations inside the fp16 range (the convolution's alpha = 1 / s undoes it exactly); 22 significant bits
+__device__ inline void split8_f16(const float v[8], float prescale, uint4& hi, uint4& lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        const float a = v[k] * prescale, b = v[k + 1] * prescale;
+        const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+        const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
+        h[k >> 1] = (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
+        l[k >> 1] = (uint32_t)__builtin_bit_cast(uint16_t, la) | ((uint32_t)__builtin_bit_cast(uint16_t, lb) << 16);
+    }
+    hi = uint4{h[0], h[1], h[2], h[3]};
+    lo = uint4{l[0], l[1], l[2], l[3]};
+}
+
 // Deterministic: every sum is formed in a fixed order (per thread over its pixels, per block over its threads through LDS,
 // per image over the blocks in groupnorm_finalize_kernel) -- with float / f64 atomics the statistics differed in the last
 // bit from run to run, and 30 layers of a decoder amplify that to the bf16 level (two decodes of the same latents differed by
@@ -146,7 +162,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restrict__ x, bf16_t* __restrict__ y,
                                                               const float* __restrict__ mr,
                                                               const T* __restrict__ w, const T* __restrict__ bb,
-                                                              int HW, int C, int G, int silu, int pair_only, int64_t total8) {
+                                                              int HW, int C, int G, int silu, int pair_only, int64_t total8,
+                                                              float prescale = 1.0f) {
     const int c8n = C >> 3, cpg = C / G;
     auto finish = [&](int64_t i, float (&v)[8]) __attribute__((always_inline)) {
         const int slice = i % c8n;
@@ -171,7 +188,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
             *reinterpret_cast<uint4*>(y + i * 8) = pack8v(v);
         } else {
             uint4 hi, lo;
-            split8(v, hi, lo);
+            if (pair_only == 2) split8_f16(v, prescale, hi, lo);     // fp16 pair [hi | unwritten | lo]
+            else split8(v, hi, lo);
             bf16_t* row = y + pix * 3 * C + slice * 8;
             *reinterpret_cast<uint4*>(row) = hi;
             if (!pair_only) *reinterpret_cast<uint4*>(row + C) = hi;
@@ -194,7 +212,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
 // (right operand: weights), 2 = [hi | unwritten | lo] (activations of the dedicated 3x3 kernel, conv_x3.hip, which reads the hi
 // and lo thirds only)
 __global__ __launch_bounds__(256) void split_x3_kernel(const float* __restrict__ x, const float* __restrict__ bias,
-                                                       bf16_t* __restrict__ out, int K, int order, int64_t total8) {
+                                                       bf16_t* __restrict__ out, int K, int order, int64_t total8, float prescale = 1.0f) {
     const int k8n = K >> 3;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
         const int slice = i % k8n;
@@ -208,10 +226,11 @@ __global__ __launch_bounds__(256) void split_x3_kernel(const float* __restrict__
             for (int k = 0; k < 8; ++k) v[k] += b8[k];
         }
         uint4 hi, lo;
-        split8(v, hi, lo);
+        if (order == 3) split8_f16(v, prescale, hi, lo);             // fp16 pair [hi | unwritten | lo]
+        else split8(v, hi, lo);
         bf16_t* row = out + r * 3 * K + slice * 8;
         *reinterpret_cast<uint4*>(row) = hi;
-        if (order != 2) *reinterpret_cast<uint4*>(row + K) = order ? lo : hi;
+        if (order < 2) *reinterpret_cast<uint4*>(row + K) = order ? lo : hi;
         *reinterpret_cast<uint4*>(row + 2 * K) = order == 1 ? hi : lo;
     }
 }
@@ -409,6 +428,38 @@ extern "C" int advgrpo_groupnorm_nhwc_x3(const float* x, void* y3, double* stats
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(groupnorm_apply_kernel<float>, dim3((int)blocks), dim3(256), 0, s, x, (bf16_t*)y3, mr, weight, bias,
                        HW, C, G, silu, pair_only, total8);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_groupnorm_nhwc_f16x2(const float* x, void* y3, double* stats, const float* weight, const float* bias,
+                                            int B, int HW, int C, int G, float eps, int silu, float prescale, void* stream) {
+    ADVGRPO_CHECK(x && y3 && stats && weight && bias, "groupnorm_f16x2: null pointer");
+    ADVGRPO_CHECK(B > 0 && HW > 0 && C % 8 == 0 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 4 == 0 && 256 % (C / 8) == 0,
+                  "groupnorm_f16x2: unsupported shape C=%d G=%d", C, G);
+    hipStream_t s = as_stream(stream);
+    const int ppb = advgrpo_groupnorm_ppb(HW), nchunks = (HW + ppb - 1) / ppb;
+    hipLaunchKernelGGL(groupnorm_stats_kernel<float>, dim3(nchunks, B), dim3(256), 0, s, x, stats, HW, C, G, ppb);
+    ADVGRPO_LAUNCH_CHECK();
+    float* mr = reinterpret_cast<float*>(stats + (size_t)B * nchunks * G * 2);
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(B * G), dim3(64), 0, s, stats, mr, B, G, nchunks,
+                       (double)HW * (C / G), eps);
+    ADVGRPO_LAUNCH_CHECK();
+    const int64_t total8 = (int64_t)B * HW * (C / 8);
+    int64_t blocks = (total8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(groupnorm_apply_kernel<float>, dim3((int)blocks), dim3(256), 0, s, x, (bf16_t*)y3, mr, weight, bias,
+                       HW, C, G, silu, 2, total8, prescale);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_split_f16x2(const float* x, const float* bias, void* out, int64_t rows, int K, float prescale, void* stream) {
+    ADVGRPO_CHECK(x && out && rows > 0 && K > 0 && K % 8 == 0, "split_f16x2: need K %% 8 == 0 (K=%d)", K);
+    const int64_t total8 = rows * (K / 8);
+    int64_t blocks = (total8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(split_x3_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, bias, (bf16_t*)out, K, 3, total8, prescale);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

@@ -534,6 +534,46 @@ def groupnorm_nhwc_x3(x, weight, bias, groups=32, eps=1e-6, silu=False, pair_onl
     return y
 
 
+# ---- "f16x2": fp16-exact decoder weights (include/advgrpo.h) -- fp16 pair activations, one-piece fp16 weights, two products
+def split_f16x2(x, prescale=1.0, bias=None):
+    """f32 [..., K] (+ bias[K]) -> [..., 3K] 16-bit: thirds [f16 hi | unwritten | f16 lo] of prescale * x (prescale: a power of two)."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    K = x.shape[-1]
+    out = torch.empty(*x.shape[:-1], 3 * K, dtype=torch.bfloat16, device=x.device)      # (16-bit container; the values are fp16)
+    _lib.check(lib.advgrpo_split_f16x2(x.data_ptr(), _lib.ptr(bias), out.data_ptr(), x.numel() // K, K, float(prescale), _lib.stream_ptr()))
+    return out
+
+
+def groupnorm_nhwc_f16x2(x, weight, bias, groups=32, eps=1e-6, silu=False, prescale=1.0):
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and weight.dtype == torch.float32
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    y = torch.empty(*x.shape[:-1], 3 * C, dtype=torch.bfloat16, device=x.device)
+    stats = torch.empty(lib.advgrpo_groupnorm_scratch_bytes(B, HW, groups) // 8, dtype=torch.float64, device=x.device)
+    _lib.check(lib.advgrpo_groupnorm_nhwc_f16x2(x.data_ptr(), y.data_ptr(), stats.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), B, HW, C,
+                                                groups, float(eps), int(silu), float(prescale), _lib.stream_ptr()))
+    return y
+
+
+def conv3x3_f16x2(x2, w16, bias=None, upsample=False, act=None, residual=None, alpha=1.0):
+    """x2 NHWC fp16-pair rows [B,Hin,Win,3C]; w16 [Cout, 9C] fp16 (k = (ky*3+kx)*C + c); bias / residual f32 -> f32 [B,Hout,Wout,Cout]."""
+    lib = _lib.load()
+    B, Hin, Win, Cin3 = x2.shape
+    Cout = w16.shape[0]
+    assert w16.dtype == torch.float16 and w16.is_contiguous() and w16.shape[1] == 3 * Cin3
+    Hout, Wout = (Hin * 2, Win * 2) if upsample else (Hin, Win)
+    assert bias is None or bias.dtype == torch.float32
+    assert residual is None or (residual.dtype == torch.float32 and residual.is_contiguous())
+    y = torch.empty(B, Hout, Wout, Cout, dtype=torch.float32, device=x2.device)
+    with _Prof(B * Hout * Wout, Cout, 2 * 3 * Cin3, 1, 1):                # two products per tap over C channels: K_eff = 2 x 9 C
+        _lib.check(lib.advgrpo_conv3x3_nhwc_f16x2(_lib.ptr(x2), _lib.ptr(w16), y.data_ptr(), B, Hout, Wout, Cin3, Cout, int(upsample),
+                                                  _lib.ptr(bias), ACT[act], _lib.ptr(residual), zero_page(x2.device).data_ptr(),
+                                                  float(alpha), _lib.stream_ptr()))
+    return y
+
+
 def softmax_rows_x3(s):
     """f32 [..., n] -> softmax rows as split bf16 [..., 3n]."""
     lib = _lib.load()

@@ -151,8 +151,10 @@ def norm_(W, name, c, g):
     W[name + ".bias"] = 0.1 * _randn(c, generator=g)
 
 
-def vae_decoder_weights(cfg, seed=4321):
-    """fp32 CPU weights keyed like diffusers AutoencoderKL.state_dict() (decoder.* only)."""
+def vae_decoder_weights(cfg, seed=4321, fp16_checkpoint=False):
+    """fp32 CPU weights keyed like diffusers AutoencoderKL.state_dict() (decoder.* only).  fp16_checkpoint: every tensor rounded
+    to fp16 and upcast again -- what the reference holds after loading the released fp16 VAE checkpoint and vae.to(float32)
+    (TP:447,481); such weights are exact in one 16-bit piece (the decoder's f16x2 path, adv_grpo_amd/vae.py)."""
     g = _gen(seed)
     W = {}
     ch = list(reversed(cfg.block_out_channels))          # 512, 512, 256, 128
@@ -178,6 +180,8 @@ def vae_decoder_weights(cfg, seed=4321):
             conv_(W, f"decoder.up_blocks.{i}.upsamplers.0.conv", co, co, 3, g)
     norm_(W, "decoder.conv_norm_out", ch[-1], g)
     conv_(W, "decoder.conv_out", 3, ch[-1], 3, g)
+    if fp16_checkpoint:
+        W = {k: v.half().float() for k, v in W.items()}
     return W
 
 

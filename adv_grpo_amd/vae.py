@@ -27,10 +27,13 @@ from . import ops
 
 
 class AutoencoderKLDecoder:
-    def __init__(self, state_dict, cfg, device="cuda", mode="bf16x3"):
+    def __init__(self, state_dict, cfg, device="cuda", mode="bf16x3", f16_weights=True):
+        """f16_weights (bf16x3 mode): run a 3x3 convolution whose weight tensor is EXACT in fp16 on the two-product f16x2 kernel
+        (decided per tensor at load time; False: always the three split-bf16 products)."""
         if mode not in ("bf16", "bf16x3"):
             raise ValueError(f"AutoencoderKLDecoder: mode must be 'bf16' or 'bf16x3', got {mode!r}")
         self.mode = mode
+        self.f16_weights = bool(f16_weights)
         self.cfg = cfg
         self.config = type("Cfg", (), {"scaling_factor": cfg.scaling_factor, "shift_factor": cfg.shift_factor})()
         self.dtype = torch.float32          # what the reference's vae.dtype says (PF:668 casts latents to it)
@@ -99,6 +102,11 @@ class AutoencoderKLDecoder:
             if v.dim() == 4 and v.shape[-1] == 3:       # conv3x3 [Co,Ci,3,3] -> [Co, 9, Ci] -> split along Ci
                 v = f32(v)
                 co, ci = v.shape[:2]
+                # a weight that is exact in fp16 (the released SD3 / SD3.5 VAE is an fp16 checkpoint, upcast at TP:481) goes to the
+                # two-product kernel as ONE fp16 piece (include/advgrpo.h "f16x2"); anything else keeps the three bf16 products
+                if self.f16_weights and co >= 128 and ci % 64 == 0 and torch.equal(v.half().float(), v):
+                    w[k + "@f16"] = v.permute(0, 2, 3, 1).contiguous().half().reshape(co, -1)
+                    continue
                 if ci % 64:
                     v = torch.cat([v, torch.zeros(co, 64 - ci % 64, 3, 3, dtype=v.dtype, device=v.device)], dim=1)
                 w[k] = ops.split_x3(v.permute(0, 2, 3, 1).contiguous(), order=1).reshape(co, -1)
@@ -115,19 +123,33 @@ class AutoencoderKLDecoder:
     def _conv3(self, name, x3, **kw):
         return ops.conv3x3_x3(x3, self.w[name + ".weight"], bias=self.w[name + ".bias"], **kw)
 
+    RAW_PRESCALE = 2.0 ** -4         # un-normalised conv inputs (the upsamplers') as fp16 pairs: |x| up to 1e6 stays in range
+
+    def _conv_auto(self, name, x, gn=None, **kw):
+        """3x3 convolution of f32 NHWC `x` (after GroupNorm `gn` + SiLU when given) in whichever arithmetic its weight allows:
+        fp16-exact weight -> fp16-pair activations, two products (f16x2); otherwise split-bf16, three products."""
+        w = self.w
+        if name + ".weight@f16" in w:
+            if gn is not None:
+                a = ops.groupnorm_nhwc_f16x2(x, w[gn + ".weight"], w[gn + ".bias"], self.G, 1e-6, True)
+                return ops.conv3x3_f16x2(a, w[name + ".weight@f16"], bias=w[name + ".bias"], **kw)
+            a = ops.split_f16x2(x, prescale=self.RAW_PRESCALE)
+            return ops.conv3x3_f16x2(a, w[name + ".weight@f16"], bias=w[name + ".bias"], alpha=1.0 / self.RAW_PRESCALE, **kw)
+        wide = w[name + ".weight"].shape[0] >= 128      # >= 128 output channels: the kernel that reads the hi and lo thirds only
+        a = self._gn3(gn, x, True, pair_only=wide) if gn is not None else ops.split_x3(x, order=2 if wide else 0)
+        return self._conv3(name, a, **kw)
+
     def _gn3(self, name, x, silu, pair_only=False):
         return ops.groupnorm_nhwc_x3(x, self.w[name + ".weight"], self.w[name + ".bias"], self.G, 1e-6, silu, pair_only)
 
     def _res3(self, p, x):
-        # a convolution with >= 128 output channels runs on the kernel that reads the hi and lo thirds only
-        po = lambda name: self.w[name + ".weight"].shape[0] >= 128
-        h = self._conv3(f"{p}.conv1", self._gn3(f"{p}.norm1", x, True, pair_only=po(f"{p}.conv1")))
+        h = self._conv_auto(f"{p}.conv1", x, gn=f"{p}.norm1")
         sc = x
         if f"{p}.conv_shortcut.weight" in self.w:
             B, H, W, C = x.shape
             sc = ops.gemm(ops.split_x3(x).view(-1, 3 * C), self.w[f"{p}.conv_shortcut.weight"], out_dtype=torch.float32
                           ).view(B, H, W, -1)
-        return self._conv3(f"{p}.conv2", self._gn3(f"{p}.norm2", h, True, pair_only=po(f"{p}.conv2")), residual=sc)
+        return self._conv_auto(f"{p}.conv2", h, gn=f"{p}.norm2", residual=sc)
 
     def _attn3(self, p, x):
         B, H, W, C = x.shape
@@ -159,8 +181,7 @@ class AutoencoderKLDecoder:
             for j in range(cfg.layers_per_block + 1):
                 x = self._res3(f"decoder.up_blocks.{i}.resnets.{j}", x)
             if i < n - 1:
-                name = f"decoder.up_blocks.{i}.upsamplers.0.conv"
-                x = self._conv3(name, ops.split_x3(x, order=2 if self.w[name + ".weight"].shape[0] >= 128 else 0), upsample=True)
+                x = self._conv_auto(f"decoder.up_blocks.{i}.upsamplers.0.conv", x, upsample=True)
         y = self._conv3("decoder.conv_out", self._gn3("decoder.conv_norm_out", x, True))
         return ops.image_postprocess(y)
 

@@ -118,7 +118,7 @@ def build_c5(device, vae_mode="bf16x3"):
     qcfg, vcfg, dcfg = QwenMMDiTConfig(), VaeConfig(), DinoConfig()
     with synthetic.on_device(device):
         tr = QwenImageTransformer2DModel(synthetic.qwen_mmdit_weights(qcfg, 4242, dtype=torch.bfloat16), qcfg, device)
-        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(vcfg, 4321), vcfg, device, mode=vae_mode)
+        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(vcfg, 4321, fp16_checkpoint=True), vcfg, device, mode=vae_mode)
         dino = vit.DinoV2(synthetic.dino_weights(dcfg, 888), dcfg, device)
         head = vit.DinoHead(synthetic.dino_head_weights(dcfg.hidden, 512, 999), device)
     tr.enable_fp8()
@@ -136,7 +136,7 @@ def build(device, large=False, vae_mode="bf16x3"):
         mcfg = MMDiTConfig(num_layers=38, num_heads=38, dual_attention_layers=(), pos_embed_max_size=192)
     with synthetic.on_device(device):
         tr = SD3Transformer2DModel(synthetic.mmdit_weights(mcfg, 1234), mcfg, device)
-        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(vcfg, 4321), vcfg, device, mode=vae_mode)
+        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(vcfg, 4321, fp16_checkpoint=True), vcfg, device, mode=vae_mode)
         # config 2's reward is the co-trained bf16 scorer (TP:514); config 4's `pickscore` reward is the fp32 scorer of the
         # reward factory (RW:561-574): the fp32-equivalent split-bf16 towers
         from adv_grpo_amd import vit_x3
@@ -192,7 +192,7 @@ def full_epoch(device, world=1, rank=0, adversarial=False):
     head = None
     with synthetic.on_device(device):
         tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, device, seed=cfg.seed)
-        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321), VaeConfig(), device)
+        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321, fp16_checkpoint=True), VaeConfig(), device)
         if adversarial:
             from adv_grpo_amd import vit
             from adv_grpo_amd.d_step import DinoHeadTrainable
@@ -545,7 +545,7 @@ def main():
                 dec = pipe.vae
             else:
                 with synthetic.on_device(device):
-                    dec = AutoencoderKLDecoder(synthetic.vae_decoder_weights(pipe.vae.cfg, 4321), pipe.vae.cfg, device, mode=mode)
+                    dec = AutoencoderKLDecoder(synthetic.vae_decoder_weights(pipe.vae.cfg, 4321, fp16_checkpoint=True), pipe.vae.cfg, device, mode=mode)
             dec.decode_to_image(lat)
             torch.cuda.synchronize()
             tv = time.perf_counter()

@@ -261,6 +261,20 @@ int advgrpo_split_bf16x3(const float* x, const float* bias, void* out, int64_t r
 int advgrpo_conv3x3_nhwc_x3(const void* x3, const void* w3, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
                             int upsample, const float* bias, int act, const float* residual, const void* zero_page,
                             void* stream);
+/* ---- "f16x2": the same fp32-equivalent decode for decoder weights that are EXACT in fp16 -- the released SD3 / SD3.5 VAE is
+ * stored in fp16 and only upcast by vae.to(torch.float32) (train_sd3_fast_pickscore.py:481).  A 3x3 convolution with such a
+ * weight needs two MFMA products, x_hi w + x_lo w on v_mfma_f32_16x16x32_f16, instead of three: activations travel as the fp16
+ * pair hi = f16(s v), lo = f16(s v - hi) (22 significant bits) in the thirds [hi | unwritten | lo] of a [.., 3C] row, weights as
+ * ONE fp16 piece [Cout, 9 C] (k = (ky*3+kx)*C + c); s = prescale is a power of two that keeps un-normalised activations inside
+ * the fp16 range, alpha = 1 / s multiplies the accumulators back (exact).  Everything between two products stays f32.
+ *   groupnorm_nhwc_f16x2 / split_f16x2: the producers (GroupNorm + SiLU of a resnet, the plain split in front of an upsampler);
+ *   conv3x3_nhwc_f16x2: Cout >= 128, bias / residual / y f32. */
+int advgrpo_groupnorm_nhwc_f16x2(const float* x, void* y3, double* stats, const float* weight, const float* bias, int B,
+                                 int HW, int C, int G, float eps, int silu, float prescale, void* stream);
+int advgrpo_split_f16x2(const float* x, const float* bias, void* out3, int64_t rows, int K, float prescale, void* stream);
+int advgrpo_conv3x3_nhwc_f16x2(const void* x2, const void* w16, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
+                               int upsample, const float* bias, int act, const float* residual, const void* zero_page,
+                               float alpha, void* stream);
 /* GroupNorm over f32 NHWC [B,HW,C], f32 affine (+ SiLU) -> split output [B,HW,3C]; stats scratch as above.
  * pair_only != 0 leaves the middle third unwritten (order 2 above: output consumed by the Cout >= 128 3x3 kernel only) */
 int advgrpo_groupnorm_nhwc_x3(const float* x, void* y3, double* stats, const float* weight, const float* bias, int B,

@@ -67,7 +67,7 @@ def main():
                                                                  dual_attention_layers=tuple(range(min(13, args.layers))))
     with synthetic.on_device(device):
         tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, device, seed=cfg.seed, lora_mode=args.lora_mode)
-        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321), VaeConfig(), device, mode=args.vae_mode)
+        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321, fp16_checkpoint=True), VaeConfig(), device, mode=args.vae_mode)
         head = None
         if any(k.startswith("dino") for k in cfg.reward_fn.keys()):
             scorer = vit.DinoV2(synthetic.dino_weights(DinoConfig(), 888), DinoConfig(), device)

@@ -299,3 +299,61 @@ def test_vae_decode_is_bitwise_reproducible():
         a = dec.decode_to_image(lat)
         b = dec.decode_to_image(lat)
         assert torch.equal(a, b), mode
+
+
+@pytest.mark.parametrize("B,H,W,C,Co,up,gn", [(2, 16, 24, 128, 128, False, True), (1, 33, 20, 256, 128, False, True),
+                                              (2, 8, 12, 512, 512, True, False), (1, 16, 16, 64, 256, False, False)])
+def test_conv3x3_f16x2_vs_fp64_conv(B, H, W, C, Co, up, gn):
+    """The two-product convolution for fp16-exact weights (include/advgrpo.h "f16x2"): fp16-pair activations (from the
+    GroupNorm + SiLU producer, or the plain split with the 2^-4 pre-scale of un-normalised inputs) x one-piece fp16 weights
+    against an fp64 convolution of the same f32 operands; the nearest x2 upsample folded in; activations of magnitude ~300 on
+    the raw path (fp16 range).  Error bound: the activations' 22-bit pairs, i.e. better than the split-bf16 kernel's 2^-16."""
+    from adv_grpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(H * 7 + C)
+    x = torch.randn(B, H, W, C, device="cuda", generator=g) * (1.0 if gn else 300.0)
+    wt = (torch.randn(Co, C, 3, 3, device="cuda", generator=g) / (C * 9) ** 0.5).half().float()      # fp16-exact
+    bias = torch.randn(Co, device="cuda", generator=g) * 0.1
+    w16 = wt.permute(0, 2, 3, 1).contiguous().half().reshape(Co, -1)
+    res = torch.randn(B, H * (2 if up else 1), W * (2 if up else 1), Co, device="cuda", generator=g)
+    if gn:
+        gw, gb = 1 + 0.1 * torch.randn(C, device="cuda", generator=g), 0.1 * torch.randn(C, device="cuda", generator=g)
+        a = ops.groupnorm_nhwc_f16x2(x, gw, gb, 32, 1e-6, True)
+        xin = torch.nn.functional.silu(torch.nn.functional.group_norm(x.permute(0, 3, 1, 2).double(), 32, gw.double(), gb.double(), 1e-6))
+        y = ops.conv3x3_f16x2(a, w16, bias=bias, upsample=up, residual=res)
+    else:
+        a = ops.split_f16x2(x, prescale=2.0 ** -4)
+        xin = x.permute(0, 3, 1, 2).double()
+        y = ops.conv3x3_f16x2(a, w16, bias=bias, upsample=up, residual=res, alpha=2.0 ** 4)
+    if up:
+        xin = torch.nn.functional.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = torch.nn.functional.conv2d(xin, wt.double(), bias.double(), padding=1).permute(0, 2, 3, 1) + res.double()
+    err = (y.double() - ref).abs().max().item() / ref.abs().max().item()
+    print("f16x2 conv rel max err", err)
+    assert err < 3e-6, err
+
+
+@pytest.mark.parametrize("B,hw", [(2, 16), (2, 64)])
+def test_vae_decode_f16x2_path_for_an_fp16_checkpoint(B, hw):
+    """The decoder on weights as the reference holds them -- the released fp16 VAE checkpoint upcast to fp32 (TP:447,481): every
+    3x3 convolution with >= 128 output channels takes the two-product f16x2 kernel (checked), the image stays within the bf16x3
+    mode's bound of the fp32 oracle decode, a weight set that is NOT exact in fp16 keeps the three-product kernels (checked), and
+    f16_weights=False on the fp16 checkpoint gives the three-product result within the same bound."""
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.vae import AutoencoderKLDecoder
+    from oracle import vae as o
+    cfg = o.VaeConfig()
+    W = synthetic.vae_decoder_weights(cfg, 99, fp16_checkpoint=True)
+    lat = torch.randn(B, 16, hw, hw, generator=torch.Generator().manual_seed(hw)).to(torch.bfloat16)
+    dec = AutoencoderKLDecoder(W, cfg, "cuda", mode="bf16x3")
+    n16 = sum(k.endswith("@f16") for k in dec.w)
+    assert n16 == 31, n16        # 2 x 14 resnets + 3 upsamplers: every 3x3 convolution but conv_in (16 input channels) and conv_out (3 outputs)
+    img = dec.decode_to_image(lat.cuda())
+    W32 = {k: v.float().cuda() for k, v in W.items()}
+    ref = o.postprocess(o.vae_decode(W32, cfg, lat.float().cuda() / cfg.scaling_factor + cfg.shift_factor))
+    err = (img - ref).abs()
+    print("vae f16x2 image err mean", err.mean().item(), "max", err.max().item(), "convolutions on the f16x2 kernel:", n16)
+    assert err.mean().item() < 2e-5 and err.max().item() < 1e-3
+    img3 = AutoencoderKLDecoder(W, cfg, "cuda", mode="bf16x3", f16_weights=False).decode_to_image(lat.cuda())
+    assert (img3 - ref).abs().mean().item() < 2e-5
+    dec_inexact = AutoencoderKLDecoder(synthetic.vae_decoder_weights(cfg, 99), cfg, "cuda", mode="bf16x3")
+    assert not any(k.endswith("@f16") for k in dec_inexact.w)
