@@ -48,10 +48,29 @@ class PickScoreScorer(torch.nn.Module):
             raise RuntimeError("string prompts need a tokenizer; pass input_ids [N,77] instead")
         return self.tokenizer(prompt, padding="max_length", truncation=True, max_length=77, return_tensors="pt").input_ids
 
+    def _text_features(self, prompt):
+        """The text tower on the UNIQUE prompts of the call.  A GRPO group scores G images of ONE prompt (TP:813-817 repeat the
+        prompt G times): when the prompts arrive as host strings (rewards.PromptBatch) equal strings are found on the host --
+        no device comparison, no synchronisation -- and the tower runs once per distinct prompt; every row of its GEMMs is
+        independent of the others, so the embeddings are bit for bit those of the full batch (tests/test_gpu_vit.py)."""
+        ids = self._ids(prompt)
+        if isinstance(prompt, (list, tuple)) and len(prompt) == ids.shape[0] and all(isinstance(t, str) for t in prompt):
+            first, inverse = {}, []
+            for i, t in enumerate(prompt):
+                inverse.append(first.setdefault(t, len(first)))
+            if len(first) < len(prompt):
+                rows = [0] * len(first)
+                for i, u in reversed(list(enumerate(inverse))):
+                    rows[u] = i
+                ids = ids.to(self.device)
+                uniq = self.model.get_text_features(ids.index_select(0, torch.tensor(rows, device=ids.device)))
+                return uniq.index_select(0, torch.tensor(inverse, device=uniq.device))
+        return self.model.get_text_features(ids)
+
     @torch.no_grad()
     def __call__(self, prompt, images):
         image_embs = self.model.get_image_features(images=self._images(images))
-        text_embs = self.model.get_text_features(self._ids(prompt))
+        text_embs = self._text_features(prompt)
         if self.dtype == torch.float32:
             return vit_x3.pickscore_scores_f32(image_embs, text_embs, self.model.logit_scale)
         return vit.pickscore_scores(image_embs, text_embs, self.model.logit_scale)

@@ -156,9 +156,11 @@ def pmc_traffic(kernel, config="c2"):
         if not os.path.exists(path):
             continue
         tot, n = 0.0, 0
+        fp8 = kernel.endswith("_fp8")                 # ops' name of the fp8 instantiations: gemm8p_kernel<PAIR, class, true>
+        base = kernel[:-4] if fp8 else kernel
         for name, v in json.load(open(path)).items():
             short = name.replace(" ", "").split("advgrpo::")[-1]
-            if short == kernel or short.startswith(kernel + "<"):        # all template instantiations of the kernel
+            if (short == base or short.startswith(base + "<")) and short.endswith(",true>") == fp8:   # all instantiations of that operand type
                 tot += v["hbm_bytes_per_launch"] * v["launches"]
                 n += v["launches"]
         if n:
@@ -448,7 +450,8 @@ def main():
                               for t in synthetic.prompt_embeddings(7 + rank, n_tokens=C5_TEXT_TOKENS, ctx_dim=3584, pooled_dim=8))
     else:
         pe, ppe, npe, nppe = (t.to(device=device, dtype=torch.bfloat16) for t in synthetic.prompt_embeddings(7 + rank))
-    ids = synthetic.clip_input_ids(G, 3 + rank).to(device)
+    # one prompt per group (TP:813-817 repeat the group's prompt G times): the scorers see G equal prompts
+    ids = synthetic.clip_input_ids(1, 3 + rank).repeat(G, 1).to(device)
 
     def step(it, exchange=True):
         sampler.set_epoch(it)
@@ -462,11 +465,11 @@ def main():
             scores, _ = dino_score(dino, dino_head, image.to(torch.bfloat16), None, None)
         elif c4:    # fp32 scorer (RW:561-574)
             from adv_grpo_amd import vit_x3
-            scores = vit_x3.pickscore_scores_f32(clip.get_image_features(images=image.to(torch.bfloat16)), clip.get_text_features(ids),    # (TP:816: images.to(bf16) before any reward fn)
+            scores = vit_x3.pickscore_scores_f32(clip.get_image_features(images=image.to(torch.bfloat16)), clip.get_text_features(ids[:1]).expand(G, -1).contiguous(),    # (TP:816: images.to(bf16) before any reward fn)
                                                  clip.logit_scale)
-        else:
+        else:       # (the text tower on the group's ONE distinct prompt, as PickScoreScorer does from the host strings)
             scores = vit.pickscore_scores(clip.get_image_features(images=image.to(torch.bfloat16)),
-                                          clip.get_text_features(ids), clip.logit_scale)
+                                          clip.get_text_features(ids[:1]).expand(G, -1).contiguous(), clip.logit_scale)
         rewards = scores.unsqueeze(1).repeat(1, T)                          # TP:926-928
         gids = torch.full((G,), prompt_idx, dtype=torch.int32, device=device)
         if not exchange:                                                    # (the solo leg of the scaling diagnostics below)

@@ -2,7 +2,7 @@
 # Re-takes every profiles/ artefact of a round on the GPU box (run through gpurun from the repo root):
 #   scripts/take_profiles.sh r3        -> gpurun_out/prof_r3/*  (copy the summaries into profiles/ afterwards: scripts/collect_profiles.py)
 set -x
-TAG=${1:-r3}
+TAG=${1:-r4}
 R=$PWD
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -11,6 +11,13 @@ FAST="--steps 3 --warmup 1 --no-epoch --no-cpu-baseline --no-pricing"
 # 1. driver-style lines
 python $R/bench.py --steps 5 --warmup 2 > $O/bench_c2.json 2> $O/bench_c2.err
 python $R/bench.py --config c4 --steps 3 --warmup 1 > $O/bench_c4.json 2> $O/bench_c4.err
+python $R/bench.py --config c3 --steps 5 --warmup 2 > $O/bench_c3.json 2> $O/bench_c3.err
+python $R/bench.py --config c5 --steps 3 --warmup 1 > $O/bench_c5.json 2> $O/bench_c5.err
+rocprofv3 --kernel-trace --stats -d $O/kt_c5 -o x -- python $R/bench.py --config c5 --steps 1 --warmup 1 --no-pricing > $O/bench_c5_prof.json 2>/dev/null
+python $R/scripts/rocpd_stats.py $O/kt_c5/x_results.db $O/kernel_stats_c5.md > /dev/null
+rocprofv3 --kernel-trace --stats -d $O/kt_c3 -o x -- python $R/bench.py --config c3 --steps 1 --warmup 1 --no-pricing > $O/bench_c3_prof.json 2>/dev/null
+python $R/scripts/rocpd_stats.py $O/kt_c3/x_results.db $O/kernel_stats_c3_with_epoch_legs.md > /dev/null
+python $R/scripts/bench_attention_d128.py 10 > $O/attention_d128.txt 2>/dev/null
 # 2. kernel tables: rollout (timed configuration only) and one G-step micro-batch
 rocprofv3 --kernel-trace --stats -d $O/kt_c2 -o x -- python $R/bench.py $FAST > $O/bench_c2_prof.json 2>/dev/null
 python $R/scripts/rocpd_stats.py $O/kt_c2/x_results.db $O/kernel_stats_c2.md > /dev/null
@@ -19,7 +26,7 @@ python $R/scripts/bench_gstep.py fp8 >> $O/gstep.txt 2>/dev/null
 rocprofv3 --kernel-trace --stats -d $O/kt_gstep -o x -- python $R/scripts/bench_gstep.py > $O/gstep_under_rocprof.txt 2>/dev/null
 python $R/scripts/rocpd_stats.py $O/kt_gstep/x_results.db $O/kernel_stats_gstep.md > /dev/null
 # 3. HBM-side traffic (separate passes, MI355X_MICROARCH "HBM"), per config
-for cfg in c2 c4; do
+for cfg in c2 c4 c5; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d $O/pmc_${cfg}_$c -o x -- python $R/bench.py --config $cfg --steps 1 --warmup 1 --no-epoch --no-cpu-baseline --no-pricing > /dev/null 2>&1
   done
@@ -29,5 +36,5 @@ done
 # 4. matrix-pipe busy share of the MFMA kernels
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY -d $O/pmc_mfma -o x -- python $R/bench.py --steps 1 --warmup 1 --no-epoch --no-cpu-baseline --no-pricing > /dev/null 2>&1
 python $R/scripts/pmc_db.py $O/pmc_mfma/x_results.db advgrpo > $O/pmc_mfma.txt
-rm -rf $O/kt_c2 $O/kt_gstep $O/pmc_c2* $O/pmc_c4_* $O/pmc_c4 $O/pmc_mfma
+rm -rf $O/kt_c2 $O/kt_c3 $O/kt_c5 $O/kt_gstep $O/pmc_c2* $O/pmc_c4_* $O/pmc_c4 $O/pmc_c5_* $O/pmc_c5 $O/pmc_mfma
 ls -la $O

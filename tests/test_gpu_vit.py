@@ -213,3 +213,29 @@ def test_dinov2_features_and_patch_head_vs_oracle():
     assert (cls.cpu() - rc.float()).abs().max().item() < 3e-2 * max(1.0, rc.float().abs().max().item())
     assert (hyb.cpu() - rh.float()).abs().max().item() < 3e-2 * max(1.0, rh.float().abs().max().item())
     assert (pat.cpu() - rp.float()).abs().max().item() < 5e-2 * max(1.0, rp.float().abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_pickscore_text_tower_runs_once_per_distinct_prompt(dtype):
+    """A GRPO group scores G images of ONE prompt: PickScoreScorer finds equal prompt STRINGS on the host (rewards.PromptBatch)
+    and runs the text tower on the distinct ones only -- scores bit-identical to the full batch, in both arithmetics, for one
+    repeated prompt and for a mixed batch (a, b, a, c, b, a)."""
+    from adv_grpo_amd import rewards, synthetic
+    from adv_grpo_amd.model_configs import ClipConfig
+    from adv_grpo_amd.pickscore_scorer import PickScoreScorer
+    cfg = ClipConfig(v_layers=2, t_layers=3)
+    W = synthetic.clip_weights(cfg, 5)
+    scorer = PickScoreScorer("cuda", dtype=dtype, model_sd=W, clip_cfg=cfg)
+    calls = []
+    full = scorer.model.get_text_features
+    scorer.model.get_text_features = lambda ids: (calls.append(ids.shape[0]), full(ids))[1]
+    imgs = torch.rand(6, 3, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    uniq_ids = synthetic.clip_input_ids(3, 9).cuda()
+    for texts, pick in ((["a"] * 6, [0] * 6), (["a", "b", "a", "c", "b", "a"], [0, 1, 0, 2, 1, 0])):
+        ids = uniq_ids[pick]
+        calls.clear()
+        s_dedup = scorer(rewards.PromptBatch(texts, clip_ids=ids), imgs)
+        assert calls == [len(set(texts))]
+        calls.clear()
+        s_full = scorer(ids, imgs)                       # bare ids: nothing to compare on the host, the whole batch runs
+        assert calls == [6] and torch.equal(s_dedup, s_full)
