@@ -126,6 +126,38 @@ class JsonlLogger:
             f.write(json.dumps(rec) + "\n")
 
 
+def write_eval_images(images, folder, rank, batch_idx, node_id=0, size=512):
+    """scripts/eval.py:258-266: [B,3,H,W] in [0,1] -> uint8 by truncation of x*255 (numpy astype) -> PIL resize to
+    512x512 (PIL's default filter) -> node<n>_rank<r>_<batch:05d>_<i>.png.  Returns the file names."""
+    from PIL import Image
+    import numpy as np
+    arr = (images.float().permute(0, 2, 3, 1).cpu().numpy() * 255).astype(np.uint8)
+    names = []
+    for i, a in enumerate(arr):
+        name = f"node{node_id}_rank{rank}_{batch_idx:05d}_{i}.png"
+        Image.fromarray(a).resize((size, size)).save(os.path.join(folder, name))
+        names.append(name)
+    return names
+
+
+def write_prompt2img(local, folder, world=1, rank=0):
+    """gather_dict + the rank-0 dump (scripts/eval.py:153-165,291-294): per-rank {prompt: [files]} maps merged in rank
+    order (lists of a prompt seen on several ranks concatenate), written as prompt2img.json (indent 2, non-ASCII kept)."""
+    gathered = [local]
+    if world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
+    merged = {}
+    for d in gathered:
+        for k, v in (d or {}).items():
+            merged.setdefault(k, []).extend(v)
+    if rank == 0:
+        with open(os.path.join(folder, "prompt2img.json"), "w", encoding="utf-8") as f:
+            json.dump(merged, f, indent=2, ensure_ascii=False)
+    return merged
+
+
 class Trainer:
     def __init__(self, config, pipeline, data, scorer, head=None, rank=0, world=1, log_path=None):
         """pipeline.transformer: SD3TransformerLoRA; scorer: PickScoreScorer (pickscore variants) or vit.DinoV2 (DINO
@@ -351,10 +383,14 @@ class Trainer:
 
     # ------------------------------------------------------------------ eval loop
     @torch.no_grad()
-    def evaluate(self, n_prompts=None, eval_reward_fn=None):
+    def evaluate(self, n_prompts=None, eval_reward_fn=None, save_folder=None):
         """eval() (TP:269-382): EMA weights swapped in, `eval_num_steps` deterministic steps (noise_level = 0), one image
         per prompt, initial latents from a CPU generator seeded with 0 for every batch (TP:298-299), rewards gathered
-        over ranks, means of the valid (!= -10) entries logged as eval_reward_<name> (TP:373-377)."""
+        over ranks, means of the valid (!= -10) entries logged as eval_reward_<name> (TP:373-377).
+
+        save_folder (scripts/eval.py:233-294): every image is also written as node0_rank<r>_<batch:05d>_<i>.png at 512x512
+        (uint8 truncation of x*255, PIL's default resize) and rank 0 writes prompt2img.json = {prompt: [file, ...]} merged
+        over ranks in rank order -- the file the trainers read back as `json_path`."""
         c = self.cfg
         model = self.pipe.transformer
         swapped = c.train.ema and getattr(model, "ema", None) is not None
@@ -367,7 +403,9 @@ class Trainer:
         bs = c.sample.test_batch_size
         n = n_prompts if n_prompts is not None else bs * self.world
         neg_pe, neg_ppe = self.data.neg
-        acc = {}
+        acc, prompt2files, batch_idx = {}, {}, 0
+        if save_folder is not None:
+            os.makedirs(save_folder, exist_ok=True)
         try:
             for start in range(self.rank * bs, n, bs * self.world):                         # test set sharded over ranks
                 idxs = list(range(start, min(start + bs, n)))
@@ -381,6 +419,11 @@ class Trainer:
                     height=c.resolution, width=c.resolution, noise_level=0, mini_num_image_per_prompt=1,
                     process_index=self.rank, sample_num_steps=c.sample.num_steps, random_timestep=c.sample.random_timestep,
                     generator=gen)                                                          # TP:303-320
+                if save_folder is not None:
+                    names = write_eval_images(images, save_folder, self.rank, batch_idx)    # eval.py:258-266
+                    for i, name in zip(idxs, names):
+                        prompt2files[self.data.prompt_text(i)] = [name]
+                batch_idx += 1
                 prompts = torch.cat([self.data.clip_ids(i, 1) for i in idxs])
                 ref = torch.cat([self.data.reference_images(i, 1) for i in idxs])
                 r, _ = fn(images.to(torch.bfloat16), prompts, [{}] * len(idxs), scorer=self.scorer, head=self.head,
@@ -392,6 +435,8 @@ class Trainer:
                 model.params = live
                 model.params_bf16 = model.params.to(torch.bfloat16)
                 model.refresh()
+        if save_folder is not None:
+            write_prompt2img(prompt2files, save_folder, self.world, self.rank)               # eval.py:291-294
         out = {}
         for k, chunks in acc.items():
             v = torch.cat(chunks)

@@ -102,7 +102,11 @@ def test_eval_loop_is_deterministic_swaps_ema_and_checkpoint_round_trips(tmp_pat
     model.ema_step(7)
     live = model.params.clone()
     a = tr_.evaluate(eval_reward_fn={"pickscore_cotrain": 1})
-    b = tr_.evaluate(eval_reward_fn={"pickscore_cotrain": 1})
+    b = tr_.evaluate(eval_reward_fn={"pickscore_cotrain": 1}, save_folder=str(tmp_path / "eval"))
+    import json
+    with open(tmp_path / "eval" / "prompt2img.json", encoding="utf-8") as f:          # scripts/eval.py:291-294
+        p2i = json.load(f)
+    assert len(p2i) == 3 and all((tmp_path / "eval" / v[0]).exists() and v[0].startswith("node0_rank0_00000_") for v in p2i.values())
     assert set(a) == set(b) == {"eval_reward_pickscore_cotrain", "eval_reward_avg"}
     # fixed seed-0 latents and noise 0: repeatable up to the order of the f64 atomic sums in the VAE's GroupNorm statistics
     assert all(v == v and abs(v - b[k]) <= 5e-3 * abs(v) for k, v in a.items())
