@@ -275,9 +275,9 @@ def attention_bwd(q, k, v, o, d_o, lse, num_heads, dq, dk, dv, scale=None):
     if scale is None:
         scale = D ** -0.5
     assert dq.stride(1) == dk.stride(1) == dv.stride(1) and dq.stride(0) == dk.stride(0) == dv.stride(0)
-    delta = torch.empty(B, num_heads, Sq, dtype=torch.float32, device=q.device)
+    work = torch.empty(B, num_heads, (Sq + 31) // 32, 64, dtype=torch.float32, device=q.device)    # (-L/c | -D) per 32 queries
     _lib.check(lib.advgrpo_attention_bwd(
-        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), work.data_ptr(),
         dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), q.stride(1), k.stride(1), v.stride(1), o.stride(1),
         d_o.stride(1), dq.stride(1), q.stride(0), k.stride(0), v.stride(0), o.stride(0), d_o.stride(0), dq.stride(0),
         B, num_heads, Sq, Skv, D, float(scale), _lib.stream_ptr()))

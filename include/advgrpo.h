@@ -214,10 +214,11 @@ int advgrpo_attention_fwd_bias(const void* q, const void* k, const void* v, void
                                const float* bias, void* stream);
 /* Backward of the fused attention (autograd of the transformer call inside compute_log_prob,
  * scripts/train_sd3_fast_pickscore.py:233-267, reached from loss.backward() at :1165).  head_dim 64.
- * d_o: gradient w.r.t. o (same view convention, pitch lddo / bsdo); lse from the forward; delta: f32 [B,H,Sq]
- * scratch (filled here: rowsum(o * d_o)); dq/dk/dv: bf16 views with pitches lddq / bsdq (one packed buffer). */
+ * d_o: gradient w.r.t. o (same view convention, pitch lddo / bsdo); lse from the forward; work: f32 scratch of
+ * B * H * ceil(Sq / 32) * 64 elements (filled here: per block of 32 queries, -lse / (scale log2 e) and -rowsum(o * d_o));
+ * dq/dk/dv: bf16 views with pitches lddq / bsdq (one packed buffer).  All pointers and pitches 16-byte aligned. */
 int advgrpo_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
-                          const float* lse, float* delta, void* dq, void* dk, void* dv,
+                          const float* lse, float* work, void* dq, void* dk, void* dv,
                           int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
                           int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, int64_t bsdo, int64_t bsdq,
                           int B, int H, int Sq, int Skv, int head_dim, float scale, void* stream);

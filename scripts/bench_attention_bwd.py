@@ -1,4 +1,4 @@
-"""Attention backward (delta + dQ + dK/dV kernels) timing at the G-step's shapes.  Usage: bench_attention_bwd.py"""
+"""Attention backward (delta + dQ + dK/dV kernels) timing at the G-step's shapes.  Usage: bench_attention_bwd.py [shape index]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adv_grpo_amd import ops
@@ -20,4 +20,6 @@ def bench(B, H, S, iters=10):
     ms = s.elapsed_time(e) / iters
     fl = 2.5 * 4 * B * H * S * S * D           # SURVEY's count: 2.5 x the forward
     print(f"B={B} H={H} S={S}: {ms * 1e3:.1f} us  {fl / ms / 1e9:.1f} TFLOP/s credited ({fl * 1.4 / ms / 1e9:.1f} executed: 7 of 5 GEMM units)")
-bench(16, 24, 1229); bench(16, 24, 1024); bench(8, 38, 4301)
+shapes = [(16, 24, 1229), (16, 24, 1024), (8, 38, 4301)]
+for i, sh in enumerate(shapes):
+    if len(sys.argv) < 2 or int(sys.argv[1]) == i: bench(*sh)
