@@ -45,6 +45,16 @@
 #ifndef BP_AHEAD
 #define BP_AHEAD 3
 #endif
+// waves per workgroup: 4 (128 own rows, two workgroups per CU) or 8 (256 own rows, one workgroup per CU: half the L2 -> LDS
+// traffic per MFMA, every wave requests ONE of the two operands' quarter tiles)
+#ifndef BP_WAVES
+#define BP_WAVES 4
+#endif
+// MFMA slot in whose shadow the step's DMA requests are issued (-1: right after the barrier, where every wave of the CU issues
+// its requests at the same moment)
+#ifndef BP_DMA_SLOT
+#define BP_DMA_SLOT -1
+#endif
 
 namespace advgrpo {
 
@@ -60,6 +70,7 @@ constexpr int BP_RING = 8;                  // tiles per ring
 constexpr int BP_RING1 = BP_RING * BP_TILE; // byte offset of the second operand's ring
 constexpr int BP_VEC = 2 * BP_RING1;        // byte offset of the (-L/c | -D) vectors, 256 bytes per slot
 constexpr int BP_LDS_DQ = BP_VEC, BP_LDS_DKDV = BP_VEC + BP_RING * 256;
+constexpr int BP_OWN = BP_WAVES * 32;      // own rows per workgroup
 
 #define BP_SB() __builtin_amdgcn_sched_barrier(0)
 #define BP_PIN(x) asm volatile("" : "+v"(x))
@@ -77,7 +88,8 @@ __device__ __forceinline__ float bp_exp2(float x) {
 }
 template <int N>
 __device__ __forceinline__ void bp_wait_vm() {
-    static_assert(N == 0 || N == 2 || N == 3 || N == 4 || N == 6 || N == 9, "add the literal");
+    static_assert(N == 0 || N == 1 || N == 2 || N == 3 || N == 4 || N == 6 || N == 9, "add the literal");
+    if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -117,11 +129,11 @@ __device__ __forceinline__ void bp_for(F&& f, std::integer_sequence<int, I...>) 
 }
 
 template <bool DKDV>
-__global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(BP_WAVES * 64, BP_WAVES == 4 ? 2 : 1) void attn_bwd_pipe_kernel(const AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int NA = DKDV ? 8 : 4;        // accumulating MFMA slots per step
     constexpr int NS = NA + 8;              // MFMA slots per step
-    constexpr int NB = DKDV ? 3 : 2;        // DMA instructions per wave and tile
+    constexpr int NB = (BP_WAVES == 4 ? 2 : 1) + (DKDV ? 1 : 0);        // DMA instructions per wave and tile
     constexpr int VS0 = 1;                  // first MFMA slot with VALU work in its shadow
     constexpr int NOPS = bp_sched<DKDV>.n;
     static_assert(NS % 4 == 0 && BP_AHEAD >= 2 && BP_AHEAD <= 3, "operand staging wraps around the step");
@@ -131,8 +143,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(const AttnBwdPara
     const int ql = lane & 31, hi = lane >> 5;
     const int n_own = DKDV ? p.Skv : p.Sq, n_str = DKDV ? p.Sq : p.Skv;
     int blk, h, b;
-    xcd_local_bh((n_own + 127) / 128, p.H, (int)gridDim.x, p.xcd_local, blk, h, b);
-    const int own0 = blk * 128 + wave * 32;
+    xcd_local_bh((n_own + BP_OWN - 1) / BP_OWN, p.H, (int)gridDim.x, p.xcd_local, blk, h, b);
+    const int own0 = blk * BP_OWN + wave * 32;
     const int64_t bh = (int64_t)b * p.H + h;
     // own side (B operands: lane = own row) and streamed side (A operands through LDS)
     const bf16_t* b0p = (DKDV ? p.k + (int64_t)b * p.bsk : p.q + (int64_t)b * p.bsq) + h * 64;
@@ -165,10 +177,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(const AttnBwdPara
     const float c = p.scale_log2e;
 
     // ---- DMA: one instruction per wave and operand fills LDS rows 8 wave .. 8 wave + 7 of a tile
-    const int R = wave * 8 + (lane >> 3), pch = lane & 7;
+    const int R = (wave & 3) * 8 + (lane >> 3), pch = lane & 7;
     const uint32_t sw = (uint32_t)((pch ^ ((((R >> 1) & 1) << 2) | ((R >> 2) & 3))) << 4);      // source chunk of LDS chunk pch
     const uint32_t x0_lo = (uint32_t)R * ld0b + sw, x1_lo = (uint32_t)R * ld1b + sw;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)(smem)) + wave * 1024;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)(smem)) + (wave & 3) * 1024;
     const uint32_t ldsv = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)(smem)) + BP_VEC;
     const uint32_t lane4 = lane * 4;
     auto dma16 = [&](const char* base, uint32_t off, uint32_t lds) __attribute__((always_inline)) {
@@ -188,14 +200,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(const AttnBwdPara
     const int64_t step0 = (int64_t)BP_ROWS * ld0b, step1 = (int64_t)BP_ROWS * ld1b;
     const bool ragged = nt * BP_ROWS > n_str;
     auto stage = [&](int t, int slot) __attribute__((always_inline)) {
-        if (ragged && t == nt - 1) {
-            asm volatile("; ragged tile" ::: "memory");
-            const uint32_t r = (uint32_t)min(R, n_str - 1 - t * BP_ROWS);
-            dma16(nxt0, r * ld0b + sw, lds0 + slot * BP_TILE);
-            dma16(nxt1, r * ld1b + sw, lds0 + BP_RING1 + slot * BP_TILE);
-        } else {
-            dma16(nxt0, x0_lo, lds0 + slot * BP_TILE);
-            dma16(nxt1, x1_lo, lds0 + BP_RING1 + slot * BP_TILE);
+        if constexpr (BP_WAVES == 4) {
+            if (ragged && t == nt - 1) {
+                asm volatile("; ragged tile" ::: "memory");
+                const uint32_t r = (uint32_t)min(R, n_str - 1 - t * BP_ROWS);
+                dma16(nxt0, r * ld0b + sw, lds0 + slot * BP_TILE);
+                dma16(nxt1, r * ld1b + sw, lds0 + BP_RING1 + slot * BP_TILE);
+            } else {
+                dma16(nxt0, x0_lo, lds0 + slot * BP_TILE);
+                dma16(nxt1, x1_lo, lds0 + BP_RING1 + slot * BP_TILE);
+            }
+        } else {                                   // waves 0-3 bring the first operand's tile, waves 4-7 the second's
+            const char* src = wave < 4 ? nxt0 : nxt1;
+            const uint32_t ldb = wave < 4 ? ld0b : ld1b, lds = lds0 + (wave < 4 ? 0 : BP_RING1) + slot * BP_TILE;
+            if (ragged && t == nt - 1) {
+                asm volatile("; ragged tile" ::: "memory");
+                dma16(src, (uint32_t)min(R, n_str - 1 - t * BP_ROWS) * ldb + sw, lds);
+            } else {
+                dma16(src, wave < 4 ? x0_lo : x1_lo, lds);
+            }
         }
         if constexpr (DKDV) dma4(nxtv, lane4, ldsv + slot * 256);
         nxt0 += step0;
@@ -251,20 +274,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(const AttnBwdPara
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[i] = bf0[i];
 
-    // the own fragments must have arrived, in the compiler's own bookkeeping, before the first DMA is issued
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) { asm volatile("" ::"v"(bf0[ks])); asm volatile("" ::"v"(bf1[ks])); }
-    asm volatile("" ::"v"(nl), "v"(negD16));
-
-    // ---- prologue: tiles 0 .. 3 requested, scores of tile 0
+    // ---- prologue: tiles 0 .. 3 requested while the own fragments are still on their way, ONE wait for everything (the
+    // compiler's own wait for the fragments would be a vmcnt(0) anyway: it does not see the DMA instructions), scores of tile 0
     stage(0, 0);
     if (nt > 1) stage(1, 1);
     if (nt > 2) stage(2, 2);
     if (nt > 3) stage(3, 3);
-    if (nt > 3) bp_wait_vm<3 * NB>();
-    else if (nt > 2) bp_wait_vm<2 * NB>();
-    else if (nt > 1) bp_wait_vm<NB>();
-    else bp_wait_vm<0>();
+    bp_wait_vm<0>();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { asm volatile("" ::"v"(bf0[ks])); asm volatile("" ::"v"(bf1[ks])); }
+    asm volatile("" ::"v"(nl), "v"(negD16));
     __builtin_amdgcn_s_barrier();
     if constexpr (DKDV) { vec_init(sc[0], 0, 0); vec_init(dp[0], 0, 1); }
     else { sc[0] = zero16; dp[0] = negD16; }
@@ -275,9 +294,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(const AttnBwdPara
     }
 
     // ---- one step: g = SL (mod 8); VALU on tile g (score set SL & 1), accumulating products of tile g - 1, scores of tile g + 1
-    auto step = [&](auto sl_tag, auto first_tag, int g) __attribute__((always_inline)) {
+    auto step = [&](auto sl_tag, auto first_tag, auto last_tag, int g) __attribute__((always_inline)) {
         constexpr int SL = decltype(sl_tag)::value;
-        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;      // LAST: no tile g + 1
         constexpr int CUR = SL & 1, NXT = CUR ^ 1;
         constexpr int T_PREV = ((SL + 7) & 7) * BP_TILE, T_NEXT = ((SL + 1) & 7) * BP_TILE, T_CUR = SL * BP_TILE;
         constexpr int V_NEXT = ((SL + 1) & 7) * 256;
@@ -288,7 +307,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(const AttnBwdPara
             else bp_wait_vm<0>();
             __builtin_amdgcn_s_barrier();
         }
-        if (g + 4 < nt) stage(g + 4, (SL + 4) & 7);            // the slot of tile g - 4
+        if constexpr (BP_DMA_SLOT < 0) {
+            if (g + 4 < nt) stage(g + 4, (SL + 4) & 7);        // the slot of tile g - 4
+        }
         if constexpr (!DKDV) {
             if (ragged && g == nt - 1) {                       // keys past the end of the sequence: P = 0
 #pragma unroll
@@ -309,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(const AttnBwdPara
                 return rfrag(which * BP_RING1 + T_NEXT, ks);
             }
         };
-        auto needs_operand = [](int s) constexpr { return s >= NS || s >= NA || !FIRST; };
+        auto needs_operand = [](int s) constexpr { return s < NA ? !FIRST : !LAST; };
         if constexpr (FIRST) {           // (later steps find their first operands staged by the step before)
             if constexpr (NA - BP_AHEAD <= 0) a[0] = operand(int_c<NA>{});
         }
@@ -344,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(const AttnBwdPara
                     if constexpr (DKDV && s < 4) acc1[db] = BP_MFMA(a[s & 3], __builtin_bit_cast(bf16x8_t, pf[NXT][kk]), acc1[db]);
                     else acc0[db] = BP_MFMA(a[s & 3], __builtin_bit_cast(bf16x8_t, dsf[NXT][kk]), acc0[db]);
                 }
-            } else if constexpr (s < NS) {
+            } else if constexpr (s < NS && !LAST) {
                 constexpr int ks = (s - NA) >> 1, which = (s - NA) & 1;
                 if constexpr (which == 0) {
                     if constexpr (ks == 0 && !DKDV) sc[NXT] = BP_MFMA(a[s & 3], bf0[0], zero16);
@@ -355,7 +376,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(const AttnBwdPara
                 }
             }
             if constexpr (s < NS && needs_operand(s + BP_AHEAD)) a[(s + BP_AHEAD) & 3] = operand(int_c<s + BP_AHEAD>{});
-            if constexpr (DKDV) {        // accumulator start values of tile g + 1
+            if constexpr (BP_DMA_SLOT >= 0 && s == BP_DMA_SLOT) {
+                if (g + 4 < nt) stage(g + 4, (SL + 4) & 7);
+            }
+            if constexpr (DKDV && !LAST) {        // accumulator start values of tile g + 1
                 if constexpr (s == 0) vec_init(sc[NXT], V_NEXT, 0);
                 if constexpr (s == 1) vec_init(dp[NXT], V_NEXT, 1);
             }
@@ -372,24 +396,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(const AttnBwdPara
         BP_SB();
     };
 
-    typedef std::integral_constant<bool, true> first_t;
-    typedef std::integral_constant<bool, false> steady_t;
-    step(int_c<0>{}, first_t{}, 0);
+    typedef std::integral_constant<bool, true> yes_t;
+    typedef std::integral_constant<bool, false> no_t;
+    // (a LAST instantiation of the step without the score products of a tile that does not exist costs registers on every path:
+    // 246 / 256 VGPRs + 344 bytes of scratch with the eight extra copies, measured 13 % slower; the last step multiplies a stale
+    // ring slot instead and nobody reads the result)
+    step(int_c<0>{}, yes_t{}, no_t{}, 0);
     int g = 1;
     for (; g + 8 <= nt; g += 8) {
-        step(int_c<1>{}, steady_t{}, g);     step(int_c<2>{}, steady_t{}, g + 1);
-        step(int_c<3>{}, steady_t{}, g + 2); step(int_c<4>{}, steady_t{}, g + 3);
-        step(int_c<5>{}, steady_t{}, g + 4); step(int_c<6>{}, steady_t{}, g + 5);
-        step(int_c<7>{}, steady_t{}, g + 6); step(int_c<0>{}, steady_t{}, g + 7);
+        step(int_c<1>{}, no_t{}, no_t{}, g);     step(int_c<2>{}, no_t{}, no_t{}, g + 1);
+        step(int_c<3>{}, no_t{}, no_t{}, g + 2); step(int_c<4>{}, no_t{}, no_t{}, g + 3);
+        step(int_c<5>{}, no_t{}, no_t{}, g + 4); step(int_c<6>{}, no_t{}, no_t{}, g + 5);
+        step(int_c<7>{}, no_t{}, no_t{}, g + 6); step(int_c<0>{}, no_t{}, no_t{}, g + 7);
     }
     // (g = 1 (mod 8) here) the up to seven left-over steps
-    if (g < nt) { step(int_c<1>{}, steady_t{}, g); ++g; }
-    if (g < nt) { step(int_c<2>{}, steady_t{}, g); ++g; }
-    if (g < nt) { step(int_c<3>{}, steady_t{}, g); ++g; }
-    if (g < nt) { step(int_c<4>{}, steady_t{}, g); ++g; }
-    if (g < nt) { step(int_c<5>{}, steady_t{}, g); ++g; }
-    if (g < nt) { step(int_c<6>{}, steady_t{}, g); ++g; }
-    if (g < nt) { step(int_c<7>{}, steady_t{}, g); ++g; }
+    if (g < nt) { step(int_c<1>{}, no_t{}, no_t{}, g); ++g; }
+    if (g < nt) { step(int_c<2>{}, no_t{}, no_t{}, g); ++g; }
+    if (g < nt) { step(int_c<3>{}, no_t{}, no_t{}, g); ++g; }
+    if (g < nt) { step(int_c<4>{}, no_t{}, no_t{}, g); ++g; }
+    if (g < nt) { step(int_c<5>{}, no_t{}, no_t{}, g); ++g; }
+    if (g < nt) { step(int_c<6>{}, no_t{}, no_t{}, g); ++g; }
+    if (g < nt) { step(int_c<7>{}, no_t{}, no_t{}, g); ++g; }
 
     // ---- the accumulating products of the last tile
     {
@@ -447,11 +474,11 @@ int attention_bwd_pipe_launch(const AttnBwdParams& p, int B, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_pipe_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BP_LDS_DKDV);
         attr_set = true;
     }
-    const int64_t nq = (int64_t)((p.Sq + 127) / 128) * p.H * B, nk = (int64_t)((p.Skv + 127) / 128) * p.H * B;
+    const int64_t nq = (int64_t)((p.Sq + BP_OWN - 1) / BP_OWN) * p.H * B, nk = (int64_t)((p.Skv + BP_OWN - 1) / BP_OWN) * p.H * B;
     ADVGRPO_CHECK(nq < (1ll << 31) && nk < (1ll << 31), "attention_bwd: grid too large");
-    hipLaunchKernelGGL(attn_bwd_pipe_kernel<false>, dim3((unsigned)nq), dim3(256), BP_LDS_DQ, s, p);
+    hipLaunchKernelGGL(attn_bwd_pipe_kernel<false>, dim3((unsigned)nq), dim3(BP_WAVES * 64), BP_LDS_DQ, s, p);
     ADVGRPO_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_pipe_kernel<true>, dim3((unsigned)nk), dim3(256), BP_LDS_DKDV, s, p);
+    hipLaunchKernelGGL(attn_bwd_pipe_kernel<true>, dim3((unsigned)nk), dim3(BP_WAVES * 64), BP_LDS_DKDV, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

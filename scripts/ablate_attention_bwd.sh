@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../adv_grpo_amd/csrc"
 make -j8 > /dev/null
 OTHERS=$(ls obj/*.o | grep -v attention_bwd_pipe.o)
 for v in "$@"; do
-  case $v in a*) DEF="-DBP_AHEAD=${v#a}";; *) DEF="-DBP_ABL=$v";; esac
+  case $v in a*) DEF="-DBP_AHEAD=${v#a}";; w*) DEF="-DBP_WAVES=${v#w}";; d*) DEF="-DBP_DMA_SLOT=${v#d}";; *) DEF="-DBP_ABL=$v";; esac
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $DEF -c attention_bwd_pipe.hip -o /tmp/att_bwd_$v.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libadvgrpo_abl_bwd_$v.so $OTHERS /tmp/att_bwd_$v.o
   echo built $v
