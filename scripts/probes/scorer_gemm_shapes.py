@@ -30,6 +30,21 @@ for _ in range(10):
 e.record()
 torch.cuda.synchronize()
 print(f"scorer call: {s.elapsed_time(e) / 10:.2f} ms")
+# the product scorer object: text tower on its own stream beside the image tower
+from adv_grpo_amd.pickscore_scorer import PickScoreScorer  # noqa: E402
+from adv_grpo_amd import rewards  # noqa: E402
+sc = PickScoreScorer(dev, dtype=torch.bfloat16, model_sd=synthetic.clip_weights(cfg, 777), clip_cfg=cfg)
+ids8 = ids.expand(8, -1).contiguous()
+prompts = rewards.PromptBatch(["a prompt"] * 8, ids8) if hasattr(rewards, "PromptBatch") else ids8
+for _ in range(3):
+    sc(prompts, img)
+torch.cuda.synchronize()
+s.record()
+for _ in range(10):
+    sc(prompts, img)
+e.record()
+torch.cuda.synchronize()
+print(f"PickScoreScorer call (text tower on a side stream, one unique prompt): {s.elapsed_time(e) / 10:.2f} ms")
 ops.PROFILE, ops.PROFILE_STRIDE = [], 1
 for _ in range(3):
     score()
