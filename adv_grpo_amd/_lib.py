@@ -33,6 +33,14 @@ class GemmDesc(ctypes.Structure):
                 ("rms_rs_out", _P)]
 
 
+class LnDesc(ctypes.Structure):
+    """advgrpo_ln_desc (include/advgrpo.h), field for field."""
+    _fields_ = [("x", _P), ("ldx", c_int64), ("out0", _P), ("out1", _P), ("ldo", c_int64), ("w", _P), ("b", _P),
+                ("scale0", _P), ("shift0", _P), ("scale1", _P), ("shift1", _P), ("mod_stride", c_int64),
+                ("rows_per_batch", c_int32), ("M", c_int32), ("D", c_int32), ("eps", c_float),
+                ("q0", _P), ("qs0", _P), ("q1", _P), ("qs1", _P), ("ldq", c_int64)]
+
+
 class Fp8Scales(ctypes.Structure):
     """advgrpo_fp8_scales (include/advgrpo.h)."""
     _fields_ = [("a_scale", _P), ("w_scale", _P)]
@@ -60,6 +68,7 @@ SIGNATURES = {
     "advgrpo_gemm_grouped": (c_int, [POINTER(GemmDesc), c_int, _P]),
     "advgrpo_gemm_fp8_grouped": (c_int, [POINTER(GemmDesc), POINTER(Fp8Scales), c_int, _P]),
     "advgrpo_quant_fp8_rows": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int, c_int, c_int, _P]),
+    "advgrpo_layernorm_mod_pair": (c_int, [POINTER(LnDesc), POINTER(LnDesc), _P]),
     "advgrpo_layernorm_mod": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int,
                                       c_int, c_float, _P]),
     "advgrpo_layernorm_mod_fp8": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int,

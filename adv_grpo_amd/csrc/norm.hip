@@ -74,11 +74,31 @@ __device__ __forceinline__ uint32_t ln_amax_bits(const uint4& b, uint32_t m) {
     return m;
 }
 
+template <int MAXC, bool FP8>
+__device__ __forceinline__ void layernorm_mod_row(const LnParams& p, int row, int lane);
+
 template <int MAXC, bool FP8 = false>
 __global__ __launch_bounds__(256) void layernorm_mod_kernel(const LnParams p) {
-    const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.M) return;
+    layernorm_mod_row<MAXC, FP8>(p, row, threadIdx.x & 63);
+}
+
+// Two independent problems in ONE launch (advgrpo_layernorm_mod_pair): blocks [0, blocks_a) run a, the rest b.  The MMDiT's
+// text-stream norms (154 rows per sample) are launch-bound on their own (6 - 7 us for 7.5 MB) -- as the tail blocks of the image
+// stream's launch they cost what their bytes cost.  Same per-row code as the single launch: bit-identical outputs.
+struct LnPair { LnParams a, b; int blocks_a; };
+template <int MAXC, bool FP8 = false>
+__global__ __launch_bounds__(256) void layernorm_mod_pair_kernel(const LnPair pp) {
+    const bool first = (int)blockIdx.x < pp.blocks_a;
+    const LnParams& p = first ? pp.a : pp.b;
+    const int row = ((int)blockIdx.x - (first ? 0 : pp.blocks_a)) * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    layernorm_mod_row<MAXC, FP8>(p, row, threadIdx.x & 63);
+}
+
+template <int MAXC, bool FP8>
+__device__ __forceinline__ void layernorm_mod_row(const LnParams& p, const int row, const int lane) {
     const int nch = p.D >> 3;
     float v[MAXC][8];
     const bf16_t* xr = p.x + (int64_t)row * p.ldx;
@@ -338,6 +358,44 @@ extern "C" int advgrpo_layernorm_mod(const void* x, int64_t ldx, void* out0, voi
                mod_stride, rows_per_batch, M, D, eps, 0, nullptr, nullptr, nullptr, nullptr, 0};
     if (D <= 2048) hipLaunchKernelGGL(layernorm_mod_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
     else hipLaunchKernelGGL(layernorm_mod_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+static int ln_from_desc(const advgrpo_ln_desc* d, LnParams& p, bool& fp8) {
+    ADVGRPO_CHECK(d && d->x && (d->out0 || d->q0), "layernorm_mod_pair: null pointer");
+    ADVGRPO_CHECK(d->M > 0 && d->D > 0 && d->D % 8 == 0 && d->D <= LN_MAX_CHUNKS * 512, "layernorm_mod_pair: need D %% 8 == 0, D <= %d (D=%d)",
+                  LN_MAX_CHUNKS * 512, d->D);
+    ADVGRPO_CHECK(d->ldx % 8 == 0 && d->ldo % 8 == 0 && d->mod_stride % 8 == 0 && d->ldq % 8 == 0, "layernorm_mod_pair: pitches must be multiples of 8");
+    ADVGRPO_CHECK((d->scale0 == nullptr) == (d->shift0 == nullptr), "layernorm_mod_pair: scale0/shift0 come together");
+    ADVGRPO_CHECK(!(d->out1 || d->q1) || (d->scale1 && d->shift1), "layernorm_mod_pair: a second output needs scale1/shift1");
+    ADVGRPO_CHECK(!d->q0 || (d->qs0 && d->ldq >= d->D), "layernorm_mod_pair: q0 needs qs0 and ldq >= D");
+    ADVGRPO_CHECK(!d->q1 || (d->q0 && d->qs1), "layernorm_mod_pair: q1 needs q0 and qs1");
+    p = LnParams{(const bf16_t*)d->x, d->ldx, (bf16_t*)d->out0, (bf16_t*)d->out1, d->ldo, (const bf16_t*)d->w, (const bf16_t*)d->b,
+                 (const bf16_t*)d->scale0, (const bf16_t*)d->shift0, (const bf16_t*)d->scale1, (const bf16_t*)d->shift1,
+                 d->mod_stride, d->rows_per_batch, d->M, d->D, d->eps, 0, (uint8_t*)d->q0, (uint8_t*)d->q1, d->qs0, d->qs1, d->ldq};
+    fp8 = d->q0 != nullptr;
+    return 0;
+}
+
+/* Two advgrpo_layernorm_mod / _fp8 problems in one launch (the image-stream and text-stream norms of an MMDiT block). */
+extern "C" int advgrpo_layernorm_mod_pair(const advgrpo_ln_desc* a, const advgrpo_ln_desc* b, void* stream) {
+    LnPair pp{};
+    bool fa = false, fb = false;
+    if (int rc = ln_from_desc(a, pp.a, fa)) return rc;
+    if (int rc = ln_from_desc(b, pp.b, fb)) return rc;
+    ADVGRPO_CHECK(fa == fb, "layernorm_mod_pair: both problems bf16 or both fp8");
+    pp.blocks_a = (pp.a.M + 3) / 4;
+    const dim3 grid(pp.blocks_a + (pp.b.M + 3) / 4);
+    const bool wide = pp.a.D > 2048 || pp.b.D > 2048;
+    hipStream_t s = as_stream(stream);
+    if (fa) {
+        if (wide) hipLaunchKernelGGL((layernorm_mod_pair_kernel<8, true>), grid, dim3(256), 0, s, pp);
+        else hipLaunchKernelGGL((layernorm_mod_pair_kernel<4, true>), grid, dim3(256), 0, s, pp);
+    } else {
+        if (wide) hipLaunchKernelGGL((layernorm_mod_pair_kernel<8, false>), grid, dim3(256), 0, s, pp);
+        else hipLaunchKernelGGL((layernorm_mod_pair_kernel<4, false>), grid, dim3(256), 0, s, pp);
+    }
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

@@ -23,7 +23,19 @@ import torch
 from . import ops
 
 
+def _ln_two_launches(a, b):
+    """ops.layernorm_mod_pair's contract through two separate launches (A/B switch `pair_norms`)."""
+    def one(kw):
+        kw = dict(kw)
+        x = kw.pop("x")
+        if kw.get("q") is not None:
+            return ops.layernorm_mod_fp8(x, kw.pop("q"), **kw)
+        return ops.layernorm_mod(x, **kw)
+    return one(a), one(b)
+
+
 class SD3Transformer2DModel:
+    pair_norms = True
     def __init__(self, state_dict, cfg, device="cuda"):
         self.cfg = cfg
         self.device = torch.device(device)
@@ -233,23 +245,24 @@ class SD3Transformer2DModel:
             # --- norms + modulation (chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
             #     [, shift_msa2, scale_msa2, gate_msa2]); AdaLayerNormContinuous (last context): scale, shift
             cs, ch = (0, 1) if b["last"] else (1, 0)
+            # (the text stream's norm rides in the image stream's launch: ops.layernorm_mod_pair, bit-identical to two launches;
+            #  self.pair_norms = False issues them separately for same-box A/Bs)
+            ln_pair = ops.layernorm_mod_pair if self.pair_norms else _ln_two_launches
             if f8 is not None:
                 # (fp8: the norms write the e4m3 rows the Linears read, and nothing else -- no bf16 copy, no quantiser launch)
                 q_x, q_c = q_n.rows(0, Mi), q_n.rows(Mi, Mi + Mt)
+                kw_x = dict(x=x, q=q_x, scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
                 if b["dual"]:
-                    ops.layernorm_mod_fp8(x, q_x, q2=q_n2, scale=mod(kx, 1), shift=mod(kx, 0), scale2=mod(kx, 7), shift2=mod(kx, 6),
-                                          rows_per_batch=Ni)
-                else:
-                    ops.layernorm_mod_fp8(x, q_x, scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
-                ops.layernorm_mod_fp8(c, q_c, scale=mod(kc, cs), shift=mod(kc, ch), rows_per_batch=Nt)
+                    kw_x.update(q2=q_n2, scale2=mod(kx, 7), shift2=mod(kx, 6))
+                ln_pair(kw_x, dict(x=c, q=q_c, scale=mod(kc, cs), shift=mod(kc, ch), rows_per_batch=Nt))
                 nx, nc, nx2 = q_x, q_c, q_n2
             else:
+                kw_x = dict(x=x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
                 if b["dual"]:
-                    _, nx2 = ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), scale2=mod(kx, 7),
-                                               shift2=mod(kx, 6), rows_per_batch=Ni)
-                else:
-                    ops.layernorm_mod(x, out=nx_buf[:, :D], scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
-                ops.layernorm_mod(c, out=nc_buf[:, :D], scale=mod(kc, cs), shift=mod(kc, ch), rows_per_batch=Nt)
+                    kw_x.update(scale2=mod(kx, 7), shift2=mod(kx, 6))
+                rx, _ = ln_pair(kw_x, dict(x=c, out=nc_buf[:, :D], scale=mod(kc, cs), shift=mod(kc, ch), rows_per_batch=Nt))
+                if b["dual"]:
+                    nx2 = rx[1]
                 nx, nc = self._lora_side_pair(b, [("qkv", nx_buf, None, None), ("cqkv", nc_buf, None, None)], D)
             # --- joint attention.  Each text-stream Linear rides in the launch of its image-stream twin
             #     (ops.gemm_grouped) and the QK RMSNorm is the epilogue of the fused QKV projection.
@@ -281,9 +294,11 @@ class SD3Transformer2DModel:
                                 dict(gate=mod(kx, 8), gate_rows=Ni, residual=x, out=x))])
             # --- MLPs
             if f8 is not None:
-                ops.layernorm_mod_fp8(x, q_n.rows(0, Mi), scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
+                kw_x = dict(x=x, q=q_n.rows(0, Mi), scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
                 if not b["last"]:
-                    ops.layernorm_mod_fp8(c, q_n.rows(Mi, Mi + Mt), scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
+                    ln_pair(kw_x, dict(x=c, q=q_n.rows(Mi, Mi + Mt), scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt))
+                else:
+                    ops.layernorm_mod_fp8(x, q_n.rows(0, Mi), scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
                 ff1 = [(q_n.rows(0, Mi), "ff1", dict(act="gelu_tanh", out=h_all[:Mi]))]
                 if not b["last"]:
                     ff1.append((q_n.rows(Mi, Mi + Mt), "cff1", dict(act="gelu_tanh", out=h_all[Mi:])))
@@ -291,11 +306,13 @@ class SD3Transformer2DModel:
                 ops.quant_fp8_rows(h_all, out=q_h)
                 hm = [q_h.rows(0, Mi), q_h.rows(Mi, Mi + Mt)]
             else:
-                nx = ops.layernorm_mod(x, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
-                ff1 = [(nx, "ff1", dict(act="gelu_tanh"))]
                 if not b["last"]:
-                    nc = ops.layernorm_mod(c, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
-                    ff1.append((nc, "cff1", dict(act="gelu_tanh")))
+                    nx, nc = ln_pair(dict(x=x, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni),
+                                                    dict(x=c, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt))
+                    ff1 = [(nx, "ff1", dict(act="gelu_tanh")), (nc, "cff1", dict(act="gelu_tanh"))]
+                else:
+                    nx = ops.layernorm_mod(x, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
+                    ff1 = [(nx, "ff1", dict(act="gelu_tanh"))]
                 hm = linears(i, b, ff1)
             ff2 = [(hm[0], "ff2", dict(gate=mod(kx, 5), gate_rows=Ni, residual=x, out=x))]
             if not b["last"]:

@@ -1,6 +1,8 @@
 """Thin Python wrappers over the C-ABI kernels (device tensors in, device tensors out).
 
 Host plumbing only: allocation via torch, pointers + sizes handed to libadvgrpo_hip.so."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -325,6 +327,46 @@ def layernorm_mod_fp8(x, q, q2=None, out=None, out2=None, w=None, b=None, scale=
                                              q2.q.data_ptr() if q2 is not None else None,
                                              q2.scale.data_ptr() if q2 is not None else None, q.q.stride(0), _lib.stream_ptr()))
     return out, out2
+
+
+def layernorm_mod_pair(a, b):
+    """Two layernorm_mod (or two layernorm_mod_fp8) problems in ONE launch: a, b are dicts of that function's keyword arguments
+    plus "x" (and "q" / "q2" for the fp8 form: then "out" / "out2" are optional and may stay None).  Returns the two results in the
+    single call's form.  Bit-identical to two calls; saves the launch-bound text-stream launch of an MMDiT block."""
+    lib = _lib.load()
+    descs, keep, rets = [], [], []
+    for kw in (a, b):
+        x = kw["x"]
+        M, D = x.shape
+        fp8 = kw.get("q") is not None
+        scale, shift, scale2, shift2 = kw.get("scale"), kw.get("shift"), kw.get("scale2"), kw.get("shift2")
+        out, out2 = kw.get("out"), kw.get("out2")
+        q, q2 = kw.get("q"), kw.get("q2")
+        if not fp8:
+            out = torch.empty(M, D, dtype=torch.bfloat16, device=x.device) if out is None else out
+            if scale2 is not None and out2 is None:
+                out2 = torch.empty_strided(out.shape, out.stride(), dtype=out.dtype, device=out.device)
+        else:
+            assert q.q.shape == (M, D) and q.q.stride(1) == 1 and q.scale.numel() == M and (q2 is None) == (scale2 is None)
+            assert q2 is None or (q2.q.shape == (M, D) and q2.q.stride(0) == q.q.stride(0))
+        assert out2 is None or (out is not None and out2.stride() == out.stride())
+        ms = scale.stride(0) if scale is not None else 0
+        if scale is not None:
+            assert shift.stride(0) == ms and scale.stride(1) == 1
+        if scale2 is not None:
+            assert scale2.stride(0) == ms and shift2.stride(0) == ms
+        dp = lambda t: t.data_ptr() if t is not None else None
+        d = _lib.LnDesc(x.data_ptr(), x.stride(0), dp(out), dp(out2), out.stride(0) if out is not None else D, dp(kw.get("w")),
+                        dp(kw.get("b")), dp(scale), dp(shift), dp(scale2), dp(shift2), ms, int(kw.get("rows_per_batch", 0)), M, D,
+                        float(kw.get("eps", 1e-6)), q.q.data_ptr() if fp8 else None, q.scale.data_ptr() if fp8 else None,
+                        q2.q.data_ptr() if q2 is not None else None, q2.scale.data_ptr() if q2 is not None else None,
+                        q.q.stride(0) if fp8 else 0)
+        descs.append(d)
+        keep.append((x, out, out2, scale, shift, scale2, shift2, q, q2, kw.get("w"), kw.get("b")))
+        rets.append((out, out2) if (fp8 or scale2 is not None) else out)
+    _lib.check(lib.advgrpo_layernorm_mod_pair(ctypes.byref(descs[0]), ctypes.byref(descs[1]), _lib.stream_ptr()))
+    del keep
+    return rets[0], rets[1]
 
 
 def rmsnorm_rows(x, w, eps=1e-6, out=None):

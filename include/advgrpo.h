@@ -151,6 +151,20 @@ int advgrpo_layernorm_mod(const void* x, int64_t ldx, void* out0, void* out1, in
                           int M, int D, float eps, void* stream);
 /* The same with fp8 outputs for the fp8 Linears (below): q0 / q1 [M, D] e4m3 codes (pitch ldq bytes) + qs0 / qs1 [M] f32 row
  * scales, bit for bit what advgrpo_quant_fp8_rows makes of out0 / out1 -- which may then be null (not written at all). */
+/* Two such problems in ONE launch: the image-stream and the text-stream norm of an MMDiT block (norm1 / norm1_context and the
+ * LayerNorms in front of the two feed-forwards, diffusers JointTransformerBlock.forward behind PF:630-637).  The text stream's 154
+ * rows per sample are launch-bound alone; bit-identical to two separate calls.  Fields as the arguments above; q0 / qs0 (/ q1 /
+ * qs1, ldq) non-null selects the fp8 form for BOTH problems. */
+typedef struct advgrpo_ln_desc {
+    const void* x; int64_t ldx;
+    void* out0; void* out1; int64_t ldo;
+    const void* w; const void* b;
+    const void* scale0; const void* shift0; const void* scale1; const void* shift1;
+    int64_t mod_stride; int rows_per_batch;
+    int M, D; float eps;
+    void* q0; float* qs0; void* q1; float* qs1; int64_t ldq;
+} advgrpo_ln_desc;
+int advgrpo_layernorm_mod_pair(const advgrpo_ln_desc* a, const advgrpo_ln_desc* b, void* stream);
 int advgrpo_layernorm_mod_fp8(const void* x, int64_t ldx, void* out0, void* out1, int64_t ldo, const void* w,
                               const void* b, const void* scale0, const void* shift0, const void* scale1,
                               const void* shift1, int64_t mod_stride, int rows_per_batch, int M, int D, float eps,

@@ -274,3 +274,44 @@ def test_grpo_loss_takes_strided_views():
         r = torch.exp(lp[:, j] - old[:, j])
         want = torch.maximum(-adv[:, j] * r, -adv[:, j] * r.clamp(1 - 1e-4, 1 + 1e-4)).mean()
         assert abs(a[0].item() - want.item()) < 1e-6 and abs(a[1].item() - 0.5 * ((lp[:, j] - old[:, j]) ** 2).mean().item()) < 1e-9
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_layernorm_mod_pair_equals_two_launches(fp8):
+    """advgrpo_layernorm_mod_pair: the image-stream and text-stream norms of an MMDiT block in one launch, bit for bit the two
+    single launches (second output on the first problem, different rows per batch and modulation rows on the second)."""
+    from adv_grpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B, Ni, Nt, D = 3, 1024, 154, 1536
+    x = torch.randn(B * Ni, D, device="cuda", generator=g).to(torch.bfloat16)
+    c = (torch.randn(B * Nt, D, device="cuda", generator=g) * 3 + 1).to(torch.bfloat16)
+    mods = (torch.randn(B, 6 * D, device="cuda", generator=g) * 0.3).to(torch.bfloat16)
+    m = lambda k: mods[:, k * D:(k + 1) * D]
+    def args(first):
+        if first:
+            kw = dict(x=x, scale=m(1), shift=m(0), scale2=m(3), shift2=m(2), rows_per_batch=Ni)
+            M = B * Ni
+        else:
+            kw = dict(x=c, scale=m(5), shift=m(4), rows_per_batch=Nt)
+            M = B * Nt
+        if fp8:
+            mk = lambda: ops.Fp8Rows(torch.empty(M, D, dtype=torch.uint8, device="cuda"), torch.empty(M, dtype=torch.float32, device="cuda"))
+            kw["q"] = mk()
+            if first:
+                kw["q2"] = mk()
+        return kw
+    a1, b1 = args(True), args(False)
+    ra, rb = ops.layernorm_mod_pair(a1, b1)
+    a2, b2 = args(True), args(False)
+    if fp8:
+        ops.layernorm_mod_fp8(a2.pop("x"), a2.pop("q"), **a2)
+        ops.layernorm_mod_fp8(b2.pop("x"), b2.pop("q"), **b2)
+        a2, b2 = args(True), args(False)        # fresh destination buffers for the reference launches
+        ops.layernorm_mod_fp8(x, a2["q"], q2=a2["q2"], scale=m(1), shift=m(0), scale2=m(3), shift2=m(2), rows_per_batch=Ni)
+        ops.layernorm_mod_fp8(c, b2["q"], scale=m(5), shift=m(4), rows_per_batch=Nt)
+        for got, want in ((a1["q"], a2["q"]), (a1["q2"], a2["q2"]), (b1["q"], b2["q"])):
+            assert torch.equal(got.q, want.q) and torch.equal(got.scale, want.scale)
+    else:
+        wa = ops.layernorm_mod(x, scale=m(1), shift=m(0), scale2=m(3), shift2=m(2), rows_per_batch=Ni)
+        wb = ops.layernorm_mod(c, scale=m(5), shift=m(4), rows_per_batch=Nt)
+        assert torch.equal(ra[0], wa[0]) and torch.equal(ra[1], wa[1]) and torch.equal(rb, wb)
