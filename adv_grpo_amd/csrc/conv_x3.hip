@@ -356,6 +356,54 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
             __builtin_amdgcn_s_barrier();
         });
     }
+    if constexpr (F16) {
+        if (p.gn_partial) {     // (uniform) the statistics of the GroupNorm that reads this output, per tile: see GemmParams::gn_partial
+            float st[2][FN][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) { st[a][j][0] = 0.f; st[a][j][1] = 0.f; }
+            const int m_split = (m0 / hw + 1) * hw;
+            gemm_epilogue_f32io<FM, FN, TM, TN, true>(p, acc, m0, n0, wm, wn, lane, st, m_split);
+            // rows: the 16 lanes that share lane >> 4 (fixed order: the same bits on every run)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        float v = st[a][j][k];
+                        v += __shfl_xor(v, 1, 64);
+                        v += __shfl_xor(v, 2, 64);
+                        v += __shfl_xor(v, 4, 64);
+                        v += __shfl_xor(v, 8, 64);
+                        st[a][j][k] = v;
+                    }
+            // waves of one tile column: through LDS (every wave is past the k loop's last barrier; the epilogue does not use LDS)
+            float* red = reinterpret_cast<float*>(smem);          // [wave][cls][chunk = j * 4 + (lane >> 4)][2]
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        float* d = red + ((wave * 2 + a) * (4 * FN) + j * 4 + (lane >> 4)) * 2;
+                        d[0] = st[a][j][0];
+                        d[1] = st[a][j][1];
+                    }
+            }
+            __syncthreads();
+            constexpr int CH = 4 * FN;                            // 4-channel chunks per wave tile
+            if (tid < 2 * X3_WN * CH * 2) {
+                const int k = tid & 1, chunk = (tid >> 1) % CH, wn_ = ((tid >> 1) / CH) % X3_WN, a = (tid >> 1) / (CH * X3_WN);
+                float v = 0.f;
+#pragma unroll
+                for (int wm_ = 0; wm_ < X3_WM; ++wm_) v += red[(((wm_ * X3_WN + wn_) * 2 + a) * CH + chunk) * 2 + k];
+                const int n = n0 + wn_ * TN + chunk * 4;
+                if (n < p.N) p.gn_partial[(((int64_t)tile_m * 2 + a) * (p.N >> 2) + (n >> 2)) * 2 + k] = v;
+            }
+            return;
+        }
+    }
     gemm_epilogue_f32io<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
 

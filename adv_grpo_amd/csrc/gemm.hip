@@ -469,7 +469,7 @@ extern "C" int advgrpo_conv3x3_nhwc(const void* x, const void* w, void* y, int o
  * [hi | hi | lo], w3 [Cout, 9*Cin3] with each tap's channels [hi | lo | hi]; bias / residual / y are f32 */
 extern "C" int advgrpo_conv3x3_nhwc_f16x2(const void* x2, const void* w16, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
                                           int upsample, const float* bias, int act, const float* residual, const void* zero_page,
-                                          float alpha, void* stream) {
+                                          float alpha, float* gn_partial, void* stream) {
     GemmParams p{};
     p.A = (const bf16_t*)x2; p.W = (const bf16_t*)w16; p.C = y;
     p.lda = Cin3; p.ldw = 3 * (int64_t)Cin3; p.ldc = Cout; p.out_dtype = ADVGRPO_F32;      // weights [Cout, 9 C], C = Cin3 / 3
@@ -481,7 +481,9 @@ extern "C" int advgrpo_conv3x3_nhwc_f16x2(const void* x2, const void* w16, float
     p.zero_page = (const bf16_t*)zero_page;
     p.splitk = 1;
     p.f32_io = 1;
+    p.gn_partial = gn_partial;
     ADVGRPO_CHECK(x2 && w16 && y && zero_page, "conv3x3_f16x2: null pointer");
+    ADVGRPO_CHECK(!gn_partial || (Hout * Wout >= 192 && Cout % 4 == 0), "conv3x3_f16x2: tile statistics need images of >= 192 pixels");
     ADVGRPO_CHECK(Cin3 % 192 == 0 && Cout >= 128, "conv3x3_f16x2: Cin3 must be 3 x (a multiple of 64), Cout >= 128 (Cin3=%d Cout=%d)", Cin3, Cout);
     return conv3x3_f16x2_launch(p, as_stream(stream));
 }

@@ -156,6 +156,38 @@ __global__ __launch_bounds__(64) void groupnorm_finalize_kernel(const double* __
     }
 }
 
+// The same from the per-TILE sums the f16x2 convolution's epilogue leaves (GemmParams::gn_partial: [tile][cls][C / 4] {sum, sum of
+// squares} f32, tile = tile_rows consecutive pixels of the [B * HW] pixel axis, cls 0 / 1 = the image of the tile's first row / the
+// next one): one wave per (image, group), lane l adds tiles l, l + 64, ... of the image in order, then the fixed xor tree.
+__global__ __launch_bounds__(64) void groupnorm_finalize_tiles_kernel(const float* __restrict__ partial, float* __restrict__ mr, int B,
+                                                                      int G, int C, int HW, int tile_rows, double cnt, float eps) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int b = i / G, g = i - b * G;
+    const int nch = C >> 2, cpg4 = (C / G) >> 2;
+    const int64_t r0 = (int64_t)b * HW, r1 = r0 + HW;
+    const int t0 = (int)(r0 / tile_rows), t1 = (int)((r1 - 1) / tile_rows);
+    double s = 0.0, q = 0.0;
+    for (int t = t0 + lane; t <= t1; t += 64) {
+        const int cls = ((int64_t)t * tile_rows / HW == b) ? 0 : 1;
+        const float* e = partial + (((int64_t)t * 2 + cls) * nch + g * cpg4) * 2;
+        for (int c = 0; c < cpg4; ++c) {
+            s += (double)e[2 * c];
+            q += (double)e[2 * c + 1];
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        s += __shfl_xor(s, m, 64);
+        q += __shfl_xor(q, m, 64);
+    }
+    if (lane == 0) {
+        const double mean = s / cnt;
+        const double var = q / cnt - mean * mean;
+        mr[2 * i] = (float)mean;
+        mr[2 * i + 1] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+    }
+}
+
 // T = bf16_t: bf16 in / bf16 affine / bf16 out.  T = float (split-bf16 mode): f32 in, f32 affine, output row of 3C bf16
 // = [hi | hi | lo] of the normalised value.
 template <typename T>
@@ -433,17 +465,24 @@ extern "C" int advgrpo_groupnorm_nhwc_x3(const float* x, void* y3, double* stats
 }
 
 extern "C" int advgrpo_groupnorm_nhwc_f16x2(const float* x, void* y3, double* stats, const float* weight, const float* bias,
-                                            int B, int HW, int C, int G, float eps, int silu, float prescale, void* stream) {
+                                            int B, int HW, int C, int G, float eps, int silu, float prescale, const float* tile_partial,
+                                            int tile_rows, void* stream) {
     ADVGRPO_CHECK(x && y3 && stats && weight && bias, "groupnorm_f16x2: null pointer");
     ADVGRPO_CHECK(B > 0 && HW > 0 && C % 8 == 0 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 4 == 0 && 256 % (C / 8) == 0,
                   "groupnorm_f16x2: unsupported shape C=%d G=%d", C, G);
     hipStream_t s = as_stream(stream);
     const int ppb = advgrpo_groupnorm_ppb(HW), nchunks = (HW + ppb - 1) / ppb;
-    hipLaunchKernelGGL(groupnorm_stats_kernel<float>, dim3(nchunks, B), dim3(256), 0, s, x, stats, HW, C, G, ppb);
-    ADVGRPO_LAUNCH_CHECK();
     float* mr = reinterpret_cast<float*>(stats + (size_t)B * nchunks * G * 2);
-    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(B * G), dim3(64), 0, s, stats, mr, B, G, nchunks,
-                       (double)HW * (C / G), eps);
+    if (tile_partial) {     // the statistics came out of the producing convolution's epilogue: no pass over x for them
+        ADVGRPO_CHECK(tile_rows > 0 && tile_rows <= HW, "groupnorm_f16x2: tile_rows %d (HW = %d)", tile_rows, HW);
+        hipLaunchKernelGGL(groupnorm_finalize_tiles_kernel, dim3(B * G), dim3(64), 0, s, tile_partial, mr, B, G, C, HW, tile_rows,
+                           (double)HW * (C / G), eps);
+    } else {
+        hipLaunchKernelGGL(groupnorm_stats_kernel<float>, dim3(nchunks, B), dim3(256), 0, s, x, stats, HW, C, G, ppb);
+        ADVGRPO_LAUNCH_CHECK();
+        hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(B * G), dim3(64), 0, s, stats, mr, B, G, nchunks,
+                           (double)HW * (C / G), eps);
+    }
     ADVGRPO_LAUNCH_CHECK();
     const int64_t total8 = (int64_t)B * HW * (C / 8);
     int64_t blocks = (total8 + 255) / 256;

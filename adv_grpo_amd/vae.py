@@ -123,6 +123,7 @@ class AutoencoderKLDecoder:
     def _conv3(self, name, x3, **kw):
         return ops.conv3x3_x3(x3, self.w[name + ".weight"], bias=self.w[name + ".bias"], **kw)
 
+    fused_gn_stats = True            # A/B switch: GroupNorm statistics from the producing convolution's epilogue
     RAW_PRESCALE = 2.0 ** -4         # un-normalised conv inputs (the upsamplers') as fp16 pairs: |x| up to 1e6 stays in range
 
     def _conv_auto(self, name, x, gn=None, **kw):
@@ -130,11 +131,15 @@ class AutoencoderKLDecoder:
         fp16-exact weight -> fp16-pair activations, two products (f16x2); otherwise split-bf16, three products."""
         w = self.w
         if name + ".weight@f16" in w:
+            # (every f16x2 convolution's output is read by a GroupNorm -- the next resnet's norm1 or this resnet's norm2 -- so its
+            #  epilogue leaves that norm's per-tile sums (`gn_tile_stats`) and the norm skips its statistics pass over the activations)
+            st = self.fused_gn_stats
             if gn is not None:
-                a = ops.groupnorm_nhwc_f16x2(x, w[gn + ".weight"], w[gn + ".bias"], self.G, 1e-6, True)
-                return ops.conv3x3_f16x2(a, w[name + ".weight@f16"], bias=w[name + ".bias"], **kw)
+                a = ops.groupnorm_nhwc_f16x2(x, w[gn + ".weight"], w[gn + ".bias"], self.G, 1e-6, True,
+                                             tile_stats=getattr(x, "gn_tile_stats", None) if st else None)
+                return ops.conv3x3_f16x2(a, w[name + ".weight@f16"], bias=w[name + ".bias"], gn_stats=st, **kw)
             a = ops.split_f16x2(x, prescale=self.RAW_PRESCALE)
-            return ops.conv3x3_f16x2(a, w[name + ".weight@f16"], bias=w[name + ".bias"], alpha=1.0 / self.RAW_PRESCALE, **kw)
+            return ops.conv3x3_f16x2(a, w[name + ".weight@f16"], bias=w[name + ".bias"], alpha=1.0 / self.RAW_PRESCALE, gn_stats=st, **kw)
         wide = w[name + ".weight"].shape[0] >= 128      # >= 128 output channels: the kernel that reads the hi and lo thirds only
         a = self._gn3(gn, x, True, pair_only=wide) if gn is not None else ops.split_x3(x, order=2 if wide else 0)
         return self._conv3(name, a, **kw)

@@ -283,13 +283,19 @@ int advgrpo_conv3x3_nhwc_x3(const void* x3, const void* w3, float* y, int B, int
  * ONE fp16 piece [Cout, 9 C] (k = (ky*3+kx)*C + c); s = prescale is a power of two that keeps un-normalised activations inside
  * the fp16 range, alpha = 1 / s multiplies the accumulators back (exact).  Everything between two products stays f32.
  *   groupnorm_nhwc_f16x2 / split_f16x2: the producers (GroupNorm + SiLU of a resnet, the plain split in front of an upsampler);
- *   conv3x3_nhwc_f16x2: Cout >= 128, bias / residual / y f32. */
+ *   conv3x3_nhwc_f16x2: Cout >= 128, bias / residual / y f32.
+ * GroupNorm statistics without a pass over the activations: gn_partial (optional; ceil(B Hout Wout / 192) * 2 * (Cout / 4) * 2
+ * floats) receives, per 192-pixel tile of the convolution's output and per 4 output channels, {sum, sum of squares} split by
+ * image (a tile straddles at most two); the GroupNorm that reads y takes them as tile_partial with tile_rows = 192
+ * (ADVGRPO_CONV_F16X2_TILE_ROWS) and skips its statistics kernel.  Deterministic (fixed summation order, no atomics). */
+#define ADVGRPO_CONV_F16X2_TILE_ROWS 192
 int advgrpo_groupnorm_nhwc_f16x2(const float* x, void* y3, double* stats, const float* weight, const float* bias, int B,
-                                 int HW, int C, int G, float eps, int silu, float prescale, void* stream);
+                                 int HW, int C, int G, float eps, int silu, float prescale, const float* tile_partial,
+                                 int tile_rows, void* stream);
 int advgrpo_split_f16x2(const float* x, const float* bias, void* out3, int64_t rows, int K, float prescale, void* stream);
 int advgrpo_conv3x3_nhwc_f16x2(const void* x2, const void* w16, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
                                int upsample, const float* bias, int act, const float* residual, const void* zero_page,
-                               float alpha, void* stream);
+                               float alpha, float* gn_partial, void* stream);
 /* GroupNorm over f32 NHWC [B,HW,C], f32 affine (+ SiLU) -> split output [B,HW,3C]; stats scratch as above.
  * pair_only != 0 leaves the middle third unwritten (order 2 above: output consumed by the Cout >= 128 3x3 kernel only) */
 int advgrpo_groupnorm_nhwc_x3(const float* x, void* y3, double* stats, const float* weight, const float* bias, int B,

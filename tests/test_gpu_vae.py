@@ -357,3 +357,43 @@ def test_vae_decode_f16x2_path_for_an_fp16_checkpoint(B, hw):
     assert (img3 - ref).abs().mean().item() < 2e-5
     dec_inexact = AutoencoderKLDecoder(synthetic.vae_decoder_weights(cfg, 99), cfg, "cuda", mode="bf16x3")
     assert not any(k.endswith("@f16") for k in dec_inexact.w)
+
+
+@pytest.mark.parametrize("B,H,W,C,Co,up", [(3, 24, 24, 128, 256, False), (2, 16, 16, 512, 512, True), (5, 40, 24, 256, 128, False)])
+def test_groupnorm_statistics_from_the_conv_epilogue(B, H, W, C, Co, up):
+    """advgrpo_conv3x3_nhwc_f16x2's gn_partial: per 192-pixel tile and 4 output channels {sum, sum of squares}, split by image where a
+    tile straddles two (HW is not a multiple of 192 in any of these cases) -- against the sums of the stored output, and the
+    GroupNorm that consumes them against the one that runs its own statistics pass (same f16-pair output up to the last bit of
+    mean / rstd: the two sum the same values in a different order)."""
+    from adv_grpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(C + H)
+    x = torch.randn(B, H, W, C, device="cuda", generator=g)
+    gw, gb = 1 + 0.1 * torch.randn(C, device="cuda", generator=g), 0.1 * torch.randn(C, device="cuda", generator=g)
+    w16 = (torch.randn(Co, 9 * C, device="cuda", generator=g) / (C * 9) ** 0.5).half()
+    bias = torch.randn(Co, device="cuda", generator=g)
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    res = torch.randn(B, Ho, Wo, Co, device="cuda", generator=g)
+    a = ops.groupnorm_nhwc_f16x2(x, gw, gb, 32, 1e-6, True)
+    y = ops.conv3x3_f16x2(a, w16, bias=bias, upsample=up, residual=res, gn_stats=True)
+    y0 = ops.conv3x3_f16x2(a, w16, bias=bias, upsample=up, residual=res)
+    assert torch.equal(y, y0) and not hasattr(y0, "gn_tile_stats")
+    part = y.gn_tile_stats                                    # [tiles, 2, Co / 4, 2]
+    HW, T = Ho * Wo, ops.CONV_F16X2_TILE_ROWS
+    rows = y.view(B * HW, Co // 4, 4).double()
+    for t in (0, 1, part.shape[0] // 2, part.shape[0] - 1):
+        r0, r1 = t * T, min((t + 1) * T, B * HW)
+        split = min((r0 // HW + 1) * HW, r1)
+        for cls, (a0, a1) in enumerate(((r0, split), (split, r1))):
+            want_s = rows[a0:a1].sum(dim=(0, 2))
+            want_q = (rows[a0:a1] ** 2).sum(dim=(0, 2))
+            assert (part[t, cls, :, 0].double() - want_s).abs().max().item() <= 1e-4 * max(1.0, want_q.max().item() ** 0.5 * (a1 - a0) ** 0.5)
+            assert (part[t, cls, :, 1].double() - want_q).abs().max().item() <= 1e-5 * max(1.0, want_q.max().item())
+    gw2, gb2 = 1 + 0.1 * torch.randn(Co, device="cuda", generator=g), 0.1 * torch.randn(Co, device="cuda", generator=g)
+    n_fused = ops.groupnorm_nhwc_f16x2(y, gw2, gb2, 32, 1e-6, True, tile_stats=part)
+    n_plain = ops.groupnorm_nhwc_f16x2(y, gw2, gb2, 32, 1e-6, True)
+    def value(n):       # fp16 pair -> f32
+        h = n.view(torch.float16).view(B, Ho, Wo, 3, Co)
+        return h[..., 0, :].float() + h[..., 2, :].float()
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(y.permute(0, 3, 1, 2).double(), 32, gw2.double(), gb2.double(), 1e-6)).permute(0, 2, 3, 1)
+    assert (value(n_fused).double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    assert (value(n_fused) - value(n_plain)).abs().max().item() < 2e-6 * ref.abs().max().item()
