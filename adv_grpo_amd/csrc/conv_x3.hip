@@ -357,50 +357,28 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
         });
     }
     if constexpr (F16) {
-        if (p.gn_partial) {     // (uniform) the statistics of the GroupNorm that reads this output, per tile: see GemmParams::gn_partial
-            float st[2][FN][2];
+        if (p.gn_partial) {     // (uniform) the sums of the GroupNorm that reads this output: see GemmParams::gn_partial
+            float st[FM][FN][2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) { st[a][j][0] = 0.f; st[a][j][1] = 0.f; }
-            const int m_split = (m0 / hw + 1) * hw;
-            gemm_epilogue_f32io<FM, FN, TM, TN, true>(p, acc, m0, n0, wm, wn, lane, st, m_split);
-            // rows: the 16 lanes that share lane >> 4 (fixed order: the same bits on every run)
+                for (int j = 0; j < FN; ++j) { st[i][j][0] = 0.f; st[i][j][1] = 0.f; }
+            gemm_epilogue_f32io<FM, FN, TM, TN, true>(p, acc, m0, n0, wm, wn, lane, st);
+            // the 16 pixels of a fragment sit in the 16 lanes that share lane >> 4: a fixed xor tree, the same bits wherever the
+            // image stands in the batch; every (16-pixel block, 4-channel chunk) belongs to exactly one wave: no LDS, no atomics
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        float v = st[a][j][k];
-                        v += __shfl_xor(v, 1, 64);
-                        v += __shfl_xor(v, 2, 64);
-                        v += __shfl_xor(v, 4, 64);
-                        v += __shfl_xor(v, 8, 64);
-                        st[a][j][k] = v;
-                    }
-            // waves of one tile column: through LDS (every wave is past the k loop's last barrier; the epilogue does not use LDS)
-            float* red = reinterpret_cast<float*>(smem);          // [wave][cls][chunk = j * 4 + (lane >> 4)][2]
-            if ((lane & 15) == 0) {
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        float* d = red + ((wave * 2 + a) * (4 * FN) + j * 4 + (lane >> 4)) * 2;
-                        d[0] = st[a][j][0];
-                        d[1] = st[a][j][1];
-                    }
-            }
-            __syncthreads();
-            constexpr int CH = 4 * FN;                            // 4-channel chunks per wave tile
-            if (tid < 2 * X3_WN * CH * 2) {
-                const int k = tid & 1, chunk = (tid >> 1) % CH, wn_ = ((tid >> 1) / CH) % X3_WN, a = (tid >> 1) / (CH * X3_WN);
-                float v = 0.f;
-#pragma unroll
-                for (int wm_ = 0; wm_ < X3_WM; ++wm_) v += red[(((wm_ * X3_WN + wn_) * 2 + a) * CH + chunk) * 2 + k];
-                const int n = n0 + wn_ * TN + chunk * 4;
-                if (n < p.N) p.gn_partial[(((int64_t)tile_m * 2 + a) * (p.N >> 2) + (n >> 2)) * 2 + k] = v;
-            }
+                for (int j = 0; j < FN; ++j) {
+                    float sv = st[i][j][0], qv = st[i][j][1];
+                    sv += __shfl_xor(sv, 1, 64); qv += __shfl_xor(qv, 1, 64);
+                    sv += __shfl_xor(sv, 2, 64); qv += __shfl_xor(qv, 2, 64);
+                    sv += __shfl_xor(sv, 4, 64); qv += __shfl_xor(qv, 4, 64);
+                    sv += __shfl_xor(sv, 8, 64); qv += __shfl_xor(qv, 8, 64);
+                    const int m = m0 + wm * TM + i * 16, n = n0 + wn * TN + j * 16 + (lane >> 4) * 4;
+                    if ((lane & 15) == 0 && m < p.M && n < p.N)
+                        *reinterpret_cast<float2*>(p.gn_partial + ((int64_t)(m >> 4) * (p.N >> 2) + (n >> 2)) * 2) = float2{sv, qv};
+                }
             return;
         }
     }

@@ -483,7 +483,7 @@ extern "C" int advgrpo_conv3x3_nhwc_f16x2(const void* x2, const void* w16, float
     p.f32_io = 1;
     p.gn_partial = gn_partial;
     ADVGRPO_CHECK(x2 && w16 && y && zero_page, "conv3x3_f16x2: null pointer");
-    ADVGRPO_CHECK(!gn_partial || (Hout * Wout >= 192 && Cout % 4 == 0), "conv3x3_f16x2: tile statistics need images of >= 192 pixels");
+    ADVGRPO_CHECK(!gn_partial || ((Hout * Wout) % 16 == 0 && Cout % 4 == 0), "conv3x3_f16x2: block sums need 16 | Hout Wout");
     ADVGRPO_CHECK(Cin3 % 192 == 0 && Cout >= 128, "conv3x3_f16x2: Cin3 must be 3 x (a multiple of 64), Cout >= 128 (Cin3=%d Cout=%d)", Cin3, Cout);
     return conv3x3_f16x2_launch(p, as_stream(stream));
 }

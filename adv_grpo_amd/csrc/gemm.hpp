@@ -38,9 +38,9 @@ struct GemmParams {
     // bytes), a_scale [M] / w_scale [N] f32 multiply the accumulators in the epilogue (per-token x per-output-channel scaling)
     int fp8; const float* a_scale; const float* w_scale;
     int f32_io;  // convolutions only: bias / residual / C are f32 (the split-bf16 VAE mode keeps f32 between kernels)
-    // f16x2 convolution only: per-tile sums for the GroupNorm that follows -- gn_partial[(tile_m * 2 + cls) * (N / 4) + n / 4] =
-    // {sum, sum of squares} (f32 pairs) over the tile's rows of 4 consecutive output channels, cls 0 = rows of the image the
-    // tile's first row belongs to, 1 = rows of the next image (a 192-row tile straddles at most two)
+    // f16x2 convolution only: sums for the GroupNorm that follows -- gn_partial[(m / 16) * (N / 4) + n / 4] = {sum, sum of squares}
+    // (f32 pairs) over 16 consecutive output pixels x 4 consecutive output channels.  16 divides every image's pixel count, so a
+    // block never straddles two images and an image's sums do not depend on its position in the batch
     float* gn_partial;
     int debug;   // experiments only (ADVGRPO_GEMM_DEBUG): bit0 = skip steady-state DMA, bit1 = skip LDS fragment reads
 };

@@ -379,11 +379,10 @@ __device__ __forceinline__ void gemm_epilogue_frag(const GemmParams& p, f32x4 (&
 // f32 in / f32 out epilogue of the split-bf16 VAE convolutions (GemmParams::f32_io): y = act(acc + bias_f32[n]) +
 // residual_f32[m, n], f32 store, straight from the accumulator layout (a lane's 4 consecutive columns are one float4;
 // the 4 lanes of a row cover 64 contiguous bytes).  Only the convolution kernels instantiate it.
-// STATS: st[cls][j][0 / 1] += sum / sum of squares of the lane's four stored values of fragment column j, cls = 1 for the rows
-// from m_split on (the next image's rows of a tile that straddles two images)
+// STATS: st[i][j][0 / 1] = sum / sum of squares of the lane's four stored values of fragment (i, j)
 template <int FM, int FN, int TM, int TN, bool STATS = false>
 __device__ __forceinline__ void gemm_epilogue_f32io(const GemmParams& p, f32x4 (&acc)[FM][FN], int m0, int n0, int wm,
-                                                    int wn, int lane, float (*st)[FN][2] = nullptr, int m_split = 0) {
+                                                    int wn, int lane, float (*st)[FN][2] = nullptr) {
     const int mrow = lane & 15, ncol = (lane >> 4) * 4;
     const float* bias = reinterpret_cast<const float*>(p.bias);
     const float* res = reinterpret_cast<const float*>(p.residual);
@@ -410,9 +409,8 @@ __device__ __forceinline__ void gemm_epilogue_f32io(const GemmParams& p, f32x4 (
             if constexpr (STATS) {
                 const float sv = (v[0] + v[1]) + (v[2] + v[3]);
                 const float qv = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                const bool second = m >= m_split;
-                st[0][j][0] += second ? 0.f : sv; st[0][j][1] += second ? 0.f : qv;
-                st[1][j][0] += second ? sv : 0.f; st[1][j][1] += second ? qv : 0.f;
+                st[i][j][0] = sv;
+                st[i][j][1] = qv;
             }
             // streaming store: up to 1 GiB of output that the next kernel reads only after it has left every cache
             __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(out + (int64_t)m * p.ldc + n));

@@ -156,20 +156,19 @@ __global__ __launch_bounds__(64) void groupnorm_finalize_kernel(const double* __
     }
 }
 
-// The same from the per-TILE sums the f16x2 convolution's epilogue leaves (GemmParams::gn_partial: [tile][cls][C / 4] {sum, sum of
-// squares} f32, tile = tile_rows consecutive pixels of the [B * HW] pixel axis, cls 0 / 1 = the image of the tile's first row / the
-// next one): one wave per (image, group), lane l adds tiles l, l + 64, ... of the image in order, then the fixed xor tree.
+// The same from the block sums the f16x2 convolution's epilogue leaves (GemmParams::gn_partial: [B * HW / 16][C / 4] {sum, sum of
+// squares} f32 over 16 pixels x 4 channels): one wave per (image, group), lane l adds the image's blocks l, l + 64, ... in order,
+// then the fixed xor tree -- nothing depends on where the image stands in the batch.
 __global__ __launch_bounds__(64) void groupnorm_finalize_tiles_kernel(const float* __restrict__ partial, float* __restrict__ mr, int B,
                                                                       int G, int C, int HW, int tile_rows, double cnt, float eps) {
     const int i = blockIdx.x, lane = threadIdx.x;
     const int b = i / G, g = i - b * G;
     const int nch = C >> 2, cpg4 = (C / G) >> 2;
-    const int64_t r0 = (int64_t)b * HW, r1 = r0 + HW;
-    const int t0 = (int)(r0 / tile_rows), t1 = (int)((r1 - 1) / tile_rows);
+    const int nblk = HW / tile_rows;
+    const float* pb = partial + ((int64_t)b * nblk * nch + g * cpg4) * 2;
     double s = 0.0, q = 0.0;
-    for (int t = t0 + lane; t <= t1; t += 64) {
-        const int cls = ((int64_t)t * tile_rows / HW == b) ? 0 : 1;
-        const float* e = partial + (((int64_t)t * 2 + cls) * nch + g * cpg4) * 2;
+    for (int t = lane; t < nblk; t += 64) {
+        const float* e = pb + (int64_t)t * nch * 2;
         for (int c = 0; c < cpg4; ++c) {
             s += (double)e[2 * c];
             q += (double)e[2 * c + 1];
@@ -474,7 +473,7 @@ extern "C" int advgrpo_groupnorm_nhwc_f16x2(const float* x, void* y3, double* st
     const int ppb = advgrpo_groupnorm_ppb(HW), nchunks = (HW + ppb - 1) / ppb;
     float* mr = reinterpret_cast<float*>(stats + (size_t)B * nchunks * G * 2);
     if (tile_partial) {     // the statistics came out of the producing convolution's epilogue: no pass over x for them
-        ADVGRPO_CHECK(tile_rows > 0 && tile_rows <= HW, "groupnorm_f16x2: tile_rows %d (HW = %d)", tile_rows, HW);
+        ADVGRPO_CHECK(tile_rows > 0 && HW % tile_rows == 0, "groupnorm_f16x2: tile_rows %d must divide HW = %d", tile_rows, HW);
         hipLaunchKernelGGL(groupnorm_finalize_tiles_kernel, dim3(B * G), dim3(64), 0, s, tile_partial, mr, B, G, C, HW, tile_rows,
                            (double)HW * (C / G), eps);
     } else {

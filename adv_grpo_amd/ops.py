@@ -587,11 +587,11 @@ def split_f16x2(x, prescale=1.0, bias=None):
     return out
 
 
-CONV_F16X2_TILE_ROWS = 192        # ADVGRPO_CONV_F16X2_TILE_ROWS
+CONV_F16X2_STAT_ROWS = 16         # ADVGRPO_CONV_F16X2_STAT_ROWS
 
 
 def groupnorm_nhwc_f16x2(x, weight, bias, groups=32, eps=1e-6, silu=False, prescale=1.0, tile_stats=None):
-    """tile_stats: the per-tile sums conv3x3_f16x2(..., gn_stats=True) attached to x (`x.gn_tile_stats`): the statistics kernel's
+    """tile_stats: the block sums conv3x3_f16x2(..., gn_stats=True) attached to x (`x.gn_tile_stats`): the statistics kernel's
     pass over x is skipped."""
     lib = _lib.load()
     assert x.dtype == torch.float32 and x.is_contiguous() and weight.dtype == torch.float32
@@ -599,16 +599,16 @@ def groupnorm_nhwc_f16x2(x, weight, bias, groups=32, eps=1e-6, silu=False, presc
     HW = x.numel() // (B * C)
     y = torch.empty(*x.shape[:-1], 3 * C, dtype=torch.bfloat16, device=x.device)
     stats = torch.empty(lib.advgrpo_groupnorm_scratch_bytes(B, HW, groups) // 8, dtype=torch.float64, device=x.device)
-    assert tile_stats is None or (tile_stats.dtype == torch.float32 and tile_stats.numel() == -(-B * HW // CONV_F16X2_TILE_ROWS) * C)
+    assert tile_stats is None or (tile_stats.dtype == torch.float32 and tile_stats.numel() == B * HW // CONV_F16X2_STAT_ROWS * (C // 4) * 2)
     _lib.check(lib.advgrpo_groupnorm_nhwc_f16x2(x.data_ptr(), y.data_ptr(), stats.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), B, HW, C,
                                                 groups, float(eps), int(silu), float(prescale), _lib.ptr(tile_stats),
-                                                CONV_F16X2_TILE_ROWS, _lib.stream_ptr()))
+                                                CONV_F16X2_STAT_ROWS, _lib.stream_ptr()))
     return y
 
 
 def conv3x3_f16x2(x2, w16, bias=None, upsample=False, act=None, residual=None, alpha=1.0, gn_stats=False):
     """x2 NHWC fp16-pair rows [B,Hin,Win,3C]; w16 [Cout, 9C] fp16 (k = (ky*3+kx)*C + c); bias / residual f32 -> f32 [B,Hout,Wout,Cout].
-    gn_stats: the epilogue also leaves the per-tile sums of the GroupNorm that reads the output, as `y.gn_tile_stats` (an attribute
+    gn_stats: the epilogue also leaves the 16-pixel x 4-channel block sums of the GroupNorm that reads the output, as `y.gn_tile_stats` (an attribute
     of THIS tensor object: views do not carry it)."""
     lib = _lib.load()
     B, Hin, Win, Cin3 = x2.shape
@@ -619,8 +619,8 @@ def conv3x3_f16x2(x2, w16, bias=None, upsample=False, act=None, residual=None, a
     assert residual is None or (residual.dtype == torch.float32 and residual.is_contiguous())
     y = torch.empty(B, Hout, Wout, Cout, dtype=torch.float32, device=x2.device)
     part = None
-    if gn_stats and Hout * Wout >= CONV_F16X2_TILE_ROWS:
-        part = torch.empty(-(-B * Hout * Wout // CONV_F16X2_TILE_ROWS), 2, Cout // 4, 2, dtype=torch.float32, device=x2.device)
+    if gn_stats and (Hout * Wout) % CONV_F16X2_STAT_ROWS == 0:
+        part = torch.empty(B * Hout * Wout // CONV_F16X2_STAT_ROWS, Cout // 4, 2, dtype=torch.float32, device=x2.device)
     with _Prof(B * Hout * Wout, Cout, 2 * 3 * Cin3, 1, 1):                # two products per tap over C channels: K_eff = 2 x 9 C
         _lib.check(lib.advgrpo_conv3x3_nhwc_f16x2(_lib.ptr(x2), _lib.ptr(w16), y.data_ptr(), B, Hout, Wout, Cin3, Cout, int(upsample),
                                                   _lib.ptr(bias), ACT[act], _lib.ptr(residual), zero_page(x2.device).data_ptr(),

@@ -284,11 +284,11 @@ int advgrpo_conv3x3_nhwc_x3(const void* x3, const void* w3, float* y, int B, int
  * the fp16 range, alpha = 1 / s multiplies the accumulators back (exact).  Everything between two products stays f32.
  *   groupnorm_nhwc_f16x2 / split_f16x2: the producers (GroupNorm + SiLU of a resnet, the plain split in front of an upsampler);
  *   conv3x3_nhwc_f16x2: Cout >= 128, bias / residual / y f32.
- * GroupNorm statistics without a pass over the activations: gn_partial (optional; ceil(B Hout Wout / 192) * 2 * (Cout / 4) * 2
- * floats) receives, per 192-pixel tile of the convolution's output and per 4 output channels, {sum, sum of squares} split by
- * image (a tile straddles at most two); the GroupNorm that reads y takes them as tile_partial with tile_rows = 192
- * (ADVGRPO_CONV_F16X2_TILE_ROWS) and skips its statistics kernel.  Deterministic (fixed summation order, no atomics). */
-#define ADVGRPO_CONV_F16X2_TILE_ROWS 192
+ * GroupNorm statistics without a pass over the activations: gn_partial (optional; (B Hout Wout / 16) * (Cout / 4) * 2 floats;
+ * needs 16 | Hout Wout) receives {sum, sum of squares} of every block of 16 consecutive output pixels x 4 consecutive output
+ * channels; the GroupNorm that reads y takes them as tile_partial with tile_rows = 16 (ADVGRPO_CONV_F16X2_STAT_ROWS) and skips its
+ * statistics kernel.  Deterministic (fixed summation order, no atomics) and independent of the image's position in the batch. */
+#define ADVGRPO_CONV_F16X2_STAT_ROWS 16
 int advgrpo_groupnorm_nhwc_f16x2(const float* x, void* y3, double* stats, const float* weight, const float* bias, int B,
                                  int HW, int C, int G, float eps, int silu, float prescale, const float* tile_partial,
                                  int tile_rows, void* stream);
