@@ -18,6 +18,9 @@ python $R/scripts/rocpd_stats.py $O/kt_c5/x_results.db $O/kernel_stats_c5.md > /
 rocprofv3 --kernel-trace --stats -d $O/kt_c3 -o x -- python $R/bench.py --config c3 --steps 1 --warmup 1 --no-pricing > $O/bench_c3_prof.json 2>/dev/null
 python $R/scripts/rocpd_stats.py $O/kt_c3/x_results.db $O/kernel_stats_c3_with_epoch_legs.md > /dev/null
 python $R/scripts/bench_attention_d128.py 10 > $O/attention_d128.txt 2>/dev/null
+python $R/scripts/bench_attention_bwd.py > $O/attention_bwd.txt 2>/dev/null
+GRAFT_REPO_ROOT=$R bash $R/scripts/probes/pmc_attention_bwd.sh 2 >> $O/attention_bwd.txt 2>/dev/null
+cd /tmp
 # 2. kernel tables: rollout (timed configuration only) and one G-step micro-batch
 rocprofv3 --kernel-trace --stats -d $O/kt_c2 -o x -- python $R/bench.py $FAST > $O/bench_c2_prof.json 2>/dev/null
 python $R/scripts/rocpd_stats.py $O/kt_c2/x_results.db $O/kernel_stats_c2.md > /dev/null
