@@ -30,7 +30,7 @@
 //   * P stays in registers as the B operand of P V (the key order inside a 16-deep MFMA step is permuted consistently
 //     on the P side and on the V side, which a sum over keys does not see); V^T fragments by ds_read_b64_tr_b16.
 //
-// Layout: workgroup = 4 waves = 128 queries of one (batch, head), two workgroups per CU (2 waves per SIMD, <= 256 VGPRs);
+// Layout: workgroup = 4 waves = 128 queries of one (batch, head), three workgroups per CU (3 waves per SIMD, <= 168 VGPRs);
 // K and V tiles of 64 keys arrive by LDS-DMA into two 3-slot rings (K runs two tiles ahead of V: iteration j multiplies
 // K[j+1] and V[j-1]), requested two iterations ahead, counted s_waitcnt + ONE barrier per tile.  Swizzles (source side of
 // the DMA, undone on the read): K chunk c of row r at LDS row r ^ ((r >> 4) & 1), slot c ^ (r & 7) -- the 16 rows of a
@@ -80,7 +80,10 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void attention_fwd_pipe_kernel(const AttnParams p) {
+// (three workgroups per CU since round 4: 168 VGPRs + 32 bytes of scratch outside the main loop against 180 / 0 at two -- the 3840
+// workgroups of the joint attention (16 x 24 x 1229) are exactly five rounds of 768 instead of seven and a half of 512: 219 vs 226 - 234 us,
+// S = 1370: 73 - 75 vs 77 - 79, S = 4301: 1.92 vs 1.98 ms, S = 1024 unchanged; 3 x 48 KiB of LDS)
+__global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnParams p) {
     constexpr int HD = 64, TILE_B = ATT_KB * 128;             // 8 KiB per K or V tile
     __shared__ __attribute__((aligned(1024))) char smem[6 * TILE_B];
     __shared__ int wg_flag[4];

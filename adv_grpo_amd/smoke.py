@@ -49,7 +49,7 @@ def run():
 def _matrix_unit(dev, g):
     """The kernels that carry the FLOPs, one small launch each, against fp32 torch arithmetic of the same operands (the
     oracle's formulas): the eight-phase 256 x 256 GEMM as a PAIRED launch with the bias + QK-norm epilogue, the pipelined
-    head-dim-64 attention, the head-dim-128 attention, and the split-bf16 3 x 3 convolution.  A wrong MFMA operand order, a
+    head-dim-64 attention forward and backward, the head-dim-128 attention, and the split-bf16 3 x 3 convolution.  A wrong MFMA operand order, a
     broken LDS swizzle or a mis-counted DMA wait fails here."""
     from adv_grpo_amd import _lib, ops
     from oracle import mmdit as o_m
@@ -92,6 +92,20 @@ def _matrix_unit(dev, g):
         r = torch.nn.functional.scaled_dot_product_attention(heads(q), heads(k), heads(v)).transpose(1, 2).reshape(1, S_att, Hh * hd)
         err = (o.cpu().float() - r).abs().max().item()
         assert err < 2e-2, f"attention head dim {hd}: max error {err}"
+        if hd == 64:      # the pipelined backward kernels (dQ and dK / dV) against autograd of the same fp32 attention
+            lse = torch.empty(1, Hh, S_att, dtype=torch.float32, device=dev)
+            o = ops.attention(dq[..., :Hh * hd], dq[..., Hh * hd:2 * Hh * hd], dq[..., 2 * Hh * hd:], Hh, lse=lse)
+            d_o = rnd(1, S_att, Hh * hd).to(bf16)
+            dd_o, grads = d(d_o), torch.zeros(1, S_att, 3 * Hh * hd, dtype=bf16, device=dev)
+            ops.attention_bwd(dq[..., :Hh * hd], dq[..., Hh * hd:2 * Hh * hd], dq[..., 2 * Hh * hd:], o, dd_o, lse, Hh,
+                              grads[..., :Hh * hd], grads[..., Hh * hd:2 * Hh * hd], grads[..., 2 * Hh * hd:])
+            leaf = [t.float().clone().requires_grad_(True) for t in (q, k, v)]
+            with torch.enable_grad():
+                r = torch.nn.functional.scaled_dot_product_attention(*(heads(t) for t in leaf)).transpose(1, 2).reshape(1, S_att, Hh * hd)
+                r.backward(d_o.float())
+            want = torch.cat([t.grad for t in leaf], dim=-1)
+            rel = ((grads.cpu().float() - want).norm() / want.norm()).item()
+            assert rel < 2e-2, f"attention backward: relative error {rel}"
     # ---- split-bf16 ("fp32-equivalent") 3 x 3 convolution, one 16 x 24 image of 64 -> 128 channels
     x = rnd(1, 16, 24, 64)
     wc, bc = rnd(128, 64, 3, 3, k=(64 * 9) ** -0.5), rnd(128, k=0.1)
