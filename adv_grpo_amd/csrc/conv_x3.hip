@@ -78,10 +78,15 @@ __device__ __forceinline__ void x3_tie(bf16x8_t (&a)[N]) {
 // [hi | unwritten | lo] rows, weights as ONE fp16 piece per tap ([Cout, 9 C], no hi / lo), and a product is x_hi w + x_lo w on
 // v_mfma_f32_16x16x32_f16: two MFMA products instead of three, half the weight bytes through L2 -> LDS (two thirds of this
 // kernel's bytes are weights), the same pipeline.  p.alpha undoes the power-of-two pre-scale of un-normalised inputs (fp16 range).
+// PIECE = 2 ("bf16x2"): the same two-product form for weights that are EXACT in bf16 (the released Qwen-Image VAE is a bf16
+// checkpoint): activations as the bf16 pair of the three-product path in the same [hi | unwritten | lo] rows (16 significant bits),
+// weights as ONE bf16 piece per tap, x_hi w + x_lo w on v_mfma_f32_16x16x32_bf16 -- the three-product form would multiply by a
+// weight "lo" that is identically zero.
 // DBG (experiments build only, scripts/probes/x3_decompose.sh): 1 = no DMA after the prologue, 2 = no MFMAs, 3 = fragments read
 // once -- WRONG results, used to price the three activities of the k loop against each other
-template <int X3_WM, int X3_WN, int DBG = 0, bool F16 = false>
+template <int X3_WM, int X3_WN, int DBG = 0, int PIECE = 0>
 __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const GemmParams p) {
+    constexpr bool F16 = PIECE != 0;                  // one-piece weights, two products (1: fp16 pieces; 2: bf16 pieces)
     constexpr int WPI = F16 ? 1 : 2;                  // weight pieces per tap (DMA instructions per 8 output channels)
     constexpr int NW = X3_WM * X3_WN, TM = X3_BM / X3_WM, TN = X3_BN / X3_WN, FM = TM / 16, FN = TN / 16;
     constexpr int XI = (X3_XINST + NW - 1) / NW;     // pixel-piece DMA instructions per wave (the last one on some waves only)
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-                    if constexpr (F16) {
+                    if constexpr (PIECE == 1) {
                         typedef _Float16 x3_f16x8 __attribute__((ext_vector_type(8)));
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(x3_f16x8, b[j]), __builtin_bit_cast(x3_f16x8, a[i]),
                                                                            acc[i][j], 0, 0, 0);
@@ -388,18 +393,21 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
 }  // namespace
 
 // fp16 pair activations x one-piece fp16 weights: p as filled by advgrpo_conv3x3_nhwc_f16x2 (Cin = 3C, lda = 3C, ldw = 9C, f32_io)
-int conv3x3_f16x2_launch(const GemmParams& p, hipStream_t s) {
+int conv3x3_f16x2_launch(const GemmParams& p, hipStream_t s, bool bf16_pieces) {
     ADVGRPO_CHECK(p.conv && p.f32_io && p.Cin % 192 == 0 && p.zero_page && p.batch == 1 && p.splitk == 1, "conv3x3_f16x2: bad parameter block");
     constexpr int WM = X3_GRID_M, WN = X3_GRID_N;
     static bool attr_set = false;
     if (!attr_set) {
-        ADVGRPO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<WM, WN, 0, true>),
+        ADVGRPO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<WM, WN, 0, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) == hipSuccess &&
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<WM, WN, 0, 2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) == hipSuccess,
                       "conv3x3_f16x2: %d bytes of LDS refused", X3_LDS);
         attr_set = true;
     }
     const int tiles = ((p.M + X3_BM - 1) / X3_BM) * ((p.N + X3_BN - 1) / X3_BN);
-    hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, true>), dim3(tiles), dim3(64 * WM * WN), X3_LDS, s, p);
+    if (bf16_pieces) hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, 2>), dim3(tiles), dim3(64 * WM * WN), X3_LDS, s, p);
+    else hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, 1>), dim3(tiles), dim3(64 * WM * WN), X3_LDS, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

@@ -467,9 +467,9 @@ extern "C" int advgrpo_conv3x3_nhwc(const void* x, const void* w, void* y, int o
 
 /* the same convolution over split-bf16 operands (vae.hip: split8): x3 [B, Hin, Win, Cin3] bf16 with Cin3 = 3*C laid out
  * [hi | hi | lo], w3 [Cout, 9*Cin3] with each tap's channels [hi | lo | hi]; bias / residual / y are f32 */
-extern "C" int advgrpo_conv3x3_nhwc_f16x2(const void* x2, const void* w16, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
-                                          int upsample, const float* bias, int act, const float* residual, const void* zero_page,
-                                          float alpha, float* gn_partial, void* stream) {
+static int conv3x3_two_products(const void* x2, const void* w16, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
+                                int upsample, const float* bias, int act, const float* residual, const void* zero_page,
+                                float alpha, float* gn_partial, void* stream, bool bf16_pieces) {
     GemmParams p{};
     p.A = (const bf16_t*)x2; p.W = (const bf16_t*)w16; p.C = y;
     p.lda = Cin3; p.ldw = 3 * (int64_t)Cin3; p.ldc = Cout; p.out_dtype = ADVGRPO_F32;      // weights [Cout, 9 C], C = Cin3 / 3
@@ -485,7 +485,19 @@ extern "C" int advgrpo_conv3x3_nhwc_f16x2(const void* x2, const void* w16, float
     ADVGRPO_CHECK(x2 && w16 && y && zero_page, "conv3x3_f16x2: null pointer");
     ADVGRPO_CHECK(!gn_partial || ((Hout * Wout) % 16 == 0 && Cout % 4 == 0), "conv3x3_f16x2: block sums need 16 | Hout Wout");
     ADVGRPO_CHECK(Cin3 % 192 == 0 && Cout >= 128, "conv3x3_f16x2: Cin3 must be 3 x (a multiple of 64), Cout >= 128 (Cin3=%d Cout=%d)", Cin3, Cout);
-    return conv3x3_f16x2_launch(p, as_stream(stream));
+    return conv3x3_f16x2_launch(p, as_stream(stream), bf16_pieces);
+}
+
+extern "C" int advgrpo_conv3x3_nhwc_f16x2(const void* x2, const void* w16, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
+                                          int upsample, const float* bias, int act, const float* residual, const void* zero_page,
+                                          float alpha, float* gn_partial, void* stream) {
+    return conv3x3_two_products(x2, w16, y, B, Hout, Wout, Cin3, Cout, upsample, bias, act, residual, zero_page, alpha, gn_partial, stream, false);
+}
+
+extern "C" int advgrpo_conv3x3_nhwc_bf16x2(const void* x2, const void* w16, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
+                                           int upsample, const float* bias, int act, const float* residual, const void* zero_page,
+                                           float alpha, float* gn_partial, void* stream) {
+    return conv3x3_two_products(x2, w16, y, B, Hout, Wout, Cin3, Cout, upsample, bias, act, residual, zero_page, alpha, gn_partial, stream, true);
 }
 
 extern "C" int advgrpo_conv3x3_nhwc_x3(const void* x3, const void* w3, float* y, int B, int Hout, int Wout, int Cin3,

@@ -393,6 +393,37 @@ __global__ void latents_to_nhwc_kernel(const void* __restrict__ z, int z_dt, bf1
     }
 }
 
+// Qwen-Image VAE: de-normalise the latents per channel (z / inv_std + mean, the pipeline's arithmetic) and apply the 1x1x1
+// post_quant_conv (y[o] = bias[o] + sum_c P[o][c] z'[c], f32, c ascending), NCHW -> NHWC padded to Cpad channels.  The latent
+// tensor is 2 MB per 1024^2 image: one thread per output element, the C strided reads of a pixel hit L2.
+template <bool X3>
+__global__ void latents_mix_to_nhwc_kernel(const void* __restrict__ z, int z_dt, bf16_t* __restrict__ out, int B, int C, int H, int W,
+                                           int Cpad, const float* __restrict__ inv_std, const float* __restrict__ mean,
+                                           const float* __restrict__ P, const float* __restrict__ bias) {
+    const int64_t total = (int64_t)B * H * W * Cpad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int o = i % Cpad;
+        const int64_t pix = i / Cpad;
+        const int w = pix % W, h = (pix / W) % H, b = pix / ((int64_t)W * H);
+        float v = 0.f;
+        if (o < C) {
+            v = bias[o];
+            for (int c = 0; c < C; ++c) {
+                const int64_t src = (((int64_t)b * C + c) * H + h) * W + w;
+                float t = z_dt == ADVGRPO_BF16 ? bf2f(reinterpret_cast<const bf16_t*>(z)[src]) : reinterpret_cast<const float*>(z)[src];
+                t = t / inv_std[c] + mean[c];
+                v = __builtin_fmaf(P[o * C + c], t, v);
+            }
+        }
+        if constexpr (X3) {
+            const float hh = round_bf16(v);
+            bf16_t* row = out + pix * 3 * Cpad + o;
+            row[0] = f2bf(hh); row[Cpad] = f2bf(hh); row[2 * Cpad] = f2bf(v - hh);
+        } else
+        out[i] = f2bf(v);
+    }
+}
+
 // y NHWC [B,H,W,ldc] (bf16 or f32; channels 0..2 used) -> image NCHW f32 [B,3,H,W] = clamp(y/2+0.5, 0, 1)
 __global__ void image_postprocess_kernel(const void* __restrict__ y, int y_dt, int ldc, float* __restrict__ img, int B,
                                          int H, int W) {
@@ -488,6 +519,71 @@ extern "C" int advgrpo_groupnorm_nhwc_f16x2(const float* x, void* y3, double* st
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(groupnorm_apply_kernel<float>, dim3((int)blocks), dim3(256), 0, s, x, (bf16_t*)y3, mr, weight, bias,
                        HW, C, G, silu, 2, total8, prescale);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+// Per-pixel RMS norm over the channel axis (the Qwen-Image VAE's QwenImageRMS_norm = F.normalize(x, dim=channels) * sqrt(C) * gamma),
+// optional SiLU.  x: [pixels, C] f32 or bf16, gamma f32 [C] (zero for padding channels).  A pixel is held by L = 16 / 32 / 64 lanes
+// (8 channels per lane; lanes past C / 8 idle), its sum of squares reduced by a fixed xor tree over those lanes: one read, one write.
+// OUT 0: bf16 [pixels, C]; 1: split-bf16 [hi | hi | lo]; 2: [hi | unwritten | lo] (conv3x3_x3 with Cout >= 128).
+template <typename T, int L>
+__global__ __launch_bounds__(256) void rmsnorm_pixels_kernel(const T* __restrict__ x, bf16_t* __restrict__ y,
+                                                             const float* __restrict__ gamma, int64_t pixels, int C, float mult,
+                                                             int silu, int out_mode) {
+    const int sub = threadIdx.x % L, c8n = C >> 3;
+    const int64_t ppb = 256 / L;
+    float g8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (sub < c8n) load8(gamma + sub * 8, g8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g8[k] *= mult;
+    for (int64_t pix = (int64_t)blockIdx.x * ppb + threadIdx.x / L; pix < pixels; pix += (int64_t)gridDim.x * ppb) {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (sub < c8n) load8(x + pix * C + sub * 8, v);
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ss = __builtin_fmaf(v[k], v[k], ss);
+#pragma unroll
+        for (int o = 1; o < L; o <<= 1) ss += __shfl_xor(ss, o, 64);
+        const float inv = 1.0f / fmaxf(__builtin_sqrtf(ss), 1e-12f);
+        if (sub >= c8n) continue;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float t = v[k] * inv * g8[k];
+            if (silu) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+            v[k] = t;
+        }
+        if (out_mode == 0) {
+            *reinterpret_cast<uint4*>(y + pix * C + sub * 8) = pack8v(v);
+        } else {
+            uint4 hi, lo;
+            split8(v, hi, lo);
+            bf16_t* row = y + pix * 3 * C + sub * 8;
+            *reinterpret_cast<uint4*>(row) = hi;
+            if (out_mode == 1) *reinterpret_cast<uint4*>(row + C) = hi;
+            *reinterpret_cast<uint4*>(row + 2 * C) = lo;
+        }
+    }
+}
+
+extern "C" int advgrpo_rmsnorm_nhwc(const void* x, int x_dtype, void* y, const float* gamma, int64_t pixels, int C, float mult,
+                                    int silu, int out_mode, void* stream) {
+    ADVGRPO_CHECK(x && y && gamma && pixels > 0, "rmsnorm_nhwc: null pointer");
+    ADVGRPO_CHECK(C % 8 == 0 && C > 0 && C <= 512 && out_mode >= 0 && out_mode <= 2 && (x_dtype == ADVGRPO_F32 || x_dtype == ADVGRPO_BF16),
+                  "rmsnorm_nhwc: unsupported shape / mode (C=%d, out_mode=%d, dtype=%d)", C, out_mode, x_dtype);
+    hipStream_t s = as_stream(stream);
+    const int L = C <= 128 ? 16 : C <= 256 ? 32 : 64;
+    int64_t blocks = (pixels + 256 / L - 1) / (256 / L);
+    if (blocks > 16384) blocks = 16384;
+#define ADVGRPO_RMS_LAUNCH(T, LL)                                                                                                  \
+    hipLaunchKernelGGL((rmsnorm_pixels_kernel<T, LL>), dim3((int)blocks), dim3(256), 0, s, (const T*)x, (bf16_t*)y, gamma, pixels, C, \
+                       mult, silu, out_mode)
+    if (x_dtype == ADVGRPO_F32) {
+        if (L == 16) ADVGRPO_RMS_LAUNCH(float, 16); else if (L == 32) ADVGRPO_RMS_LAUNCH(float, 32); else ADVGRPO_RMS_LAUNCH(float, 64);
+    } else {
+        if (L == 16) ADVGRPO_RMS_LAUNCH(bf16_t, 16); else if (L == 32) ADVGRPO_RMS_LAUNCH(bf16_t, 32); else ADVGRPO_RMS_LAUNCH(bf16_t, 64);
+    }
+#undef ADVGRPO_RMS_LAUNCH
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
@@ -591,6 +687,19 @@ extern "C" int advgrpo_latents_to_nhwc_x3(const void* z, int z_dtype, void* out3
     ADVGRPO_CHECK(z && out3 && B > 0 && C > 0 && Cpad >= C, "latents_to_nhwc_x3: bad argument");
     hipLaunchKernelGGL(latents_to_nhwc_kernel<true>, dim3(1024), dim3(256), 0, as_stream(stream), z, z_dtype, (bf16_t*)out3, B,
                        C, H, W, Cpad, scaling_factor, shift_factor);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_latents_mix_to_nhwc(const void* z, int z_dtype, void* out, int x3, int B, int C, int H, int W, int Cpad,
+                                           const float* inv_std, const float* mean, const float* P, const float* bias, void* stream) {
+    ADVGRPO_CHECK(z && out && inv_std && mean && P && bias && B > 0 && C > 0 && Cpad >= C, "latents_mix_to_nhwc: bad argument");
+    if (x3)
+        hipLaunchKernelGGL(latents_mix_to_nhwc_kernel<true>, dim3(1024), dim3(256), 0, as_stream(stream), z, z_dtype, (bf16_t*)out, B, C,
+                           H, W, Cpad, inv_std, mean, P, bias);
+    else
+        hipLaunchKernelGGL(latents_mix_to_nhwc_kernel<false>, dim3(1024), dim3(256), 0, as_stream(stream), z, z_dtype, (bf16_t*)out, B, C,
+                           H, W, Cpad, inv_std, mean, P, bias);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

@@ -76,3 +76,25 @@ class QwenMMDiTConfig:  # Qwen/Qwen-Image transformer (diffusers QwenImageTransf
     @property
     def dim(self):
         return self.num_heads * self.head_dim
+
+
+@dataclass
+class QwenVaeConfig:  # Qwen/Qwen-Image vae (diffusers AutoencoderKLQwenImage: Wan-2.1-style causal 3-D VAE; BASELINE config 5)
+    base_dim: int = 96
+    z_dim: int = 16
+    dim_mult: tuple = (1, 2, 4, 4)
+    num_res_blocks: int = 2
+    latents_mean: tuple = (-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
+                           0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921)
+    latents_std: tuple = (2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
+                          3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160)
+
+    @property
+    def dims(self):
+        m = self.dim_mult
+        return [self.base_dim * u for u in (m[-1],) + tuple(reversed(m))]     # [384, 384, 384, 192, 96]
+
+    def up_block_io(self, i):
+        """(input width, output width, has upsampler) of decoder.up_blocks[i]: every upsampler halves the width."""
+        d = self.dims
+        return (d[i] if i == 0 else d[i] // 2), d[i + 1], i != len(self.dim_mult) - 1

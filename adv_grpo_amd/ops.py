@@ -576,6 +576,33 @@ def groupnorm_nhwc_x3(x, weight, bias, groups=32, eps=1e-6, silu=False, pair_onl
     return y
 
 
+def latents_mix_to_nhwc(z, cpad, inv_std, mean, P, bias, x3=False):
+    """Qwen-Image VAE: (z / inv_std + mean) through the 1x1 post_quant_conv (P [C,C], bias [C], f32) -> NHWC bf16 [B,H,W,cpad]
+    (x3: split rows [B,H,W,3 cpad])."""
+    lib = _lib.load()
+    B, C, H, W = z.shape
+    out = torch.empty(B, H, W, (3 if x3 else 1) * cpad, dtype=torch.bfloat16, device=z.device)
+    z = z.contiguous()
+    for t in (inv_std, mean, P, bias):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    _lib.check(lib.advgrpo_latents_mix_to_nhwc(_lib.ptr(z), _lib.dtype_code(z.dtype), out.data_ptr(), int(x3), B, C, H, W, cpad,
+                                               inv_std.data_ptr(), mean.data_ptr(), P.data_ptr(), bias.data_ptr(), _lib.stream_ptr()))
+    return out
+
+
+def rmsnorm_nhwc(x, gamma, mult, silu=False, out="bf16"):
+    """Per-pixel RMS norm over the last (channel) axis: x / max(||x||, 1e-12) * mult * gamma (+ SiLU).  x f32 or bf16 [..., C];
+    out "bf16" -> bf16 [..., C]; "x3" -> split rows [..., 3C] ([hi | hi | lo]); "x3pair" -> [hi | unwritten | lo]."""
+    lib = _lib.load()
+    assert x.is_contiguous() and gamma.dtype == torch.float32 and gamma.numel() == x.shape[-1]
+    C = x.shape[-1]
+    mode = {"bf16": 0, "x3": 1, "x3pair": 2}[out]
+    y = torch.empty(*x.shape[:-1], C if mode == 0 else 3 * C, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.advgrpo_rmsnorm_nhwc(x.data_ptr(), _lib.dtype_code(x.dtype), y.data_ptr(), gamma.data_ptr(), x.numel() // C, C,
+                                        float(mult), int(silu), mode, _lib.stream_ptr()))
+    return y
+
+
 # ---- "f16x2": fp16-exact decoder weights (include/advgrpo.h) -- fp16 pair activations, one-piece fp16 weights, two products
 def split_f16x2(x, prescale=1.0, bias=None):
     """f32 [..., K] (+ bias[K]) -> [..., 3K] 16-bit: thirds [f16 hi | unwritten | f16 lo] of prescale * x (prescale: a power of two)."""
@@ -606,14 +633,16 @@ def groupnorm_nhwc_f16x2(x, weight, bias, groups=32, eps=1e-6, silu=False, presc
     return y
 
 
-def conv3x3_f16x2(x2, w16, bias=None, upsample=False, act=None, residual=None, alpha=1.0, gn_stats=False):
+def conv3x3_f16x2(x2, w16, bias=None, upsample=False, act=None, residual=None, alpha=1.0, gn_stats=False, bf16_pieces=False):
     """x2 NHWC fp16-pair rows [B,Hin,Win,3C]; w16 [Cout, 9C] fp16 (k = (ky*3+kx)*C + c); bias / residual f32 -> f32 [B,Hout,Wout,Cout].
+    bf16_pieces: the "bf16x2" form -- x2 = bf16 [hi | unwritten | lo] rows, w16 one bf16 piece (weights exact in bf16).
     gn_stats: the epilogue also leaves the 16-pixel x 4-channel block sums of the GroupNorm that reads the output, as `y.gn_tile_stats` (an attribute
     of THIS tensor object: views do not carry it)."""
     lib = _lib.load()
     B, Hin, Win, Cin3 = x2.shape
     Cout = w16.shape[0]
-    assert w16.dtype == torch.float16 and w16.is_contiguous() and w16.shape[1] == 3 * Cin3
+    assert w16.dtype == (torch.bfloat16 if bf16_pieces else torch.float16) and w16.is_contiguous() and w16.shape[1] == 3 * Cin3
+    fn = lib.advgrpo_conv3x3_nhwc_bf16x2 if bf16_pieces else lib.advgrpo_conv3x3_nhwc_f16x2
     Hout, Wout = (Hin * 2, Win * 2) if upsample else (Hin, Win)
     assert bias is None or bias.dtype == torch.float32
     assert residual is None or (residual.dtype == torch.float32 and residual.is_contiguous())
@@ -622,9 +651,9 @@ def conv3x3_f16x2(x2, w16, bias=None, upsample=False, act=None, residual=None, a
     if gn_stats and (Hout * Wout) % CONV_F16X2_STAT_ROWS == 0:
         part = torch.empty(B * Hout * Wout // CONV_F16X2_STAT_ROWS, Cout // 4, 2, dtype=torch.float32, device=x2.device)
     with _Prof(B * Hout * Wout, Cout, 2 * 3 * Cin3, 1, 1):                # two products per tap over C channels: K_eff = 2 x 9 C
-        _lib.check(lib.advgrpo_conv3x3_nhwc_f16x2(_lib.ptr(x2), _lib.ptr(w16), y.data_ptr(), B, Hout, Wout, Cin3, Cout, int(upsample),
-                                                  _lib.ptr(bias), ACT[act], _lib.ptr(residual), zero_page(x2.device).data_ptr(),
-                                                  float(alpha), _lib.ptr(part), _lib.stream_ptr()))
+        _lib.check(fn(_lib.ptr(x2), _lib.ptr(w16), y.data_ptr(), B, Hout, Wout, Cin3, Cout, int(upsample),
+                      _lib.ptr(bias), ACT[act], _lib.ptr(residual), zero_page(x2.device).data_ptr(),
+                      float(alpha), _lib.ptr(part), _lib.stream_ptr()))
     if part is not None:
         y.gn_tile_stats = part
     return y

@@ -185,6 +185,47 @@ def vae_decoder_weights(cfg, seed=4321, fp16_checkpoint=False):
     return W
 
 
+def qwen_vae_decoder_weights(cfg, seed=2468, dtype=None):
+    """fp32 CPU weights keyed like diffusers AutoencoderKLQwenImage.state_dict() (post_quant_conv + decoder.*; the upsamplers'
+    `time_conv`, which a still image never runs, is left out).  3-D kernels [Co, Ci, kt, kh, kw]; dtype: round every tensor
+    through it (the released checkpoint is bf16)."""
+    g = _gen(seed)
+    W = {}
+
+    def conv3d(name, co, ci, k):
+        W[name + ".weight"] = _randn(co, ci, k, k, k, generator=g) / math.sqrt(ci * k * k)      # (only one temporal tap meets data)
+        W[name + ".bias"] = _randn(co, generator=g) * 0.1
+
+    def gamma(name, c, nd):
+        W[name + ".gamma"] = (1 + 0.1 * _randn(c, generator=g)).view(c, *([1] * nd))
+
+    def res(p, ci, co):
+        gamma(f"{p}.norm1", ci, 3); conv3d(f"{p}.conv1", co, ci, 3)
+        gamma(f"{p}.norm2", co, 3); conv3d(f"{p}.conv2", co, co, 3)
+        if ci != co:
+            conv3d(f"{p}.conv_shortcut", co, ci, 1)
+    d = cfg.dims
+    conv3d("post_quant_conv", cfg.z_dim, cfg.z_dim, 1)
+    conv3d("decoder.conv_in", d[0], cfg.z_dim, 3)
+    res("decoder.mid_block.resnets.0", d[0], d[0])
+    a = "decoder.mid_block.attentions.0"
+    gamma(f"{a}.norm", d[0], 2)
+    conv_(W, f"{a}.to_qkv", 3 * d[0], d[0], 1, g)
+    conv_(W, f"{a}.proj", d[0], d[0], 1, g)
+    res("decoder.mid_block.resnets.1", d[0], d[0])
+    for i in range(len(cfg.dim_mult)):
+        ci, co, up = cfg.up_block_io(i)
+        for j in range(cfg.num_res_blocks + 1):
+            res(f"decoder.up_blocks.{i}.resnets.{j}", ci if j == 0 else co, co)
+        if up:
+            conv_(W, f"decoder.up_blocks.{i}.upsamplers.0.resample.1", co // 2, co, 3, g)
+    gamma("decoder.norm_out", d[-1], 3)
+    conv3d("decoder.conv_out", 3, d[-1], 3)
+    if dtype is not None:
+        W = {k: v.to(dtype).float() for k, v in W.items()}
+    return W
+
+
 def _ln(W, name, d, g):
     W[name + ".weight"] = 1 + 0.1 * _randn(d, generator=g)
     W[name + ".bias"] = 0.1 * _randn(d, generator=g)

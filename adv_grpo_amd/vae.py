@@ -77,9 +77,13 @@ class AutoencoderKLDecoder:
         return self._conv(f"{p}.conv2", self._gn(f"{p}.norm2", h, True), residual=sc)
 
     def _attn(self, p, x):
+        return self._attn_core(p, self._gn(f"{p}.group_norm", x, False), x)
+
+    def _attn_core(self, p, h, x):
+        """Single-head attention over the H x W pixels of `x` given its normalised copy `h` (bf16 NHWC)."""
         B, H, W, C = x.shape
         T = H * W
-        h = self._gn(f"{p}.group_norm", x, False).view(B * T, C)
+        h = h.view(B * T, C)
         w = self.w
         q = ops.gemm(h, w[f"{p}.to_q.weight"], bias=w[f"{p}.to_q.bias"]).view(B, T, C)
         k = ops.gemm(h, w[f"{p}.to_k.weight"], bias=w[f"{p}.to_k.bias"]).view(B, T, C)
@@ -157,11 +161,15 @@ class AutoencoderKLDecoder:
         return self._conv_auto(f"{p}.conv2", h, gn=f"{p}.norm2", residual=sc)
 
     def _attn3(self, p, x):
+        return self._attn3_core(p, self._gn3(f"{p}.group_norm", x, False), x)
+
+    def _attn3_core(self, p, h3, x):
+        """The same over f32 `x` and its normalised copy as split rows `h3` [B,H,W,3C]."""
         B, H, W, C = x.shape
         T = H * W
         w = self.w
         f32 = torch.float32
-        h3 = self._gn3(f"{p}.group_norm", x, False).view(B * T, 3 * C)
+        h3 = h3.view(B * T, 3 * C)
         q3 = ops.split_x3(ops.gemm(h3, w[f"{p}.to_q.weight"], out_dtype=f32), 0, bias=w[f"{p}.to_q.bias"]).view(B, T, 3 * C)
         k3 = ops.split_x3(ops.gemm(h3, w[f"{p}.to_k.weight"], out_dtype=f32), 1, bias=w[f"{p}.to_k.bias"]).view(B, T, 3 * C)
         # V^T[b] = Wv . h[b]^T; the weight is the [hi|lo|hi] side, the activations the [hi|hi|lo] side: same three products

@@ -108,17 +108,17 @@ C5_TEXT_TOKENS = 128      # synthetic prompt length of the config-5 line (Qwen-I
 
 
 def build_c5(device, vae_mode="bf16x3"):
-    """BASELINE config 5's model set: the Qwen-Image MMDiT (60 blocks, 24 x 128, fp8 Linears), the SD3 VAE decoder standing in
-    for Qwen-Image's own (Wan-style) VAE -- said so in config.workload -- and the DINOv2-B/14 patch scorer + head."""
+    """BASELINE config 5's model set: the Qwen-Image MMDiT (60 blocks, 24 x 128, fp8 Linears), Qwen-Image's own VAE decoder (the
+    Wan-style causal 3-D VAE run on one frame, adv_grpo_amd/qwen_vae.py) and the DINOv2-B/14 patch scorer + head."""
     from adv_grpo_amd import synthetic, vit
-    from adv_grpo_amd.model_configs import DinoConfig, QwenMMDiTConfig, VaeConfig
+    from adv_grpo_amd.model_configs import DinoConfig, QwenMMDiTConfig, QwenVaeConfig
     from adv_grpo_amd.pipeline import SD3Pipeline
     from adv_grpo_amd.qwen_mmdit import QwenImageTransformer2DModel
-    from adv_grpo_amd.vae import AutoencoderKLDecoder
-    qcfg, vcfg, dcfg = QwenMMDiTConfig(), VaeConfig(), DinoConfig()
+    from adv_grpo_amd.qwen_vae import AutoencoderKLQwenImageDecoder
+    qcfg, vcfg, dcfg = QwenMMDiTConfig(), QwenVaeConfig(), DinoConfig()
     with synthetic.on_device(device):
         tr = QwenImageTransformer2DModel(synthetic.qwen_mmdit_weights(qcfg, 4242, dtype=torch.bfloat16), qcfg, device)
-        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(vcfg, 4321, fp16_checkpoint=True), vcfg, device, mode=vae_mode)
+        vae = AutoencoderKLQwenImageDecoder(synthetic.qwen_vae_decoder_weights(vcfg, 2468, dtype=torch.bfloat16), vcfg, device, mode=vae_mode)
         dino = vit.DinoV2(synthetic.dino_weights(dcfg, 888), dcfg, device)
         head = vit.DinoHead(synthetic.dino_head_weights(dcfg.hidden, 512, 999), device)
     tr.enable_fp8()
@@ -532,9 +532,11 @@ def main():
             qc, n_img = pipe.transformer.cfg, (RES // 16) ** 2
             f_fwd = flops_per_sample_forward(qc, n_img, C5_TEXT_TOKENS) / 1e12
             f_attn = 4.0 * qc.dim * (n_img + C5_TEXT_TOKENS) ** 2 * qc.num_layers / 1e12
-            per_image_tflop = 10 * 2 * f_fwd + 4 * 2.51 + 0.30
+            from adv_grpo_amd.qwen_vae import flops_decode
+            f_vae = flops_decode(pipe.vae.cfg, RES // 8, RES // 8) / 1e12        # Qwen-Image's own decoder on one frame: 4.71 TFLOP at 1024^2
+            per_image_tflop = 10 * 2 * f_fwd + f_vae + 0.30
             # seconds per image at the peaks of the units the work runs on: what "1.0 of the roofline" would be for this mix
-            mixed_peak_s = (10 * 2 * (f_fwd - f_attn)) / FP8_DENSE_PEAK_TFLOPS + (10 * 2 * f_attn + 4 * 2.51 + 0.30) / BF16_DENSE_PEAK_TFLOPS
+            mixed_peak_s = (10 * 2 * (f_fwd - f_attn)) / FP8_DENSE_PEAK_TFLOPS + (10 * 2 * f_attn + f_vae + 0.30) / BF16_DENSE_PEAK_TFLOPS
         # the decoder on its own (bf16 MFMA / f32 accumulate; the reference decodes in fp32, TP:481 -- DESIGN 3 deviation 1)
         # and the fp32-equivalent split-bf16 mode (3 bf16 MFMA products per f32 product, f32 between the kernels) beside it
         from adv_grpo_amd import synthetic
@@ -548,7 +550,11 @@ def main():
                 dec = pipe.vae
             else:
                 with synthetic.on_device(device):
-                    dec = AutoencoderKLDecoder(synthetic.vae_decoder_weights(pipe.vae.cfg, 4321, fp16_checkpoint=True), pipe.vae.cfg, device, mode=mode)
+                    if c5:
+                        from adv_grpo_amd.qwen_vae import AutoencoderKLQwenImageDecoder
+                        dec = AutoencoderKLQwenImageDecoder(synthetic.qwen_vae_decoder_weights(pipe.vae.cfg, 2468, dtype=torch.bfloat16), pipe.vae.cfg, device, mode=mode)
+                    else:
+                        dec = AutoencoderKLDecoder(synthetic.vae_decoder_weights(pipe.vae.cfg, 4321, fp16_checkpoint=True), pipe.vae.cfg, device, mode=mode)
             dec.decode_to_image(lat)
             torch.cuda.synchronize()
             tv = time.perf_counter()
@@ -656,8 +662,8 @@ def main():
                                     "per-token x per-channel scales, f32 accumulation; attention / norms / embedders bf16) 1024x1024 = 4096 packed "
                                     f"latent positions + {C5_TEXT_TOKENS} synthetic text tokens (3584-wide), 10 steps, CFG 4.5 as u + s (t - u) "
                                     "(the rollout function's combine, PF:640-642, not QwenImagePipeline's norm-rescaled one), G=8, SDE window 2 @ noise 0.8 on "
-                                    "the SD3 sigma table (shift 3), VAE decode (" + pipe.vae.mode + ") with the SD3 16-channel decoder standing in for "
-                                    "Qwen-Image's own VAE (not built), DINOv2-B/14 patch reward + head (RW:375-434), reward all-gather + group advantage")
+                                    "the SD3 sigma table (shift 3), VAE decode (" + pipe.vae.mode + ") with Qwen-Image's own decoder (AutoencoderKLQwenImage on one "
+                                    "frame: widths 384 / 192 / 96, per-pixel RMS norm), DINOv2-B/14 patch reward + head (RW:375-434), reward all-gather + group advantage")
                                    if c5 else (("BASELINE config 4 shapes: SD3.5-large (38 blocks, D=2432) LoRA-merged 1024x1024, 10 steps, CFG 4.5, "
                                     "G=4, SDE window 2 @ noise 0.8, VAE decode (" + pipe.vae.mode + "), fp32-equivalent PickScore reward (the OCR half of the reward is a "
                                     "host plugin outside the timed path), reward all-gather + group advantage") if c4 else

@@ -296,6 +296,26 @@ int advgrpo_split_f16x2(const float* x, const float* bias, void* out3, int64_t r
 int advgrpo_conv3x3_nhwc_f16x2(const void* x2, const void* w16, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
                                int upsample, const float* bias, int act, const float* residual, const void* zero_page,
                                float alpha, float* gn_partial, void* stream);
+/* Qwen-Image VAE decode, first step: latents [B,C,H,W] (f32 | bf16) de-normalised per channel (z / inv_std[c] + mean[c]: the
+ * pipeline's `latents / latents_std + latents_mean` with latents_std = 1 / std) and sent through the 1x1x1 `post_quant_conv`
+ * (P [C,C] row-major, bias [C]; f32) -> NHWC [B,H,W,Cpad] bf16 (x3 = 0) or split rows [B,H,W,3 Cpad] (x3 = 1), channels >= C zero.
+ * Replaces the head of AutoencoderKLQwenImage.decode behind the rollout's decode call (see advgrpo_rmsnorm_nhwc). */
+int advgrpo_latents_mix_to_nhwc(const void* z, int z_dtype, void* out, int x3, int B, int C, int H, int W, int Cpad,
+                                const float* inv_std, const float* mean, const float* P, const float* bias, void* stream);
+/* Per-pixel RMS norm over the channel axis of NHWC activations [pixels, C] (f32 or bf16 by x_dtype), f32 gamma[C] (+ SiLU):
+ * y = x / max(||x||_2, 1e-12) * mult * gamma.  Replaces diffusers' QwenImageRMS_norm (F.normalize(x, dim=1) * dim**0.5 * gamma)
+ * of the Qwen-Image VAE decoder behind the decode call of the rollout (the Qwen-Image twin of
+ * adv_grpo/diffusers_patch/sd3_pipeline_with_logprob_fast.py:667-670; BASELINE config 5, README.md:75); mult = sqrt(real
+ * channel count) when C is padded.  out_mode 0: bf16 [pixels, C]; 1: split rows [hi | hi | lo]; 2: [hi | unwritten | lo]. */
+int advgrpo_rmsnorm_nhwc(const void* x, int x_dtype, void* y, const float* gamma, int64_t pixels, int C, float mult, int silu,
+                         int out_mode, void* stream);
+/* "bf16x2": the same two-product convolution for weights that are EXACT in bf16 (the released Qwen-Image VAE is a bf16
+ * checkpoint; BASELINE config 5's decode, see advgrpo_rmsnorm_nhwc): x2 = split rows [hi | unwritten | lo] of bf16 pieces
+ * (advgrpo_split_bf16x3 order 2, advgrpo_rmsnorm_nhwc out_mode 2), w16 = ONE bf16 piece [Cout, 9 C]; x_hi w + x_lo w on the bf16
+ * MFMA.  Same arguments as advgrpo_conv3x3_nhwc_f16x2. */
+int advgrpo_conv3x3_nhwc_bf16x2(const void* x2, const void* w16, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
+                                int upsample, const float* bias, int act, const float* residual, const void* zero_page,
+                                float alpha, float* gn_partial, void* stream);
 /* GroupNorm over f32 NHWC [B,HW,C], f32 affine (+ SiLU) -> split output [B,HW,3C]; stats scratch as above.
  * pair_only != 0 leaves the middle third unwritten (order 2 above: output consumed by the Cout >= 128 3x3 kernel only) */
 int advgrpo_groupnorm_nhwc_x3(const float* x, void* y3, double* stats, const float* weight, const float* bias, int B,

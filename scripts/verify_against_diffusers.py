@@ -102,7 +102,7 @@ def main():
         vae = AutoencoderKL.from_pretrained(a.model, subfolder="vae", torch_dtype=torch.float32)
     vae = vae.to(dev).float().eval()
     vcfg = o_v.VaeConfig(scaling_factor=float(vae.config.scaling_factor), shift_factor=float(vae.config.shift_factor))
-    Wv = {k[len("decoder."):]: v.detach() for k, v in vae.state_dict().items() if k.startswith("decoder.")}
+    Wv = {k: v.detach() for k, v in vae.state_dict().items() if k.startswith("decoder.")}      # oracle/vae.py reads "decoder.*"
     lat = torch.randn(1, 16, 32, 32, device=dev)
     with torch.no_grad():
         z = lat / vcfg.scaling_factor + vcfg.shift_factor
@@ -111,6 +111,31 @@ def main():
     dmax = (img - ref_img).abs().max().item()
     print(f"AutoencoderKL.decode + postprocess('pt'): max abs {dmax:.2e}")
     ok &= dmax < 1e-4
+    # ---------------------------------------------------------------- Qwen-Image VAE decoder (BASELINE config 5; diffusers >= 0.35)
+    try:
+        from diffusers import AutoencoderKLQwenImage
+    except ImportError:
+        AutoencoderKLQwenImage = None
+        print("AutoencoderKLQwenImage: not in this diffusers (needs >= 0.35) -- oracle/qwen_vae.py stays unpinned here")
+    if AutoencoderKLQwenImage is not None:
+        from oracle import qwen_vae as o_q
+        qv = (AutoencoderKLQwenImage() if a.random else
+              AutoencoderKLQwenImage.from_pretrained("Qwen/Qwen-Image", subfolder="vae", torch_dtype=torch.float32)).to(dev).float().eval()
+        if a.random:
+            torch.manual_seed(5)
+            with torch.no_grad():
+                for prm in qv.parameters():
+                    prm.copy_(torch.randn_like(prm) * 0.05 + (1.0 if prm.dim() > 1 and prm.numel() == prm.shape[0] else 0.0))   # gammas near 1
+        qcfg = o_q.QwenVaeConfig(latents_mean=tuple(qv.config.latents_mean), latents_std=tuple(qv.config.latents_std))
+        Wq = {k: v.detach() for k, v in qv.state_dict().items() if k.startswith(("decoder.", "post_quant_conv.")) and "time_conv" not in k}
+        latq = torch.randn(1, 16, 24, 24, device=dev)
+        with torch.no_grad():
+            zq = o_q.denormalise(qcfg, latq[:, :, None])
+            ref_q = VaeImageProcessor(vae_scale_factor=8).postprocess(qv.decode(zq, return_dict=False)[0][:, :, 0], output_type="pt")
+            img_q = o_q.decode_to_image(Wq, qcfg, latq)
+        dq = (img_q - ref_q).abs().max().item()
+        print(f"AutoencoderKLQwenImage.decode (one frame) + postprocess('pt'): max abs {dq:.2e}")
+        ok &= dq < 1e-4
     print("PINNED: oracle/{scheduler,mmdit,vae}.py reproduce diffusers on this machine" if ok else "MISMATCH: see the lines above")
     return 0 if ok else 1
 
