@@ -88,6 +88,7 @@ SIGNATURES = {
                                           c_int, c_float, _P]),
     "advgrpo_rmsnorm_heads_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int64,
                                           c_int64, _P]),
+    "advgrpo_qk_norm_rope_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),
     "advgrpo_gate_mul": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, _P]),
     "advgrpo_sumsq_workspace_bytes": (c_int64, []),
     "advgrpo_sumsq_f32": (c_int, [_P, c_int64, _P, _P, _P]),

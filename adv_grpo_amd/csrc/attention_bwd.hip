@@ -59,7 +59,7 @@ extern "C" int advgrpo_attention_bwd(const void* q, const void* k, const void* v
                                      int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t bsq,
                                      int64_t bsk, int64_t bsv, int64_t bso, int64_t bsdo, int64_t bsdq, int B, int H,
                                      int Sq, int Skv, int head_dim, float scale, void* stream) {
-    ADVGRPO_CHECK(head_dim == 64, "attention_bwd: head_dim %d not supported (64)", head_dim);
+    ADVGRPO_CHECK(head_dim == 64 || head_dim == 128, "attention_bwd: head_dim %d not supported (64, 128)", head_dim);
     ADVGRPO_CHECK(q && k && v && o && d_o && lse && work && dq && dk && dv, "attention_bwd: null pointer");
     ADVGRPO_CHECK(B > 0 && H > 0 && Sq > 0 && Skv > 0, "attention_bwd: bad shape");
     ADVGRPO_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0 &&
@@ -77,6 +77,10 @@ extern "C" int advgrpo_attention_bwd(const void* q, const void* k, const void* v
     p.bsq = bsq; p.bsk = bsk; p.bsv = bsv; p.bso = bso; p.bsdo = bsdo; p.bsdq = bsdq;
     p.H = H; p.Sq = Sq; p.Skv = Skv; p.nb32 = (Sq + 31) / 32; p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
     hipStream_t s = as_stream(stream);
+    if (head_dim == 128) {
+        p.xcd_local = 1;
+        return attention_bwd_d128_launch(p, B, s);
+    }
     hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)(((int64_t)B * p.nb32 * 32 + 3) / 4)), dim3(256), 0, s, p, B);
     ADVGRPO_LAUNCH_CHECK();
     int xcd_local = 1;

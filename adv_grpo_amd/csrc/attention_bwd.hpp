@@ -21,5 +21,7 @@ struct AttnBwdParams {
 
 // dQ (DKDV = false) and dK / dV (true): software-pipelined kernels of attention_bwd_pipe.hip
 int attention_bwd_pipe_launch(const AttnBwdParams& p, int B, hipStream_t s);
+// head dim 128 (attention_bwd_d128.hip): its own delta kernel writes D[b,h,q] = sum_d O dO as a plain [B,H,Sq] array into p.vec
+int attention_bwd_d128_launch(const AttnBwdParams& p, int B, hipStream_t s);
 
 }  // namespace advgrpo

@@ -1,0 +1,242 @@
+// attention_bwd_d128.hip -- attention backward for head dim 128 on gfx950 (bf16 in/out, f32 math): the joint attention of the
+// Qwen-Image MMDiT (BASELINE config 5) in the G-step.
+//
+// Replaces autograd of F.scaled_dot_product_attention behind the transformer call of compute_log_prob
+// (scripts/train_sd3_fast_pickscore.py:233-267, loss.backward() :1165) for the Qwen-Image model the reference names but does not
+// ship (README.md:75, config/grpo.py:324,330).
+//
+// FIRST VERSION: correct, deterministic (no atomics; probabilities recomputed from the forward's base-2 log-sum-exp, the same
+// two-pass arithmetic as attention_bwd_pipe.hip) and simple -- v_mfma_f32_16x16x32_bf16, operand tiles staged through LDS by plain
+// loads with the next tile's global loads in flight during the products; NOT software-pipelined like the head-dim-64 kernel.
+//   dQ    (DKDV = false): a workgroup owns 64 queries (wave = 16) and streams the keys in tiles of 32:
+//           S^T = K Q^T, P^T = exp2(c S^T - L[q]), dP^T = V dO^T, dS^T = P^T (dP^T - D[q]), dQ^T += K^T dS^T
+//   dK/dV (DKDV = true):  a workgroup owns 64 keys and streams the queries:
+//           S = Q K^T, P = exp2(c S - L[q]), dP = dO V^T, dS = P (dP - D[q]), dV^T += dO^T P, dK^T += Q^T dS
+// In both, the OWN side is the B operand of every product (lane & 15 = own row), so the score tile comes out of the matrix unit
+// with C layout "column = own row, rows = streamed rows (lane >> 4) * 4 + r" -- which IS the B-operand layout of the accumulating
+// products once the contraction index is permuted (slot j of k-group g <-> streamed row 16 (j >> 2) + 4 g + (j & 3)): P and dS
+// never leave registers, and the A operand (the streamed tile transposed, [d][32 rows] in LDS) is read with the same permutation
+// as two 8-byte reads.
+#include "attention_bwd.hpp"
+
+namespace advgrpo {
+
+namespace {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int B8_OWN = 64;            // own rows per workgroup (16 per wave)
+constexpr int B8_ROWS = 32;           // streamed rows per tile
+constexpr int B8_HD = 128;
+constexpr int B8_RP = B8_HD + 8;      // row-major tile pitch (elements): 272 bytes, rows 4 banks apart
+constexpr int B8_TP = B8_ROWS + 8;    // transposed tile pitch (elements): 80 bytes
+constexpr int B8_ROWMAJ = B8_ROWS * B8_RP * 2, B8_TRANS = B8_HD * B8_TP * 2;      // bytes
+
+__device__ __forceinline__ uint32_t b8_pack(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+template <bool DKDV>
+__global__ __launch_bounds__(256) void attn_bwd_d128_kernel(const AttnBwdParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * B8_ROWMAJ + 2 * B8_TRANS + 2 * B8_ROWS * 4];
+    bf16_t* x0 = reinterpret_cast<bf16_t*>(smem);                        // streamed operand 0 (K | Q), row-major
+    bf16_t* x1 = reinterpret_cast<bf16_t*>(smem + B8_ROWMAJ);             // streamed operand 1 (V | dO), row-major
+    bf16_t* x0t = reinterpret_cast<bf16_t*>(smem + 2 * B8_ROWMAJ);        // operand 0 transposed [d][row]
+    bf16_t* x1t = reinterpret_cast<bf16_t*>(smem + 2 * B8_ROWMAJ + B8_TRANS);
+    float* lvec = reinterpret_cast<float*>(smem + 2 * B8_ROWMAJ + 2 * B8_TRANS);      // dK/dV: -L and -D of the tile's queries
+    float* dvec = lvec + B8_ROWS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kg = lane >> 4;
+    const int n_own = DKDV ? p.Skv : p.Sq, n_str = DKDV ? p.Sq : p.Skv;
+    int blk, h, b;
+    xcd_local_bh((n_own + B8_OWN - 1) / B8_OWN, p.H, (int)gridDim.x, p.xcd_local, blk, h, b);
+    const int own0 = blk * B8_OWN + wave * 16;
+    const int64_t bh = (int64_t)b * p.H + h;
+    const bf16_t* b0p = (DKDV ? p.k + (int64_t)b * p.bsk : p.q + (int64_t)b * p.bsq) + h * B8_HD;
+    const bf16_t* b1p = (DKDV ? p.v + (int64_t)b * p.bsv : p.d_o + (int64_t)b * p.bsdo) + h * B8_HD;
+    const int64_t ld_b0 = DKDV ? p.ldk : p.ldq, ld_b1 = DKDV ? p.ldv : p.lddo;
+    const bf16_t* s0p = (DKDV ? p.q + (int64_t)b * p.bsq : p.k + (int64_t)b * p.bsk) + h * B8_HD;
+    const bf16_t* s1p = (DKDV ? p.d_o + (int64_t)b * p.bsdo : p.v + (int64_t)b * p.bsv) + h * B8_HD;
+    const int64_t ld_s0 = DKDV ? p.ldq : p.ldk, ld_s1 = DKDV ? p.lddo : p.ldv;
+    const float* Lp = p.lse + bh * p.Sq;             // base-2 log-sum-exp of the scaled scores
+    const float* Dp = p.vec + bh * p.Sq;             // D[q] = sum_d O dO (attn_bwd_delta128_kernel)
+    const float c = p.scale_log2e;
+
+    // own-side B fragments: row own0 + col, k = d = ks * 32 + kg * 8 .. + 7
+    const int own_r = min(own0 + col, n_own - 1);
+    bf16x8_t b0[4], b1[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        b0[ks] = *reinterpret_cast<const bf16x8_t*>(b0p + (int64_t)own_r * ld_b0 + ks * 32 + kg * 8);
+        b1[ks] = *reinterpret_cast<const bf16x8_t*>(b1p + (int64_t)own_r * ld_b1 + ks * 32 + kg * 8);
+    }
+    float negL_own = 0.f, negD_own = 0.f;
+    if constexpr (!DKDV) { negL_own = -Lp[own_r]; negD_own = -Dp[own_r]; }
+
+    f32x4_t acc0[8], acc1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { acc0[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc1[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+    // tile loader: thread -> (row = tid >> 3, 16-byte chunks (tid & 7) and (tid & 7) + 8) of both operands
+    const int lrow = tid >> 3, lch = tid & 7;
+    uint4 g0[2], g1[2];
+    float gl = 0.f, gd = 0.f;
+    auto fetch = [&](int t) {
+        const int r = min(t * B8_ROWS + lrow, n_str - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            g0[i] = *reinterpret_cast<const uint4*>(s0p + (int64_t)r * ld_s0 + (lch + 8 * i) * 8);
+            g1[i] = *reinterpret_cast<const uint4*>(s1p + (int64_t)r * ld_s1 + (lch + 8 * i) * 8);
+        }
+        if constexpr (DKDV) {
+            if (tid < B8_ROWS) {
+                const int q = t * B8_ROWS + tid;
+                gl = q < n_str ? -Lp[q] : -INFINITY;       // a query past the end: P = 0 exactly
+                gd = q < n_str ? -Dp[q] : 0.f;
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = lch + 8 * i;
+            *reinterpret_cast<uint4*>(x0 + lrow * B8_RP + ch * 8) = g0[i];
+            *reinterpret_cast<uint4*>(x1 + lrow * B8_RP + ch * 8) = g1[i];
+            const uint32_t w0[4] = {g0[i].x, g0[i].y, g0[i].z, g0[i].w}, w1[4] = {g1[i].x, g1[i].y, g1[i].z, g1[i].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int d = ch * 8 + e;
+                x0t[d * B8_TP + lrow] = (bf16_t)((w0[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                if constexpr (DKDV) x1t[d * B8_TP + lrow] = (bf16_t)((w1[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+            }
+        }
+        if constexpr (DKDV) {
+            if (tid < B8_ROWS) { lvec[tid] = gl; dvec[tid] = gd; }
+        }
+    };
+
+    const int nt = (n_str + B8_ROWS - 1) / B8_ROWS;
+    fetch(0);
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();                      // everyone is done with the previous tile
+        commit();
+        __syncthreads();
+        if (t + 1 < nt) fetch(t + 1);         // in flight during the products
+
+        // ---- scores and dP of the two 16-row blocks of the tile
+        f32x4_t sc[2], dp[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            f32x4_t s = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(x0 + (rb * 16 + col) * B8_RP + ks * 32 + kg * 8);
+                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(x1 + (rb * 16 + col) * B8_RP + ks * 32 + kg * 8);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[ks], s, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[ks], d, 0, 0, 0);
+            }
+            sc[rb] = s; dp[rb] = d;
+        }
+        // ---- P and dS in registers: element (rb, r) belongs to streamed row rb * 16 + kg * 4 + r, own row `col`
+        float pv[8], ds[8];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sr = rb * 16 + kg * 4 + r;
+                float nl, nd;
+                if constexpr (DKDV) { nl = lvec[sr]; nd = dvec[sr]; }
+                else { nl = (t * B8_ROWS + sr < n_str) ? negL_own : -INFINITY; nd = negD_own; }      // a key past the end: P = 0
+                const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[rb][r], c, nl));
+                pv[rb * 4 + r] = pe;
+                ds[rb * 4 + r] = pe * (dp[rb][r] + nd);
+            }
+        uint4 dsw, pw;
+        dsw.x = b8_pack(ds[0], ds[1]); dsw.y = b8_pack(ds[2], ds[3]); dsw.z = b8_pack(ds[4], ds[5]); dsw.w = b8_pack(ds[6], ds[7]);
+        pw.x = b8_pack(pv[0], pv[1]); pw.y = b8_pack(pv[2], pv[3]); pw.z = b8_pack(pv[4], pv[5]); pw.w = b8_pack(pv[6], pv[7]);
+        const bf16x8_t dsf = __builtin_bit_cast(bf16x8_t, dsw), pf = __builtin_bit_cast(bf16x8_t, pw);
+        // ---- accumulating products: A = transposed streamed tile, rows d = db * 16 + col, k slots in the permuted order
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            const bf16_t* r0 = x0t + (db * 16 + col) * B8_TP + kg * 4;
+            uint4 aw;
+            const uint2 lo = *reinterpret_cast<const uint2*>(r0), up = *reinterpret_cast<const uint2*>(r0 + 16);
+            aw.x = lo.x; aw.y = lo.y; aw.z = up.x; aw.w = up.y;
+            acc0[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw), dsf, acc0[db], 0, 0, 0);
+            if constexpr (DKDV) {
+                const bf16_t* r1 = x1t + (db * 16 + col) * B8_TP + kg * 4;
+                uint4 bw;
+                const uint2 lo1 = *reinterpret_cast<const uint2*>(r1), up1 = *reinterpret_cast<const uint2*>(r1 + 16);
+                bw.x = lo1.x; bw.y = lo1.y; bw.z = up1.x; bw.w = up1.y;
+                acc1[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bw), pf, acc1[db], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- store: acc[db] holds (own row col, d = db * 16 + kg * 4 + r): four consecutive d = 8 bytes per lane and block
+    const int orow = own0 + col;
+    if (orow < n_own) {
+        bf16_t* o0 = (DKDV ? p.dk : p.dq) + (int64_t)b * p.bsdq + (int64_t)orow * p.lddq + h * B8_HD;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            uint2 v;
+            v.x = b8_pack(acc0[db][0] * p.scale, acc0[db][1] * p.scale);
+            v.y = b8_pack(acc0[db][2] * p.scale, acc0[db][3] * p.scale);
+            *reinterpret_cast<uint2*>(o0 + db * 16 + kg * 4) = v;
+        }
+        if constexpr (DKDV) {
+            bf16_t* o1 = p.dv + (int64_t)b * p.bsdq + (int64_t)orow * p.lddq + h * B8_HD;
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                uint2 v;
+                v.x = b8_pack(acc1[db][0], acc1[db][1]);
+                v.y = b8_pack(acc1[db][2], acc1[db][3]);
+                *reinterpret_cast<uint2*>(o1 + db * 16 + kg * 4) = v;
+            }
+        }
+    }
+}
+
+// D[b, h, q] = sum_d O[q, d] dO[q, d]: one wave per (b, q) row, 16 lanes per head
+__global__ __launch_bounds__(256) void attn_bwd_delta128_kernel(const AttnBwdParams p, int B) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)B * p.Sq) return;
+    const int b = row / p.Sq, q = row % p.Sq;
+    const bf16_t* o = p.o + (int64_t)b * p.bso + (int64_t)q * p.ldo;
+    const bf16_t* d = p.d_o + (int64_t)b * p.bsdo + (int64_t)q * p.lddo;
+    const int sub = lane & 15;
+    for (int h0 = 0; h0 < p.H; h0 += 4) {
+        const int h = h0 + (lane >> 4);
+        float s = 0.f;
+        if (h < p.H) {
+            const uint4 a = *reinterpret_cast<const uint4*>(o + h * B8_HD + sub * 8);
+            const uint4 c = *reinterpret_cast<const uint4*>(d + h * B8_HD + sub * 8);
+            const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                s += bf2f((bf16_t)(aw[k] & 0xffffu)) * bf2f((bf16_t)(cw[k] & 0xffffu)) +
+                     bf2f((bf16_t)(aw[k] >> 16)) * bf2f((bf16_t)(cw[k] >> 16));
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 8, 64);
+        if (h < p.H && sub == 0) p.vec[((int64_t)b * p.H + h) * p.Sq + q] = s;
+    }
+}
+
+}  // namespace
+
+int attention_bwd_d128_launch(const AttnBwdParams& p, int B, hipStream_t s) {
+    hipLaunchKernelGGL(attn_bwd_delta128_kernel, dim3((unsigned)(((int64_t)B * p.Sq + 3) / 4)), dim3(256), 0, s, p, B);
+    ADVGRPO_LAUNCH_CHECK();
+    const int64_t nq = (int64_t)((p.Sq + B8_OWN - 1) / B8_OWN) * p.H * B, nk = (int64_t)((p.Skv + B8_OWN - 1) / B8_OWN) * p.H * B;
+    ADVGRPO_CHECK(nq < (1ll << 31) && nk < (1ll << 31), "attention_bwd (d128): grid too large");
+    hipLaunchKernelGGL(attn_bwd_d128_kernel<false>, dim3((unsigned)nq), dim3(256), 0, s, p);
+    ADVGRPO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_d128_kernel<true>, dim3((unsigned)nk), dim3(256), 0, s, p);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace advgrpo

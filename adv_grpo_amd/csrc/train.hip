@@ -168,6 +168,57 @@ __global__ __launch_bounds__(256) void rmsnorm_heads_bwd_kernel(bf16_t* __restri
     }
 }
 
+// ---- backward of qk_norm_rope_kernel (norm.hip), in place on dy = the gradient w.r.t. the rotated, normalised, weighted q | k heads
+// of a packed joint QKV buffer (the Qwen-Image MMDiT in the G-step).  y = that forward's saved output.  Per (token, head):
+//   un-rotate both (the rotation is orthogonal: its transpose is the rotation by -angle):  g' = R^T dy,  y_n = R^T y
+//   then the weighted RMSNorm backward of rmsnorm_heads_bwd_kernel:  xhat = y_n / w,  g = g' w,  dx = rs (g - xhat mean(g xhat)).
+// One wave per token row, HD / 8 lanes per head, the token's (cos, sin) row loaded once for all heads.
+template <int HD>
+__global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(bf16_t* __restrict__ dy, int64_t lddy, const bf16_t* __restrict__ y,
+                                                               int64_t ldy, const float* __restrict__ rs, int rows, int S, int n_first,
+                                                               int col0, int nheads, const bf16_t* __restrict__ w_first,
+                                                               const bf16_t* __restrict__ w_rest, int heads_per_weight,
+                                                               const float* __restrict__ rope) {
+    constexpr int LPH = HD / 8, HPP = 64 / LPH;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int s = row % S;
+    const bf16_t* w = s < n_first ? w_first : w_rest;
+    const int sub = lane % LPH;
+    float cs[8] = {1.f, 0.f, 1.f, 0.f, 1.f, 0.f, 1.f, 0.f};
+    if (rope) {
+        const float4 a = *reinterpret_cast<const float4*>(rope + (int64_t)s * HD + sub * 8);
+        const float4 b = *reinterpret_cast<const float4*>(rope + (int64_t)s * HD + sub * 8 + 4);
+        cs[0] = a.x; cs[1] = a.y; cs[2] = a.z; cs[3] = a.w; cs[4] = b.x; cs[5] = b.y; cs[6] = b.z; cs[7] = b.w;
+    }
+    for (int h0 = 0; h0 < nheads; h0 += HPP) {
+        const int hh = h0 + lane / LPH;
+        if (hh >= nheads) break;
+        float d[8], yy[8], ww[8];
+        bf16_t* dp = dy + (int64_t)row * lddy + col0 + hh * HD + sub * 8;
+        unpack8t(*reinterpret_cast<const uint4*>(dp), d);
+        unpack8t(*reinterpret_cast<const uint4*>(y + (int64_t)row * ldy + col0 + hh * HD + sub * 8), yy);
+        unpack8t(*reinterpret_cast<const uint4*>(w + (hh / heads_per_weight) * HD + sub * 8), ww);
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            const float co = cs[k], si = cs[k + 1];
+            const float ga = d[k] * co + d[k + 1] * si, gb = -d[k] * si + d[k + 1] * co;
+            const float ya = yy[k] * co + yy[k + 1] * si, yb = -yy[k] * si + yy[k + 1] * co;
+            d[k] = ga * ww[k]; d[k + 1] = gb * ww[k + 1];               // g
+            yy[k] = ya / ww[k]; yy[k + 1] = yb / ww[k + 1];             // xhat
+            dot += d[k] * yy[k] + d[k + 1] * yy[k + 1];
+        }
+        dot = group8_sum(dot);
+        if (LPH == 16) dot += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dot), 0x140, 0xf, 0xf, true));
+        const float r = rs[(int64_t)row * nheads + hh], mdot = dot * (1.0f / HD);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = r * (d[k] - yy[k] * mdot);
+        *reinterpret_cast<uint4*>(dp) = pack8t(d);
+    }
+}
+
 // ---- y[m, :] = gate[(m / rows_per_batch) * gate_stride + :] * x[m, :]
 __global__ __launch_bounds__(256) void gate_mul_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate,
                                                        bf16_t* __restrict__ y, int64_t total8, int D8, int rows_per_batch,
@@ -282,6 +333,23 @@ extern "C" int advgrpo_rmsnorm_heads_bwd(void* dy, int64_t lddy, const void* y, 
     hipLaunchKernelGGL(rmsnorm_heads_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), (bf16_t*)dy, lddy,
                        (const bf16_t*)y, ldy, rs, M, col0, nheads, (const bf16_t*)weight, heads_per_weight, seg_rows,
                        seg_stride, seg_off);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_qk_norm_rope_bwd(void* dy, int64_t lddy, const void* y, int64_t ldy, const float* rs, int rows, int S,
+                                        int n_first, int col0, int nheads, int head_dim, const void* w_first, const void* w_rest,
+                                        int heads_per_weight, const float* rope, void* stream) {
+    ADVGRPO_CHECK(dy && y && rs && w_first && w_rest && rows > 0 && S > 0 && nheads > 0 && heads_per_weight > 0, "qk_norm_rope_bwd: bad argument");
+    ADVGRPO_CHECK(head_dim == 64 || head_dim == 128, "qk_norm_rope_bwd: head_dim %d not supported (64, 128)", head_dim);
+    ADVGRPO_CHECK(lddy % 8 == 0 && ldy % 8 == 0 && col0 % 8 == 0, "qk_norm_rope_bwd: pitch/offset must be multiples of 8");
+    const dim3 grid((rows + 3) / 4);
+    if (head_dim == 128)
+        hipLaunchKernelGGL(qk_norm_rope_bwd_kernel<128>, grid, dim3(256), 0, as_stream(stream), (bf16_t*)dy, lddy, (const bf16_t*)y, ldy,
+                           rs, rows, S, n_first, col0, nheads, (const bf16_t*)w_first, (const bf16_t*)w_rest, heads_per_weight, rope);
+    else
+        hipLaunchKernelGGL(qk_norm_rope_bwd_kernel<64>, grid, dim3(256), 0, as_stream(stream), (bf16_t*)dy, lddy, (const bf16_t*)y, ldy,
+                           rs, rows, S, n_first, col0, nheads, (const bf16_t*)w_first, (const bf16_t*)w_rest, heads_per_weight, rope);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

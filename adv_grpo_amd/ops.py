@@ -268,7 +268,7 @@ def attention_fallback_count(reset=True):
 
 
 def attention_bwd(q, k, v, o, d_o, lse, num_heads, dq, dk, dv, scale=None):
-    """Gradients of ops.attention.  q,k,v,o,d_o: [B,S,H*64] bf16 views; lse f32 [B,H,Sq] from the forward;
+    """Gradients of ops.attention (head dim 64 or 128).  q,k,v,o,d_o: [B,S,H*hd] bf16 views; lse f32 [B,H,Sq] from the forward;
     dq/dk/dv: bf16 views of ONE packed buffer (same row / batch pitch)."""
     lib = _lib.load()
     B, Sq, HD = q.shape
@@ -838,6 +838,17 @@ def rmsnorm_heads_bwd(dy, y, rs, col0, nheads, weight, heads_per_weight, seg=Non
     _lib.check(lib.advgrpo_rmsnorm_heads_bwd(dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), rs.data_ptr(), M, col0,
                                              nheads, weight.data_ptr(), heads_per_weight, int(seg_rows), int(seg_stride),
                                              int(seg_off), _lib.stream_ptr()))
+    return dy
+
+
+def qk_norm_rope_bwd(dy, y, rs, S, n_first, nheads, head_dim, w_first, w_rest, heads_per_weight, rope=None, col0=0):
+    """In place on dy [B * S, ld] bf16: gradient w.r.t. the output of ops.qk_norm_rope (same arguments; y = its saved output,
+    rs = its rs_out [B * S, nheads] f32) -> gradient w.r.t. its input."""
+    lib = _lib.load()
+    assert dy.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and dy.stride(1) == 1 and y.stride(1) == 1 and rs.dtype == torch.float32
+    _lib.check(lib.advgrpo_qk_norm_rope_bwd(dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), rs.data_ptr(), dy.shape[0], int(S),
+                                            int(n_first), int(col0), int(nheads), int(head_dim), w_first.data_ptr(), w_rest.data_ptr(),
+                                            int(heads_per_weight), rope.data_ptr() if rope is not None else None, _lib.stream_ptr()))
     return dy
 
 

@@ -449,6 +449,13 @@ int advgrpo_layernorm_mod_bwd(const void* x, int64_t ldx, const void* dy0, const
 int advgrpo_rmsnorm_heads_bwd(void* dy, int64_t lddy, const void* y, int64_t ldy, const float* rs, int M,
                               int col0, int nheads, const void* weight, int heads_per_weight, int seg_rows,
                               int64_t seg_stride, int64_t seg_off, void* stream);
+/* backward of advgrpo_qk_norm_rope, in place: dy (grad of the rotated + normalised + weighted q | k heads of the joint buffer) ->
+ * grad of the raw projections; y = the forward's saved output, rs = its rs_out; row / weight / rope conventions as the forward.
+ * Autograd of norm_q / norm_k / norm_added_* + apply_rotary_emb_qwen in the G-step of BASELINE config 5 (TP:1165 on the
+ * Qwen-Image model the reference names at README.md:75). */
+int advgrpo_qk_norm_rope_bwd(void* dy, int64_t lddy, const void* y, int64_t ldy, const float* rs, int rows, int S, int n_first,
+                             int col0, int nheads, int head_dim, const void* w_first, const void* w_rest, int heads_per_weight,
+                             const float* rope, void* stream);
 int advgrpo_gate_mul(const void* x, const void* gate, void* y, int M, int D, int rows_per_batch,
                      int64_t gate_stride, void* stream);
 /* workspace: advgrpo_sumsq_workspace_bytes() bytes of device memory (per-block partial sums, added in a fixed order: the result
