@@ -1,0 +1,222 @@
+"""LoRA training of the Qwen-Image MMDiT on the gfx950 kernels: the update half (G-step) of BASELINE config 5.
+
+The reference has no Qwen-Image code (README.md:75, config/grpo.py:324,330); this is the Qwen-Image twin of what
+mmdit_train.py replaces for SD3 (scripts/train_sd3_fast_pickscore.py:1077-1187: peft LoRA r=32 / alpha=64 on the attention
+projections attn.{to_q,to_k,to_v,to_out.0,add_q_proj,add_k_proj,add_v_proj,to_add_out} (TP:490-511), autograd through the
+transformer call of compute_log_prob (TP:233-267), clip_grad_norm_ + AdamW (TP:1165-1171), EMAModuleWrapper), with the same
+flat parameter / gradient / moment vectors, merged-LoRA forward, token-contracted adapter-gradient GEMMs on a side stream and
+fused AdamW -- those methods are SD3TransformerLoRA's own, bound here unchanged.
+
+What differs from the SD3 model:
+  * ACTIVATION RECOMPUTATION PER BLOCK.  Sixty blocks at CFG batch 16 and 4224 joint tokens would keep ~7 GB of activations
+    each (440 GB); `forward_train` keeps only the two residual streams entering every block (0.4 GB per block) and `backward`
+    re-runs one block's forward -- the same launches, so the same bits -- before differentiating it: 4/3 of the matrix work
+    for 1/17 of the memory, the whole model + optimiser + checkpoints inside one GPU's 288 GB.
+  * head dim 128: `attention_bwd_d128.hip`; QK-norm + rotary backward: `advgrpo_qk_norm_rope_bwd` (the forward's in-place kernel
+    saves 1/rms per head).
+  * every block is a full two-stream block (no dual attention, no context_pre_only last block): the text stream's gradient
+    enters the last block as zero.
+  * the modulation rows come from the timestep embedding alone and are shared by the batch (row stride 0).
+Linears run in bf16 here (the fp8 rollout mode is not replayed by this first version: `forward_train` raises if it is on).
+"""
+import torch
+
+from . import ops
+from .ema import EMAModuleWrapper
+from .mmdit_train import RANK, RPAD, SD3TransformerLoRA, _Adapter
+from .qwen_mmdit import QwenImageTransformer2DModel
+
+TARGETS = ("to_q", "to_k", "to_v", "to_out.0", "add_q_proj", "add_k_proj", "add_v_proj", "to_add_out")
+GROUPS = {"qkv": ("to_q", "to_k", "to_v"), "cqkv": ("add_q_proj", "add_k_proj", "add_v_proj"), "out": ("to_out.0",), "cout": ("to_add_out",)}
+
+
+class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
+    lora_mode = "merged"
+
+    def __init__(self, state_dict, cfg, device="cuda", lora_alpha=64, seed=0, lora_state=None):
+        super().__init__(state_dict, cfg, device)
+        self.scale = lora_alpha / RANK
+        D = cfg.dim
+        self.adapters, off = {}, 0
+        for i in range(cfg.num_layers):
+            for n in TARGETS:
+                key = f"transformer_blocks.{i}.attn.{n}"
+                self.adapters[key] = _Adapter(key, D, D, off, off + RPAD * D)
+                off += RPAD * D + D * RPAD
+        self.n_params = off
+        dev = self.device
+        self.params = torch.zeros(off, dtype=torch.float32, device=dev)
+        g = torch.Generator().manual_seed(seed)
+        for key, ad in self.adapters.items():
+            if lora_state is not None:
+                A, Bm = lora_state[key + ".lora_A.weight"].float(), lora_state[key + ".lora_B.weight"].float()
+            else:                                                  # init_lora_weights="gaussian": A ~ N(0, 1/r), B = 0
+                A, Bm = torch.randn(RANK, ad.K, generator=g) / RANK, torch.zeros(ad.N, RANK)
+            self.A_view(ad)[:RANK] = A.to(dev)
+            self.B_view(ad)[:, :RANK] = Bm.to(dev)
+        self.grads = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.params_bf16 = self.params.to(torch.bfloat16)
+        self.opt_step = 0
+        self.ema_wrapper = EMAModuleWrapper([self.params], decay=0.9, update_step_interval=8, device=dev)
+        self.ema = self.ema_wrapper.ema_parameters[0]
+        self.overlap_wgrad = True
+        self._wgrad_stream = ops.concurrent_stream(dev)
+        self._base_T = {}
+        self._prepare_transposes()
+        self.refresh()
+
+    # the flat-vector machinery is the SD3 model's (same adapter layout, same kernels)
+    A_view = SD3TransformerLoRA.A_view
+    B_view = SD3TransformerLoRA.B_view
+    lora_state_dict = SD3TransformerLoRA.lora_state_dict
+    load_lora_state = SD3TransformerLoRA.load_lora_state
+    save_pretrained = SD3TransformerLoRA.save_pretrained
+    lora_grads = SD3TransformerLoRA.lora_grads
+    refresh = SD3TransformerLoRA.refresh
+    _lora_wgrad = SD3TransformerLoRA._lora_wgrad
+    _lora_wgrad_now = SD3TransformerLoRA._lora_wgrad_now
+    optimizer_step = SD3TransformerLoRA.optimizer_step
+    ema_step = SD3TransformerLoRA.ema_step
+
+    def _prepare_transposes(self):
+        """Transposed copies for the data-gradient GEMMs; base (un-merged) copies of the adapted weights and their transposes
+        (the blocks hold the base weights until the first refresh() merges the adapters in)."""
+        T = lambda w: w.t().contiguous()
+        for i, b in enumerate(self.blocks):
+            b["last"] = False                  # (refresh() asks: every Qwen-Image block has a text-stream output projection)
+            for k in ("ff1", "ff2", "cff1", "cff2"):
+                b[k + ".wT"] = T(b[k + ".w"])
+            self._base_T[i] = {gk: (b[gk + ".w"].clone(), T(b[gk + ".w"])) for gk in GROUPS}
+        self.w["proj_out.wT"] = T(self.w["proj_out.w"])
+
+    # ------------------------------------------------------------------ one block, bf16 Linears: the launches of __call__
+    def _block(self, i, x, c, mods, rope, B, Ni, Nt, save=None):
+        """In place on x [B * Ni, D], c [B * Nt, D].  `save` (a dict) receives what the block's backward needs."""
+        cfg, b = self.cfg, self.blocks[i]
+        D, H, hd = cfg.dim, cfg.num_heads, cfg.head_dim
+        S, Mi, Mt = Ni + Nt, B * Ni, B * Nt
+        dev, bf16 = x.device, torch.bfloat16
+        kx, kc = ("x", i), ("c", i)
+
+        def mod(key, j):
+            o = self.mod_off[key] + j * D
+            return mods[:, o:o + D]
+
+        def linears(items):
+            return ops.gemm_grouped([ops.gemm_desc(a, b[key + ".w"], bias=b[key + ".b"], **kw) for a, key, kw in items])
+        nx = ops.layernorm_mod(x, scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
+        nc = ops.layernorm_mod(c, scale=mod(kc, 1), shift=mod(kc, 0), rows_per_batch=Nt)
+        qkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
+        qkv3 = qkv.view(B, S, 3 * D)
+        linears([(nx, "qkv", dict(out=qkv, seg=(Ni, S, 0))), (nc, "cqkv", dict(out=qkv, seg=(Nt, S, Ni)))])
+        rs = torch.empty(B * S, 2 * H, dtype=torch.float32, device=dev) if save is not None else None
+        ops.qk_norm_rope(qkv, S, Ni, 2 * H, hd, b["rms_x"], b["rms_c"], H, rope=rope, eps=1e-6, rs_out=rs)
+        att = torch.empty(B, S, D, dtype=bf16, device=dev)
+        lse = torch.empty(B, H, S, dtype=torch.float32, device=dev) if save is not None else None
+        ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att, lse=lse)
+        att2d = att.view(B * S, D)
+        linears([(att2d, "out", dict(gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x, a_seg=(Ni, S, 0), M=Mi)),
+                 (att2d, "cout", dict(gate=mod(kc, 2), gate_rows=Nt, residual=c, out=c, a_seg=(Nt, S, Ni), M=Mt))])
+        pre = cpre = None
+        if save is not None:
+            save.update(nx=nx, nc=nc, qkv=qkv, rs=rs, att=att, lse=lse, x_mid=x.clone(), c_mid=c.clone())
+            pre = torch.empty(Mi, 4 * D, dtype=bf16, device=dev)
+            cpre = torch.empty(Mt, 4 * D, dtype=bf16, device=dev)
+            save.update(pre=pre, cpre=cpre)
+        nx2 = ops.layernorm_mod(x, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
+        nc2 = ops.layernorm_mod(c, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
+        aux = (lambda t: dict(aux_out=t)) if save is not None else (lambda t: {})
+        hm = linears([(nx2, "ff1", dict(act="gelu_tanh", **aux(pre))), (nc2, "cff1", dict(act="gelu_tanh", **aux(cpre)))])
+        linears([(hm[0], "ff2", dict(gate=mod(kx, 5), gate_rows=Ni, residual=x, out=x)),
+                 (hm[1], "cff2", dict(gate=mod(kc, 5), gate_rows=Nt, residual=c, out=c))])
+
+    # ------------------------------------------------------------------ forward keeping one checkpoint per block
+    @torch.no_grad()
+    def forward_train(self, hidden_states, timestep, encoder_hidden_states, pooled_projections=None):
+        """Same arithmetic as __call__ (bf16 Linears).  Returns (v [B,16,h,w] bf16, ctx)."""
+        if self.fp8 is not None:
+            raise NotImplementedError("QwenImageTransformerLoRA: the G-step replays bf16 Linears; switch the fp8 rollout mode off")
+        cfg, w = self.cfg, self.w
+        D = cfg.dim
+        B, C, h, wd = hidden_states.shape
+        hh, ww = h // cfg.patch_size, wd // cfg.patch_size
+        Ni, Nt = hh * ww, encoder_hidden_states.shape[1]
+        x = ops.gemm(ops.patchify(hidden_states.contiguous()), w["img_in.w"], bias=w["img_in.b"])
+        t_rows = timestep[:1] if (timestep.dim() == 0 or timestep.numel() == 1 or timestep.stride(0) == 0) else timestep
+        mods = self._mods(self._temb(t_rows.reshape(-1)))
+        mods = mods.expand(B, -1) if mods.shape[0] == 1 else mods
+        c = self.embed_context(encoder_hidden_states)
+        rope = self._rope(hh, ww, Nt)
+        ctx = {"B": B, "Ni": Ni, "Nt": Nt, "h": h, "w": wd, "mods": mods, "rope": rope, "x_in": [], "c_in": []}
+        for i in range(cfg.num_layers):
+            ctx["x_in"].append(x.clone())
+            ctx["c_in"].append(c.clone())
+            self._block(i, x, c, mods, rope, B, Ni, Nt)
+        ctx["x_final"] = x
+        o = self.mod_off[("out",)]
+        nx = ops.layernorm_mod(x, scale=mods[:, o:o + D], shift=mods[:, o + D:o + 2 * D], rows_per_batch=Ni)
+        tok = ops.gemm(nx, w["proj_out.w"], bias=w["proj_out.b"])
+        return ops.unpatchify(tok, B, cfg.out_channels, h, wd, torch.bfloat16), ctx
+
+    # ------------------------------------------------------------------ explicit backward, one recomputed block at a time
+    @torch.no_grad()
+    def backward(self, ctx, dv):
+        """dv: gradient w.r.t. the model output [B,16,h,w] (bf16).  Accumulates LoRA gradients into self.grads; returns the
+        gradients w.r.t. the two embedded streams."""
+        cfg, w = self.cfg, self.w
+        D, H, hd = cfg.dim, cfg.num_heads, cfg.head_dim
+        B, Ni, Nt = ctx["B"], ctx["Ni"], ctx["Nt"]
+        S = Ni + Nt
+        mods, rope = ctx["mods"], ctx["rope"]
+        dev, bf16 = dv.device, torch.bfloat16
+
+        def mod(key, j):
+            o = self.mod_off[key] + j * D
+            return mods[:, o:o + D]
+        side = self._wgrad_stream if self.overlap_wgrad else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        dtok = SD3TransformerLoRA._patch_rows_of_output_grad(self, dv)           # [B*Ni, 64], column (py*2+px)*C + c
+        dnx = ops.gemm(dtok, w["proj_out.wT"])
+        dx = ops.layernorm_mod_bwd(ctx["x_final"], dnx, scale0=mod(("out",), 0), rows_per_batch=Ni)
+        dc = torch.zeros(B * Nt, D, dtype=bf16, device=dev)       # nothing reads the text stream after the last block
+        for i in reversed(range(cfg.num_layers)):
+            b, s = self.blocks[i], {}
+            kx, kc = ("x", i), ("c", i)
+            x_in, c_in = ctx["x_in"][i], ctx["c_in"][i]
+            self._block(i, x_in.clone(), c_in.clone(), mods, rope, B, Ni, Nt, save=s)
+            # ---- MLPs (the text-stream GEMMs ride in the launches of their image-stream twins, as in the forward)
+            dyg, dcyg = ops.gate_mul(dx, mod(kx, 5), Ni), ops.gate_mul(dc, mod(kc, 5), Nt)
+            dpres = ops.gemm_grouped([ops.gemm_desc(dyg, b["ff2.wT"], act="dgelu_tanh", aux_in=s["pre"]),
+                                      ops.gemm_desc(dcyg, b["cff2.wT"], act="dgelu_tanh", aux_in=s["cpre"])])
+            dmid = ops.gemm_grouped([ops.gemm_desc(dpres[0], b["ff1.wT"]), ops.gemm_desc(dpres[1], b["cff1.wT"])])
+            dx1 = ops.layernorm_mod_bwd(s["x_mid"], dmid[0], scale0=mod(kx, 4), dres=dx, rows_per_batch=Ni)
+            dc1 = ops.layernorm_mod_bwd(s["c_mid"], dmid[1], scale0=mod(kc, 4), dres=dc, rows_per_batch=Nt)
+            del dpres, dmid, dyg, dcyg
+            # ---- joint attention
+            datt = torch.empty(B * S, D, dtype=bf16, device=dev)
+            dyo, dyc = ops.gate_mul(dx1, mod(kx, 2), Ni), ops.gate_mul(dc1, mod(kc, 2), Nt)
+            ops.gemm_grouped([ops.gemm_desc(dyo, b["out.wT"], out=datt, seg=(Ni, S, 0)),
+                              ops.gemm_desc(dyc, b["cout.wT"], out=datt, seg=(Nt, S, Ni))])
+            att2d = s["att"].view(B * S, D)
+            self._lora_wgrad((i, "out"), att2d, B * Ni, (Ni, S, 0), dyo, None)
+            self._lora_wgrad((i, "cout"), att2d, B * Nt, (Nt, S, Ni), dyc, None)
+            q3 = s["qkv"].view(B, S, 3 * D)
+            dqkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
+            d3 = dqkv.view(B, S, 3 * D)
+            ops.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], s["att"], datt.view(B, S, D), s["lse"], H,
+                              d3[:, :, :D], d3[:, :, D:2 * D], d3[:, :, 2 * D:])
+            ops.qk_norm_rope_bwd(dqkv, s["qkv"], s["rs"], S, Ni, 2 * H, hd, b["rms_x"], b["rms_c"], H, rope=rope)
+            dnx, dnc = ops.gemm_grouped([ops.gemm_desc(dqkv, b["qkv.wT"], a_seg=(Ni, S, 0), M=B * Ni),
+                                         ops.gemm_desc(dqkv, b["cqkv.wT"], a_seg=(Nt, S, Ni), M=B * Nt)])
+            self._lora_wgrad((i, "qkv"), s["nx"], B * Ni, None, dqkv, (Ni, S, 0))
+            self._lora_wgrad((i, "cqkv"), s["nc"], B * Nt, None, dqkv, (Nt, S, Ni))
+            # ---- first norms
+            dx = ops.layernorm_mod_bwd(x_in, dnx, scale0=mod(kx, 1), dres=dx1, rows_per_batch=Ni)
+            dc = ops.layernorm_mod_bwd(c_in, dnc, scale0=mod(kc, 1), dres=dc1, rows_per_batch=Nt)
+            ctx["x_in"][i] = ctx["c_in"][i] = None       # the checkpoint is spent
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        return dx, dc

@@ -74,3 +74,75 @@ def test_qk_norm_rope_backward_matches_autograd(hd, H, Ni, Nt, B):
     assert torch.equal(got[:, :, 2], dy.float().view(B, S, 3, H, hd)[:, :, 2])
     rel = ((got[:, :, :2] - x.grad[:, :, :2]).norm() / x.grad[:, :, :2].norm()).item()
     assert rel < 1e-2, rel
+
+
+# ---------------------------------------------------------------- the model: LoRA gradients vs autograd through the oracle
+def _cos(a, b):
+    return (torch.dot(a.flatten().double(), b.flatten().double()) / (a.double().norm() * b.double().norm() + 1e-30)).item()
+
+
+def _lora_init(cfg, seed):
+    g = torch.Generator().manual_seed(seed)
+    D, sd = cfg.dim, {}
+    for i in range(cfg.num_layers):
+        for n in ("to_q", "to_k", "to_v", "to_out.0", "add_q_proj", "add_k_proj", "add_v_proj", "to_add_out"):
+            key = f"transformer_blocks.{i}.attn.{n}"
+            sd[key + ".lora_A.weight"] = (torch.randn(32, D, generator=g) / 32).to(bf16).float()
+            sd[key + ".lora_B.weight"] = (torch.randn(D, 32, generator=g) * 0.02).to(bf16).float()
+    return sd
+
+
+def _lora_case(cfg, seed, B, hw, Nt, per_sample_t=False):
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.qwen_mmdit_train import QwenImageTransformerLoRA
+    from oracle import lora as o_lora
+    from oracle import qwen_mmdit as o
+    W = {k: v.to(bf16) for k, v in synthetic.qwen_mmdit_weights(cfg, seed).items()}
+    lora = _lora_init(cfg, seed + 1)
+    g = torch.Generator().manual_seed(seed + 2)
+    lat = torch.randn(B, 16, hw, hw, generator=g).to(bf16)
+    ctx = torch.randn(B, Nt, cfg.joint_attention_dim, generator=g).to(bf16)
+    t = (torch.tensor([913.3488, 700.0, 500.0, 300.0][:B]) if per_sample_t else torch.full((B,), 913.3488)).float()
+    model = QwenImageTransformerLoRA(dict(W), cfg, "cuda", lora_state=lora)
+    v, saved = model.forward_train(lat.cuda(), t.cuda(), ctx.cuda())
+    (v_inf,) = model(lat.cuda(), t.cuda(), ctx.cuda())
+    assert torch.equal(v, v_inf)                                              # training forward == rollout forward
+    dv = torch.randn(v.shape, generator=g).to(bf16)
+    model.backward(saved, dv.cuda())
+    grads = model.lora_grads()
+    W32 = {k: x.float().cuda() for k, x in W.items()}
+    lo = {k: x.cuda().requires_grad_(True) for k, x in lora.items()}
+    out = o.qwen_forward(o_lora.effective_weights(W32, lo), cfg, lat.float().cuda(), t.cuda() / 1000, ctx.float().cuda())
+    assert ((v.float() - out).norm() / out.norm()).item() < 3e-2
+    (out * dv.float().cuda()).sum().backward()
+    worst, worst_ratio = 1.0, 1.0
+    for k, gr in grads.items():
+        ref = lo[k].grad
+        if ref is None or ref.norm().item() == 0:          # add_q_proj / to_add_out of the last block: nothing reads its text-stream output
+            assert gr.abs().max().item() == 0, k
+            continue
+        c, ratio = _cos(gr, ref), (gr.norm() / ref.norm()).item()
+        worst, worst_ratio = min(worst, c), max(worst_ratio, max(ratio, 1 / ratio))
+        assert c > 0.97 and 0.9 < ratio < 1.1, (k, c, ratio)
+    print("qwen LoRA grads: worst cosine", worst, "worst norm ratio", worst_ratio)
+    return model
+
+
+@pytest.mark.parametrize("per_sample_t", [False, True])
+def test_qwen_lora_backward_vs_autograd_small(per_sample_t):
+    """3 blocks of 4 heads x 128, 8 x 8 packed positions + 13 text tokens: every adapter's A and B gradient (image and text stream,
+    q / k through the QK-norm + rotary backward, v, both output projections) against fp32 autograd through W + s B A of the oracle;
+    one shared timestep (the rollout's) and one per sample (the replay's, TP:246-251)."""
+    from oracle.qwen_mmdit import QwenMMDiTConfig
+    cfg = QwenMMDiTConfig(num_layers=3, num_heads=4, joint_attention_dim=256)
+    model = _lora_case(cfg, 41, B=4, hw=16, Nt=13, per_sample_t=per_sample_t)
+    # the optimiser step of the SD3 model's flat vectors moves the merged weights
+    w0 = model.blocks[1]["qkv.w"].clone()
+    model.optimizer_step(lr=1e-3)
+    assert not torch.equal(model.blocks[1]["qkv.w"], w0) and model.grads.abs().max().item() == 0
+
+
+def test_qwen_lora_backward_vs_autograd_full_width():
+    """The real width (24 x 128 = 3072, 3584-wide text states) on two blocks at 32 x 32 packed positions + 64 text tokens."""
+    from oracle.qwen_mmdit import QwenMMDiTConfig
+    _lora_case(QwenMMDiTConfig(num_layers=2), 43, B=2, hw=64, Nt=64)
