@@ -146,3 +146,54 @@ def test_qwen_lora_backward_vs_autograd_full_width():
     """The real width (24 x 128 = 3072, 3584-wide text states) on two blocks at 32 x 32 packed positions + 64 text tokens."""
     from oracle.qwen_mmdit import QwenMMDiTConfig
     _lora_case(QwenMMDiTConfig(num_layers=2), 43, B=2, hw=64, Nt=64)
+
+
+def test_qwen_g_step_chain_rollout_replay_loss_backward_adamw():
+    """Config 5's loop in small: the SD3 rollout function drives the LoRA model (4 steps, SDE window 2), then every trained timestep
+    goes through g_step.micro_step (compute_log_prob TP:233-267 -> GRPO loss TP:1111-1130 -> backward TP:1165): the replayed
+    log-probs are the rollout's up to the bf16 cast of the stored latents (importance ratio 1 before the first update), the G-step is bitwise repeatable,
+    and one clip + AdamW step (TP:1166-1171) moves the policy."""
+    from adv_grpo_amd import g_step, synthetic
+    from adv_grpo_amd.diffusers_patch.sd3_pipeline_with_logprob_fast import pipeline_with_logprob_random
+    from adv_grpo_amd.model_configs import QwenVaeConfig
+    from adv_grpo_amd.pipeline import SD3Pipeline
+    from adv_grpo_amd.qwen_mmdit_train import QwenImageTransformerLoRA
+    from adv_grpo_amd.qwen_vae import AutoencoderKLQwenImageDecoder
+    from oracle.qwen_mmdit import QwenMMDiTConfig
+    cfg = QwenMMDiTConfig(num_layers=2, num_heads=4, joint_attention_dim=256)
+    W = {k: v.to(bf16) for k, v in synthetic.qwen_mmdit_weights(cfg, 5).items()}
+    model = QwenImageTransformerLoRA(W, cfg, "cuda", lora_state=_lora_init(cfg, 6))
+    vcfg = QwenVaeConfig()
+    vae = AutoencoderKLQwenImageDecoder(synthetic.qwen_vae_decoder_weights(vcfg, 7, dtype=bf16), vcfg, "cuda", mode="bf16")
+    pipe = SD3Pipeline(model, vae, "cuda")
+    g = torch.Generator().manual_seed(8)
+    pe, npe = (torch.randn(1, 20, cfg.joint_attention_dim, generator=g).to(bf16).cuda() for _ in range(2))
+    pooled = torch.zeros(1, 8, dtype=bf16, device="cuda")
+    G, T = 4, 2
+    images, lats, lps, tss = pipeline_with_logprob_random(
+        pipe, prompt_embeds=pe, pooled_prompt_embeds=pooled, negative_prompt_embeds=npe, negative_pooled_prompt_embeds=pooled,
+        num_inference_steps=4, guidance_scale=4.0, height=256, width=256, noise_level=0.8, mini_num_image_per_prompt=G,
+        train_num_steps=T, process_index=0, sample_num_steps=4, random_timestep=0, seed=77)
+    assert images.shape == (G, 3, 256, 256) and torch.isfinite(images).all()
+    lat = torch.stack(lats, dim=1)
+    sample = {"latents": lat[:, :-1], "next_latents": lat[:, 1:], "timesteps": torch.stack(tss, dim=1)}
+    old = torch.stack(lps, dim=1)
+    embeds = torch.cat([npe.repeat(G, 1, 1), pe.repeat(G, 1, 1)])                # negative first (TP:1084-1091)
+    adv = torch.tensor([1.0, -0.5, 0.25, -0.75], device="cuda")
+    kw = dict(guidance_scale=4.0, noise_level=0.8, adv_clip_max=5, clip_range=1e-4)
+    first = int(pipe.last_random_timestep)
+    for j in range(T):
+        info = g_step.micro_step(model, pipe.scheduler, sample, j, embeds, None, old[:, j], adv, step_index=first + j, **kw)
+        # on-policy replay: ratio == 1 up to the bf16 cast of the stored latents (the rollout's log-prob comes from the f32 sample
+        # BEFORE the cast, PF:646-660, the replay's from the stored one, TP:258 -- as in the reference and the SD3 trainer tests)
+        assert (info["log_prob"] - old[:, j]).abs().max().item() < 3e-4 and 0.0 <= float(info["approx_kl"]) < 1e-7, j
+    g1 = model.grads.clone()
+    assert torch.isfinite(g1).all() and g1.abs().max().item() > 0
+    model.grads.zero_()
+    for j in range(T):
+        g_step.micro_step(model, pipe.scheduler, sample, j, embeds, None, old[:, j], adv, step_index=first + j, **kw)
+    assert torch.equal(model.grads, g1)                                        # bitwise repeatable G-step
+    model.optimizer_step(lr=1e-3)
+    model.ema_step(1)
+    after = g_step.micro_step(model, pipe.scheduler, sample, 0, embeds, None, old[:, 0], adv, step_index=first, **kw)
+    assert not torch.equal(after["log_prob"], old[:, 0]) and torch.isfinite(after["log_prob"]).all()
