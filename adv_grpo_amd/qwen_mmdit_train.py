@@ -17,7 +17,9 @@ What differs from the SD3 model:
   * every block is a full two-stream block (no dual attention, no context_pre_only last block): the text stream's gradient
     enters the last block as zero.
   * the modulation rows come from the timestep embedding alone and are shared by the batch (row stride 0).
-Linears run in bf16 here (the fp8 rollout mode is not replayed by this first version: `forward_train` raises if it is on).
+fp8 Linears (enable_fp8, the arithmetic BASELINE config 5 names): the replay runs the SAME e4m3 launches as the rollout, so the
+importance ratio starts at 1; the backward differentiates the bf16 Linear from the bf16 activations kept beside the e4m3 rows
+(straight-through), exactly as SD3TransformerLoRA does.
 """
 import torch
 
@@ -104,40 +106,69 @@ class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
             o = self.mod_off[key] + j * D
             return mods[:, o:o + D]
 
+        f8 = self.fp8
+
         def linears(items):
+            if f8 is not None:
+                return ops.gemm_grouped_fp8([ops.gemm_desc_fp8(a, f8[(i, key)], bias=b[key + ".b"], **kw) for a, key, kw in items])
             return ops.gemm_grouped([ops.gemm_desc(a, b[key + ".w"], bias=b[key + ".b"], **kw) for a, key, kw in items])
-        nx = ops.layernorm_mod(x, scale=mod(kx, 1), shift=mod(kx, 0), rows_per_batch=Ni)
-        nc = ops.layernorm_mod(c, scale=mod(kc, 1), shift=mod(kc, 0), rows_per_batch=Nt)
+
+        def rows8(M, K):
+            return ops.Fp8Rows(torch.empty(M, K, dtype=torch.uint8, device=dev), torch.empty(M, dtype=torch.float32, device=dev))
+
+        def norm(t, key, j_scale, j_shift, rows, q=None):
+            """LayerNorm + modulation: bf16 rows (what the backward keeps) and, in fp8 mode, the e4m3 rows the Linears read."""
+            if f8 is None:
+                y = ops.layernorm_mod(t, scale=mod(key, j_scale), shift=mod(key, j_shift), rows_per_batch=rows)
+                return y, y
+            y = torch.empty_like(t) if save is not None else None
+            ops.layernorm_mod_fp8(t, q, out=y, scale=mod(key, j_scale), shift=mod(key, j_shift), rows_per_batch=rows)
+            return y, q
+        q_n = rows8(Mi + Mt, D) if f8 is not None else None
+        nx, nx_in = norm(x, kx, 1, 0, Ni, q_n.rows(0, Mi) if f8 is not None else None)
+        nc, nc_in = norm(c, kc, 1, 0, Nt, q_n.rows(Mi, Mi + Mt) if f8 is not None else None)
         qkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
         qkv3 = qkv.view(B, S, 3 * D)
-        linears([(nx, "qkv", dict(out=qkv, seg=(Ni, S, 0))), (nc, "cqkv", dict(out=qkv, seg=(Nt, S, Ni)))])
+        linears([(nx_in, "qkv", dict(out=qkv, seg=(Ni, S, 0))), (nc_in, "cqkv", dict(out=qkv, seg=(Nt, S, Ni)))])
         rs = torch.empty(B * S, 2 * H, dtype=torch.float32, device=dev) if save is not None else None
         ops.qk_norm_rope(qkv, S, Ni, 2 * H, hd, b["rms_x"], b["rms_c"], H, rope=rope, eps=1e-6, rs_out=rs)
         att = torch.empty(B, S, D, dtype=bf16, device=dev)
         lse = torch.empty(B, H, S, dtype=torch.float32, device=dev) if save is not None else None
         ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att, lse=lse)
         att2d = att.view(B * S, D)
-        linears([(att2d, "out", dict(gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x, a_seg=(Ni, S, 0), M=Mi)),
-                 (att2d, "cout", dict(gate=mod(kc, 2), gate_rows=Nt, residual=c, out=c, a_seg=(Nt, S, Ni), M=Mt))])
+        if f8 is not None:
+            ops.quant_fp8_rows(att2d, out=q_n, split=(Ni, S))
+            linears([(q_n.rows(0, Mi), "out", dict(gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x)),
+                     (q_n.rows(Mi, Mi + Mt), "cout", dict(gate=mod(kc, 2), gate_rows=Nt, residual=c, out=c))])
+        else:
+            linears([(att2d, "out", dict(gate=mod(kx, 2), gate_rows=Ni, residual=x, out=x, a_seg=(Ni, S, 0), M=Mi)),
+                     (att2d, "cout", dict(gate=mod(kc, 2), gate_rows=Nt, residual=c, out=c, a_seg=(Nt, S, Ni), M=Mt))])
         pre = cpre = None
         if save is not None:
             save.update(nx=nx, nc=nc, qkv=qkv, rs=rs, att=att, lse=lse, x_mid=x.clone(), c_mid=c.clone())
             pre = torch.empty(Mi, 4 * D, dtype=bf16, device=dev)
             cpre = torch.empty(Mt, 4 * D, dtype=bf16, device=dev)
             save.update(pre=pre, cpre=cpre)
-        nx2 = ops.layernorm_mod(x, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
-        nc2 = ops.layernorm_mod(c, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
         aux = (lambda t: dict(aux_out=t)) if save is not None else (lambda t: {})
-        hm = linears([(nx2, "ff1", dict(act="gelu_tanh", **aux(pre))), (nc2, "cff1", dict(act="gelu_tanh", **aux(cpre)))])
+        if f8 is not None:            # (the MLP's normalised inputs are not kept: its backward needs the pre-activations only)
+            ops.layernorm_mod_fp8(x, q_n.rows(0, Mi), scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
+            ops.layernorm_mod_fp8(c, q_n.rows(Mi, Mi + Mt), scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
+            h_all = torch.empty(Mi + Mt, 4 * D, dtype=bf16, device=dev)
+            linears([(q_n.rows(0, Mi), "ff1", dict(act="gelu_tanh", out=h_all[:Mi], **aux(pre))),
+                     (q_n.rows(Mi, Mi + Mt), "cff1", dict(act="gelu_tanh", out=h_all[Mi:], **aux(cpre)))])
+            q_h = ops.quant_fp8_rows(h_all)
+            hm = [q_h.rows(0, Mi), q_h.rows(Mi, Mi + Mt)]
+        else:
+            nx2 = ops.layernorm_mod(x, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
+            nc2 = ops.layernorm_mod(c, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
+            hm = linears([(nx2, "ff1", dict(act="gelu_tanh", **aux(pre))), (nc2, "cff1", dict(act="gelu_tanh", **aux(cpre)))])
         linears([(hm[0], "ff2", dict(gate=mod(kx, 5), gate_rows=Ni, residual=x, out=x)),
                  (hm[1], "cff2", dict(gate=mod(kc, 5), gate_rows=Nt, residual=c, out=c))])
 
     # ------------------------------------------------------------------ forward keeping one checkpoint per block
     @torch.no_grad()
     def forward_train(self, hidden_states, timestep, encoder_hidden_states, pooled_projections=None):
-        """Same arithmetic as __call__ (bf16 Linears).  Returns (v [B,16,h,w] bf16, ctx)."""
-        if self.fp8 is not None:
-            raise NotImplementedError("QwenImageTransformerLoRA: the G-step replays bf16 Linears; switch the fp8 rollout mode off")
+        """Same arithmetic as __call__ (bf16 or fp8 Linears).  Returns (v [B,16,h,w] bf16, ctx)."""
         cfg, w = self.cfg, self.w
         D = cfg.dim
         B, C, h, wd = hidden_states.shape

@@ -92,7 +92,7 @@ def _lora_init(cfg, seed):
     return sd
 
 
-def _lora_case(cfg, seed, B, hw, Nt, per_sample_t=False):
+def _lora_case(cfg, seed, B, hw, Nt, per_sample_t=False, fp8=False):
     from adv_grpo_amd import synthetic
     from adv_grpo_amd.qwen_mmdit_train import QwenImageTransformerLoRA
     from oracle import lora as o_lora
@@ -104,6 +104,8 @@ def _lora_case(cfg, seed, B, hw, Nt, per_sample_t=False):
     ctx = torch.randn(B, Nt, cfg.joint_attention_dim, generator=g).to(bf16)
     t = (torch.tensor([913.3488, 700.0, 500.0, 300.0][:B]) if per_sample_t else torch.full((B,), 913.3488)).float()
     model = QwenImageTransformerLoRA(dict(W), cfg, "cuda", lora_state=lora)
+    if fp8:
+        model.enable_fp8()
     v, saved = model.forward_train(lat.cuda(), t.cuda(), ctx.cuda())
     (v_inf,) = model(lat.cuda(), t.cuda(), ctx.cuda())
     assert torch.equal(v, v_inf)                                              # training forward == rollout forward
@@ -113,9 +115,10 @@ def _lora_case(cfg, seed, B, hw, Nt, per_sample_t=False):
     W32 = {k: x.float().cuda() for k, x in W.items()}
     lo = {k: x.cuda().requires_grad_(True) for k, x in lora.items()}
     out = o.qwen_forward(o_lora.effective_weights(W32, lo), cfg, lat.float().cuda(), t.cuda() / 1000, ctx.float().cuda())
-    assert ((v.float() - out).norm() / out.norm()).item() < 3e-2
+    assert ((v.float() - out).norm() / out.norm()).item() < (8e-2 if fp8 else 3e-2)
     (out * dv.float().cuda()).sum().backward()
     worst, worst_ratio = 1.0, 1.0
+    c_min, r_lo, r_hi = (0.9, 0.8, 1.25) if fp8 else (0.97, 0.9, 1.1)
     for k, gr in grads.items():
         ref = lo[k].grad
         if ref is None or ref.norm().item() == 0:          # add_q_proj / to_add_out of the last block: nothing reads its text-stream output
@@ -123,8 +126,8 @@ def _lora_case(cfg, seed, B, hw, Nt, per_sample_t=False):
             continue
         c, ratio = _cos(gr, ref), (gr.norm() / ref.norm()).item()
         worst, worst_ratio = min(worst, c), max(worst_ratio, max(ratio, 1 / ratio))
-        assert c > 0.97 and 0.9 < ratio < 1.1, (k, c, ratio)
-    print("qwen LoRA grads: worst cosine", worst, "worst norm ratio", worst_ratio)
+        assert c > c_min and r_lo < ratio < r_hi, (k, c, ratio)
+    print("qwen LoRA grads" + (" (fp8 forward, straight-through)" if fp8 else "") + ": worst cosine", worst, "worst norm ratio", worst_ratio)
     return model
 
 
@@ -197,3 +200,11 @@ def test_qwen_g_step_chain_rollout_replay_loss_backward_adamw():
     model.ema_step(1)
     after = g_step.micro_step(model, pipe.scheduler, sample, 0, embeds, None, old[:, 0], adv, step_index=first, **kw)
     assert not torch.equal(after["log_prob"], old[:, 0]) and torch.isfinite(after["log_prob"]).all()
+
+
+def test_qwen_lora_backward_fp8_replay_straight_through():
+    """fp8 Linears (the arithmetic BASELINE config 5 names): the training forward issues the rollout's e4m3 launches (bit-identical
+    output), the backward is the bf16 Linear's from the bf16 activations kept beside the e4m3 rows; its LoRA gradients against fp32
+    autograd through the (unquantised) oracle -- a stated property with looser bounds, no reference arithmetic exists."""
+    from oracle.qwen_mmdit import QwenMMDiTConfig
+    _lora_case(QwenMMDiTConfig(num_layers=3, num_heads=4, joint_attention_dim=256), 47, B=4, hw=16, Nt=20, fp8=True)      # (the fp8 GEMM's row epilogue wants >= 16 text tokens)
