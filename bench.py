@@ -168,12 +168,15 @@ def pmc_traffic(kernel, config="c2"):
     return None, None
 
 
-def full_epoch(device, world=1, rank=0, adversarial=False):
+def full_epoch(device, world=1, rank=0, adversarial=False, qwen=False):
     """the whole sample -> score -> gather -> advantage -> G-step loop and its phases, outside the timed
     region of the headline metric: config 2 (pickscore_cotrain_sd3_fast preset, 8 images per prompt so that one rank
     holds whole groups), 2 prompt groups per epoch = 16 images, 2 optimizer steps; the second epoch is reported.
     adversarial (config 3): the dino_cotrain_sd3_patch_fast preset with its DINOv2-B/14 + head discriminator (TD:156-232,
-    1091-1115), d_times = 2 here so that a D epoch and a G epoch alternate: after a warm-up pair, one of each is timed."""
+    1091-1115), d_times = 2 here so that a D epoch and a G epoch alternate: after a warm-up pair, one of each is timed.
+    qwen (config 5): the same adversarial preset on the Qwen-Image model set at 1024^2 -- QwenImageTransformerLoRA (60 blocks, fp8
+    Linears in rollout AND replay, one activation checkpoint per block), Qwen-Image's own VAE decoder, DINOv2-B/14 + head; ONE prompt
+    group (8 images) per epoch."""
     from adv_grpo_amd import synthetic
     from adv_grpo_amd.config.experiments import get_config
     from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
@@ -184,8 +187,11 @@ def full_epoch(device, world=1, rank=0, adversarial=False):
     from adv_grpo_amd.vae import AutoencoderKLDecoder
     cfg = get_config("dino_cotrain_sd3_patch_fast" if adversarial else "pickscore_cotrain_sd3_fast", gpu_number=world)
     cfg.sample.num_image_per_prompt = 8
-    cfg.sample.num_batches_per_epoch = 2
+    cfg.sample.num_batches_per_epoch = 1 if qwen else 2
     cfg.train.gradient_accumulation_steps = 1
+    if qwen:
+        cfg.resolution = 1024
+        cfg.linear_dtype = "fp8"
     if adversarial:
         cfg.d_times = 2                      # D epoch, G epoch, D epoch, ... (the shipped preset: 9 D epochs per G epoch, TD:1097)
     else:
@@ -193,8 +199,16 @@ def full_epoch(device, world=1, rank=0, adversarial=False):
     mcfg = MMDiTConfig()
     head = None
     with synthetic.on_device(device):
-        tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, device, seed=cfg.seed)
-        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321, fp16_checkpoint=True), VaeConfig(), device)
+        if qwen:
+            from adv_grpo_amd.model_configs import QwenMMDiTConfig, QwenVaeConfig
+            from adv_grpo_amd.qwen_mmdit_train import QwenImageTransformerLoRA
+            from adv_grpo_amd.qwen_vae import AutoencoderKLQwenImageDecoder
+            tr = QwenImageTransformerLoRA(synthetic.qwen_mmdit_weights(QwenMMDiTConfig(), 4242, dtype=torch.bfloat16), QwenMMDiTConfig(), device,
+                                          seed=cfg.seed)
+            vae = AutoencoderKLQwenImageDecoder(synthetic.qwen_vae_decoder_weights(QwenVaeConfig(), 2468, dtype=torch.bfloat16), QwenVaeConfig(), device)
+        else:
+            tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, device, seed=cfg.seed)
+            vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321, fp16_checkpoint=True), VaeConfig(), device)
         if adversarial:
             from adv_grpo_amd import vit
             from adv_grpo_amd.d_step import DinoHeadTrainable
@@ -203,8 +217,9 @@ def full_epoch(device, world=1, rank=0, adversarial=False):
             head = DinoHeadTrainable(device=device, seed=0)
         else:
             scorer = PickScoreScorer(device, dtype=torch.bfloat16, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
-    trainer = Trainer(cfg, SD3Pipeline(tr, vae, device), SyntheticData(resolution=cfg.resolution, device=device), scorer,
-                      head, rank, world, log_path=None)
+    data = SyntheticData(n_tokens=C5_TEXT_TOKENS, ctx_dim=3584, pooled_dim=8, resolution=cfg.resolution, device=device) if qwen else \
+        SyntheticData(resolution=cfg.resolution, device=device)
+    trainer = Trainer(cfg, SD3Pipeline(tr, vae, device), data, scorer, head, rank, world, log_path=None)
     for _ in range(2 if adversarial else 1):
         trainer.run_epoch()                  # warm-up: one epoch (config 2) / a D epoch and a G epoch (config 3)
     trainer.timers.clear()
@@ -242,19 +257,28 @@ def full_epoch(device, world=1, rank=0, adversarial=False):
         d_s = next(t for ph, t in epoch_s if ph == "D")
         g_s = next(t for ph, t in epoch_s if ph == "G")
         adv = {"epochs_timed": [ph for ph, _ in epoch_s], "d_epoch_s": round(d_s, 3), "g_epoch_s": round(g_s, 3),
-               "images_per_s_at_d_times_10": round(world * 16 * 10 / (9 * d_s + g_s), 3),
+               "images_per_s_at_d_times_10": round(world * cfg.sample.num_batches_per_epoch * 8 * 10 / (9 * d_s + g_s), 3),
                "adversarial_note": "D epoch = sample + score (generated and reference images through DINOv2-B/14 @ 518 + head) + train_dino "
-                                   "(hinge on CLS + 0.3 x hinge on 64 patches, 16 real + 16 generated images, Adam on the head, TD:156-232); "
+                                   f"(hinge on CLS + 0.3 x hinge on 64 patches, {8 * cfg.sample.num_batches_per_epoch} real + {8 * cfg.sample.num_batches_per_epoch} generated images, Adam on the head, TD:156-232); "
                                    "G epoch = the same sampling + the GRPO update; phases_s sums both epochs (this rank's host clock)"}
+    if qwen:
+        adv["peak_memory_gib"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
+        adv["config5_note"] = ("Qwen-Image MMDiT LoRA (r = 32 on the 8 attention projections of all 60 blocks: 189 M padded adapter parameters), "
+                               "1024^2, ONE group of 8 images per epoch: G epoch = sampling + 2 SDE timesteps x (forward with one checkpoint "
+                               "per block + backward with per-block recomputation) at CFG batch 16 + clip + AdamW + EMA; fp8 Linears in the "
+                               "rollout and in the replay (straight-through backward)")
     return {"images": images, "seconds": round(dt, 3), "images_per_s_full_epoch": round(images / dt, 3), **adv,
             "phases_s": {k: round(v, 4) for k, v in phases.items()}, "phases_are": "max over ranks" if world > 1 else "rank 0",
             "g_step_inside": g_inside, "g_step_inside_is": "HIP events on the launch stream around each call, this rank, in situ (after the "
                                                            "sampling phase of the same epoch)",
             "exchanges": "reward all-gather once per epoch; all-reduce of the flat LoRA gradient before each optimizer step (TP:1165)",
-            "note": "sample = rollout + VAE decode; score = PickScore of generated AND reference images; g_step = "
-                    "2 groups x 2 SDE timesteps fwd+bwd at CFG batch 16 + 2 clip+AdamW steps + EMA (+ for N > 1 the all-reduce of "
-                    "the 37.6 MB flat LoRA gradient before each optimizer step); reward scoring runs on the worker stream and "
-                    "overlaps the next group's rollout, `score` is the wait at the end of the sampling loop"}
+            "note": ("sample = rollout + VAE decode; score = the DINOv2 patch discriminator on generated AND reference images; g_step = 1 group x 2 SDE "
+                     "timesteps fwd+bwd at CFG batch 16 + 1 clip+AdamW step + EMA (+ for N > 1 the all-reduce of the 755 MB flat LoRA gradient "
+                     "before the optimizer step)") if qwen else
+                    ("sample = rollout + VAE decode; score = PickScore of generated AND reference images; g_step = "
+                     "2 groups x 2 SDE timesteps fwd+bwd at CFG batch 16 + 2 clip+AdamW steps + EMA (+ for N > 1 the all-reduce of "
+                     "the 37.6 MB flat LoRA gradient before each optimizer step); reward scoring runs on the worker stream and "
+                     "overlaps the next group's rollout, `score` is the wait at the end of the sampling loop")}
 
 
 def cpu_baseline():
@@ -702,13 +726,15 @@ def main():
                      "ms_per_step": lora_ms,
                      "value_if_side": round(world * G / (lora_ms["side"] * 1e-3), 3) if "side" in lora_ms else None},
         }
-    run_epoch = not c4 and not c5 and not args.no_epoch       # at every N: for N > 1 this is the leg with the LoRA-gradient all-reduce (TP:1165)
+    run_epoch = not c4 and not args.no_epoch       # at every N: for N > 1 this is the leg with the LoRA-gradient all-reduce (TP:1165)
     if run_epoch:                                   # every rank takes part (LoRA-gradient all-reduce, reward gather)
-        if c3:
+        if c3 or c5:
             del dino, dino_head
         del pipe, clip
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
-        ep = full_epoch(device, world, rank, adversarial=c3)
+        ep = full_epoch(device, world, rank, adversarial=c3 or c5, qwen=c5)
         if rank == 0:
             res["epoch"] = ep
     if rank == 0:
