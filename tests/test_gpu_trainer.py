@@ -529,3 +529,63 @@ def test_full_size_epoch_config3(tmp_path):
     assert 0.0 <= steps[0]["approx_kl"] < 1e-8, steps[0]                  # update 0: ratio == 1 up to the bf16 cast of the latents
     for k in ("loss", "policy_loss", "approx_kl", "clipfrac", "clipfrac_gt_one", "clipfrac_lt_one"):
         assert all(torch.isfinite(torch.tensor(float(s[k]))) for s in steps), k
+
+
+def test_full_size_epoch_config5(tmp_path):
+    """BASELINE config 5 at FULL size on one rank, through the Trainer: Qwen-Image MMDiT (60 blocks, 24 x 128, LoRA r = 32 on the eight
+    attention projections of every block), 1024^2, 10 steps, G = 8, fp8 Linears in the rollout AND in the replay, Qwen-Image's own VAE
+    decoder, reward = the co-trained DINOv2-B/14 patch discriminator + head (`dino_cotrain_sd3_patch_fast` with the model set swapped:
+    the reference names the config, config/grpo.py:324,330, and ships no Qwen-Image code, README.md:75).  One group per epoch; a D epoch
+    then a G epoch (forward with one activation checkpoint per block, backward with per-block recomputation).  The property set of
+    test_full_size_epoch_config3, and the whole thing inside one GPU's memory."""
+    import json
+    from adv_grpo_amd import synthetic, vit
+    from adv_grpo_amd.config.experiments import get_config
+    from adv_grpo_amd.d_step import DinoHeadTrainable
+    from adv_grpo_amd.model_configs import DinoConfig, QwenMMDiTConfig, QwenVaeConfig
+    from adv_grpo_amd.pipeline import SD3Pipeline
+    from adv_grpo_amd.qwen_mmdit_train import QwenImageTransformerLoRA
+    from adv_grpo_amd.qwen_vae import AutoencoderKLQwenImageDecoder
+    from adv_grpo_amd.trainer import SyntheticData, Trainer
+    cfg = get_config("dino_cotrain_sd3_patch_fast", gpu_number=1)
+    cfg.sample.num_image_per_prompt = 8
+    cfg.sample.num_batches_per_epoch = 1
+    cfg.train.gradient_accumulation_steps = 1
+    cfg.d_times = 2
+    cfg.resolution = 1024
+    cfg.linear_dtype = "fp8"
+    qcfg, vcfg, dcfg = QwenMMDiTConfig(), QwenVaeConfig(), DinoConfig()
+    torch.cuda.reset_peak_memory_stats()
+    with synthetic.on_device("cuda"):
+        tr = QwenImageTransformerLoRA(synthetic.qwen_mmdit_weights(qcfg, 4242, dtype=torch.bfloat16), qcfg, "cuda", seed=cfg.seed)
+        vae = AutoencoderKLQwenImageDecoder(synthetic.qwen_vae_decoder_weights(vcfg, 2468, dtype=torch.bfloat16), vcfg, "cuda")
+        scorer = vit.DinoV2(synthetic.dino_weights(dcfg, 888), dcfg, "cuda")
+    head = DinoHeadTrainable(device="cuda", seed=0)
+    log = tmp_path / "metrics.jsonl"
+    data = SyntheticData(n_tokens=128, ctx_dim=3584, pooled_dim=8, resolution=1024, device="cuda")
+    trainer = Trainer(cfg, SD3Pipeline(tr, vae, "cuda"), data, scorer, head, 0, 1, log_path=str(log))
+    assert trainer.needs_reference and trainer.variant == "dino" and tr.fp8 is not None
+    p0, h0 = tr.params.clone(), head.params.clone()
+    a = trainer.run_epoch()
+    torch.cuda.synchronize()
+    assert a["phase"] == "D" and torch.isfinite(torch.tensor(float(a["train/d_loss"]))) and 0.0 <= float(a["train/acc"]) <= 1.0
+    assert not torch.equal(head.params, h0) and torch.isfinite(head.params).all() and torch.equal(tr.params, p0)
+    h1 = head.params.clone()
+    b = trainer.run_epoch()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    print(f"config 5 epochs: phases {trainer.timers}, d_loss {float(a['train/d_loss']):.4f}, acc {float(a['train/acc']):.3f}, peak memory {peak:.1f} GiB")
+    assert b["phase"] == "G" and trainer.epoch == 2 and peak < 200
+    assert torch.isfinite(tr.params).all() and not torch.equal(tr.params, p0) and (tr.grads == 0).all() and torch.equal(head.params, h1)
+    recs = [json.loads(l) for l in open(log)]
+    ep = [r for r in recs if "reward_avg" in r]
+    assert len(ep) == 2
+    for r in ep:
+        for k in ("reward_avg", "reference_reward_avg", "zero_std_ratio", "reward_std_mean", "group_size", "trained_prompt_num"):
+            assert k in r and torch.isfinite(torch.tensor(float(r[k]))), (k, r)
+        assert r["group_size"] == 8
+    steps = [r for r in recs if "approx_kl" in r]
+    assert len(steps) == 1
+    assert 0.0 <= steps[0]["approx_kl"] < 1e-7, steps[0]          # update 0: the fp8 replay repeats the fp8 rollout (up to the bf16 cast of the stored latents)
+    for k in ("loss", "policy_loss", "approx_kl", "clipfrac", "clipfrac_gt_one", "clipfrac_lt_one"):
+        assert torch.isfinite(torch.tensor(float(steps[0][k]))), k
