@@ -29,14 +29,18 @@ constexpr int B8_CB = 2;              // 16-row blocks of own rows per wave: eve
 constexpr int B8_OWN = 64 * B8_CB;    // own rows per workgroup (16 B8_CB per wave)
 constexpr int B8_ROWS = 32;           // streamed rows per tile
 constexpr int B8_HD = 128;
-constexpr int B8_RP = B8_HD + 8;      // row-major tile pitch (elements): 272 bytes, rows 4 banks apart
-constexpr int B8_TP = B8_ROWS + 8;    // transposed tile pitch (elements): 80 bytes
+constexpr int B8_RP = B8_HD;          // row-major tile pitch (elements): 256 bytes; 16-byte chunk c of row r sits at chunk c ^ (r & 15),
+                                      // so the 16 rows x 4 chunks of one fragment read spread evenly over the 64 banks
+constexpr int B8_TP = B8_ROWS + 4;    // transposed tile pitch (elements): 72 bytes -- the eight d-rows one wave's transposing
+                                      // stores hit are 576 bytes apart: four bank groups (80 bytes put them on two)
 constexpr int B8_ROWMAJ = B8_ROWS * B8_RP * 2, B8_TRANS = B8_HD * B8_TP * 2;      // bytes
 
 __device__ __forceinline__ uint32_t b8_pack(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
+// (two waves per SIMD: the dK/dV instantiation would take 314 registers and run one wave per SIMD, 15 % slower than with the few
+// spills this bound costs it)
 template <bool DKDV>
-__global__ __launch_bounds__(256) void attn_bwd_d128_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_d128_kernel(const AttnBwdParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * B8_ROWMAJ + 2 * B8_TRANS + 2 * B8_ROWS * 4];
     bf16_t* x0 = reinterpret_cast<bf16_t*>(smem);                        // streamed operand 0 (K | Q), row-major
     bf16_t* x1 = reinterpret_cast<bf16_t*>(smem + B8_ROWMAJ);             // streamed operand 1 (V | dO), row-major
@@ -106,14 +110,27 @@ __global__ __launch_bounds__(256) void attn_bwd_d128_kernel(const AttnBwdParams 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int ch = lch + 8 * i;
-            *reinterpret_cast<uint4*>(x0 + lrow * B8_RP + ch * 8) = g0[i];
-            *reinterpret_cast<uint4*>(x1 + lrow * B8_RP + ch * 8) = g1[i];
+            *reinterpret_cast<uint4*>(x0 + lrow * B8_RP + ((ch ^ (lrow & 15)) * 8)) = g0[i];
+            *reinterpret_cast<uint4*>(x1 + lrow * B8_RP + ((ch ^ (lrow & 15)) * 8)) = g1[i];
+            // transposed copy [d][row] as 4-byte stores of two neighbouring rows: the lane 8 further on holds row lrow ^ 1 of the same
+            // chunk (DPP row_ror:8 swaps the halves of a 16-lane row); the even row's lane writes d = 8 ch + 0..3, the odd row's 4..7
             const uint32_t w0[4] = {g0[i].x, g0[i].y, g0[i].z, g0[i].w}, w1[4] = {g1[i].x, g1[i].y, g1[i].z, g1[i].w};
+            const int odd = lrow & 1;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int d = ch * 8 + e;
-                x0t[d * B8_TP + lrow] = (bf16_t)((w0[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-                if constexpr (DKDV) x1t[d * B8_TP + lrow] = (bf16_t)((w1[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+            for (int j = 0; j < 2; ++j) {                     // dword j (+ 2 for the odd row's lane) = d pair (2j, 2j + 1) (+ 4)
+                const uint32_t mine0 = odd ? w0[j + 2] : w0[j], give0 = odd ? w0[j] : w0[j + 2];
+                const uint32_t got0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give0, 0x128, 0xf, 0xf, true);
+                const uint32_t ev0 = odd ? got0 : mine0, od0 = odd ? mine0 : got0;      // (even row's value, odd row's value) of the d pair
+                const int d = ch * 8 + 4 * odd + 2 * j;
+                *reinterpret_cast<uint32_t*>(x0t + d * B8_TP + (lrow & ~1)) = (ev0 & 0xffffu) | (od0 << 16);
+                *reinterpret_cast<uint32_t*>(x0t + (d + 1) * B8_TP + (lrow & ~1)) = (ev0 >> 16) | (od0 & 0xffff0000u);
+                if constexpr (DKDV) {
+                    const uint32_t mine1 = odd ? w1[j + 2] : w1[j], give1 = odd ? w1[j] : w1[j + 2];
+                    const uint32_t got1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give1, 0x128, 0xf, 0xf, true);
+                    const uint32_t ev1 = odd ? got1 : mine1, od1 = odd ? mine1 : got1;
+                    *reinterpret_cast<uint32_t*>(x1t + d * B8_TP + (lrow & ~1)) = (ev1 & 0xffffu) | (od1 << 16);
+                    *reinterpret_cast<uint32_t*>(x1t + (d + 1) * B8_TP + (lrow & ~1)) = (ev1 >> 16) | (od1 & 0xffff0000u);
+                }
             }
         }
         if constexpr (DKDV) {
@@ -137,8 +154,8 @@ __global__ __launch_bounds__(256) void attn_bwd_d128_kernel(const AttnBwdParams 
             for (int cb = 0; cb < B8_CB; ++cb) { sc[rb][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[rb][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(x0 + (rb * 16 + col) * B8_RP + ks * 32 + kg * 8);
-                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(x1 + (rb * 16 + col) * B8_RP + ks * 32 + kg * 8);
+                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(x0 + (rb * 16 + col) * B8_RP + (((ks * 4 + kg) ^ col) * 8));
+                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(x1 + (rb * 16 + col) * B8_RP + (((ks * 4 + kg) ^ col) * 8));
 #pragma unroll
                 for (int cb = 0; cb < B8_CB; ++cb) {
                     sc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[cb][ks], sc[rb][cb], 0, 0, 0);

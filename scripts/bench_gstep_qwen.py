@@ -1,5 +1,5 @@
 """One G-step micro-batch of BASELINE config 5 at full size: Qwen-Image MMDiT (60 blocks, 24 x 128), 1024^2, CFG batch 16 (G = 8),
-128 text tokens: forward with one checkpoint per block + backward with per-block recomputation.  `python scripts/bench_gstep_qwen.py [layers]`"""
+128 text tokens: forward with one checkpoint per block + backward with per-block recomputation.  `python scripts/bench_gstep_qwen.py [layers] [fp8]`"""
 import sys, time
 import torch
 sys.path.insert(0, ".")
@@ -10,10 +10,13 @@ from adv_grpo_amd.qwen_mmdit_train import QwenImageTransformerLoRA
 from adv_grpo_amd.scheduler import FlowMatchEulerDiscreteScheduler
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+FP8 = len(sys.argv) > 2 and sys.argv[2] == "fp8"
 dev = "cuda"
 cfg = QwenMMDiTConfig(num_layers=L)
 with synthetic.on_device(dev):
     model = QwenImageTransformerLoRA(synthetic.qwen_mmdit_weights(cfg, 4242, dtype=torch.bfloat16), cfg, dev)
+if FP8:
+    model.enable_fp8()
 print(f"model + transposes + optimiser state: {torch.cuda.memory_allocated() / 2**30:.1f} GiB", flush=True)
 G, Nt = 8, 128
 sch = FlowMatchEulerDiscreteScheduler(device=dev); sch.set_timesteps(10)
@@ -34,7 +37,7 @@ for _ in range(n):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 f = 2 * G * flops_per_sample_forward(cfg, 4096, Nt) / 1e12
-print(f"micro-step (CFG batch {2 * G}, {L} blocks): {dt * 1e3:.0f} ms; peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+print(f"micro-step (CFG batch {2 * G}, {L} blocks, {'fp8 replay' if FP8 else 'bf16'} Linears): {dt * 1e3:.0f} ms; peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 print(f"  1 forward + 1 data gradient = {2 * f:.0f} TFLOP credited (recomputation and adapter gradients not counted): "
       f"{2 * f / dt:.0f} TFLOP/s = {2 * f / dt / 2500:.3f} of the bf16 peak")
 t0 = time.perf_counter()
