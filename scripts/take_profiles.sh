@@ -13,12 +13,20 @@ python $R/bench.py --steps 5 --warmup 2 > $O/bench_c2.json 2> $O/bench_c2.err
 python $R/bench.py --config c4 --steps 3 --warmup 1 > $O/bench_c4.json 2> $O/bench_c4.err
 python $R/bench.py --config c3 --steps 5 --warmup 2 > $O/bench_c3.json 2> $O/bench_c3.err
 python $R/bench.py --config c5 --steps 3 --warmup 1 > $O/bench_c5.json 2> $O/bench_c5.err
-rocprofv3 --kernel-trace --stats -d $O/kt_c5 -o x -- python $R/bench.py --config c5 --steps 1 --warmup 1 --no-pricing > $O/bench_c5_prof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $O/kt_c5 -o x -- python $R/bench.py --config c5 --steps 1 --warmup 1 --no-pricing --no-epoch > $O/bench_c5_prof.json 2>/dev/null
 python $R/scripts/rocpd_stats.py $O/kt_c5/x_results.db $O/kernel_stats_c5.md > /dev/null
 rocprofv3 --kernel-trace --stats -d $O/kt_c3 -o x -- python $R/bench.py --config c3 --steps 1 --warmup 1 --no-pricing > $O/bench_c3_prof.json 2>/dev/null
 python $R/scripts/rocpd_stats.py $O/kt_c3/x_results.db $O/kernel_stats_c3_with_epoch_legs.md > /dev/null
 python $R/scripts/bench_attention_d128.py 10 > $O/attention_d128.txt 2>/dev/null
 python $R/scripts/bench_attention_bwd.py > $O/attention_bwd.txt 2>/dev/null
+# config 5's pieces: its VAE decoder, the head-dim-128 attention backward, one full-size G-step micro-batch, the kernel table of a 6-block one
+export PYTHONPATH=$R
+python $R/scripts/probes/qwen_vae_time.py 2>/dev/null | grep -v amdgpu > $O/qwen_vae.txt
+python $R/scripts/probes/attn_bwd_d128_time.py 2>/dev/null | grep -v amdgpu > $O/attention_bwd_d128.txt
+python $R/scripts/bench_gstep_qwen.py 60 fp8 2>/dev/null | grep -v amdgpu > $O/gstep_qwen.txt
+python $R/scripts/bench_gstep_qwen.py 60 2>/dev/null | grep -v amdgpu >> $O/gstep_qwen.txt
+rocprofv3 --kernel-trace --stats -d $O/kt_gq -o x -- python $R/scripts/bench_gstep_qwen.py 6 fp8 > /dev/null 2>&1
+python $R/scripts/rocpd_stats.py $O/kt_gq/x_results.db $O/kernel_stats_gstep_qwen_6_blocks.md > /dev/null
 GRAFT_REPO_ROOT=$R bash $R/scripts/probes/pmc_attention_bwd.sh 2 >> $O/attention_bwd.txt 2>/dev/null
 cd /tmp
 # 2. kernel tables: rollout (timed configuration only) and one G-step micro-batch
@@ -39,5 +47,5 @@ done
 # 4. matrix-pipe busy share of the MFMA kernels
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY -d $O/pmc_mfma -o x -- python $R/bench.py --steps 1 --warmup 1 --no-epoch --no-cpu-baseline --no-pricing > /dev/null 2>&1
 python $R/scripts/pmc_db.py $O/pmc_mfma/x_results.db advgrpo > $O/pmc_mfma.txt
-rm -rf $O/kt_c2 $O/kt_c3 $O/kt_c5 $O/kt_gstep $O/pmc_c2* $O/pmc_c4_* $O/pmc_c4 $O/pmc_c5_* $O/pmc_c5 $O/pmc_mfma
+rm -rf $O/kt_c2 $O/kt_c3 $O/kt_c5 $O/kt_gstep $O/kt_gq $O/pmc_c2* $O/pmc_c4_* $O/pmc_c4 $O/pmc_c5_* $O/pmc_c5 $O/pmc_mfma
 ls -la $O
