@@ -92,7 +92,7 @@ def _matrix_unit(dev, g):
         r = torch.nn.functional.scaled_dot_product_attention(heads(q), heads(k), heads(v)).transpose(1, 2).reshape(1, S_att, Hh * hd)
         err = (o.cpu().float() - r).abs().max().item()
         assert err < 2e-2, f"attention head dim {hd}: max error {err}"
-        if hd == 64:      # the pipelined backward kernels (dQ and dK / dV) against autograd of the same fp32 attention
+        if True:          # the backward kernels (dQ and dK / dV; head dim 64: pipelined, 128: attention_bwd_d128.hip) against autograd of the same fp32 attention
             lse = torch.empty(1, Hh, S_att, dtype=torch.float32, device=dev)
             o = ops.attention(dq[..., :Hh * hd], dq[..., Hh * hd:2 * Hh * hd], dq[..., 2 * Hh * hd:], Hh, lse=lse)
             d_o = rnd(1, S_att, Hh * hd).to(bf16)
@@ -105,7 +105,7 @@ def _matrix_unit(dev, g):
                 r.backward(d_o.float())
             want = torch.cat([t.grad for t in leaf], dim=-1)
             rel = ((grads.cpu().float() - want).norm() / want.norm()).item()
-            assert rel < 2e-2, f"attention backward: relative error {rel}"
+            assert rel < 2e-2, f"attention backward (head dim {hd}): relative error {rel}"
     # ---- split-bf16 ("fp32-equivalent") 3 x 3 convolution, one 16 x 24 image of 64 -> 128 channels
     x = rnd(1, 16, 24, 64)
     wc, bc = rnd(128, 64, 3, 3, k=(64 * 9) ** -0.5), rnd(128, k=0.1)
@@ -115,3 +115,12 @@ def _matrix_unit(dev, g):
     r = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), wc.double(), bc.double(), padding=1).permute(0, 2, 3, 1)
     err = (y.cpu().double() - r).abs().max().item()
     assert err < 2e-4, f"conv3x3_x3: max error {err}"
+    # ---- the Qwen-Image decoder's pieces: per-pixel RMS norm -> [hi | . | lo] rows -> two-product convolution on one-piece bf16 weights
+    gam = 1 + 0.1 * rnd(64)
+    wb = wc.to(bf16)
+    a2 = ops.rmsnorm_nhwc(d(x), d(gam), 8.0, silu=True, out="x3pair")
+    y2 = ops.conv3x3_f16x2(a2, d(wb).permute(0, 2, 3, 1).reshape(128, -1).contiguous(), bias=dbc, bf16_pieces=True)
+    xn = torch.nn.functional.silu(torch.nn.functional.normalize(x, dim=-1) * 8.0 * gam)
+    r2 = torch.nn.functional.conv2d(xn.permute(0, 3, 1, 2).double(), wb.double(), bc.double(), padding=1).permute(0, 2, 3, 1)
+    err = (y2.cpu().double() - r2).abs().max().item()
+    assert err < 2e-4, f"rmsnorm_nhwc + conv3x3 bf16x2: max error {err}"
