@@ -17,6 +17,8 @@
 // products once the contraction index is permuted (slot j of k-group g <-> streamed row 16 (j >> 2) + 4 g + (j & 3)): P and dS
 // never leave registers, and the A operand (the streamed tile transposed, [d][32 rows] in LDS) is read with the same permutation
 // as two 8-byte reads.
+#include <stdlib.h>
+
 #include "attention_bwd.hpp"
 
 namespace advgrpo {
@@ -25,8 +27,7 @@ namespace {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int B8_CB = 2;              // 16-row blocks of own rows per wave: every A fragment read from LDS feeds B8_CB MFMAs
-constexpr int B8_OWN = 64 * B8_CB;    // own rows per workgroup (16 B8_CB per wave)
+// B8_CB (template): 16-row blocks of own rows per wave -- every A fragment read from LDS feeds B8_CB MFMAs; a workgroup owns 64 B8_CB rows
 constexpr int B8_ROWS = 32;           // streamed rows per tile
 constexpr int B8_HD = 128;
 constexpr int B8_RP = B8_HD;          // row-major tile pitch (elements): 256 bytes; 16-byte chunk c of row r sits at chunk c ^ (r & 15),
@@ -39,8 +40,9 @@ __device__ __forceinline__ uint32_t b8_pack(float lo, float hi) { return (uint32
 
 // (two waves per SIMD: the dK/dV instantiation would take 314 registers and run one wave per SIMD, 15 % slower than with the few
 // spills this bound costs it)
-template <bool DKDV>
-__global__ __launch_bounds__(256, 2) void attn_bwd_d128_kernel(const AttnBwdParams p) {
+template <bool DKDV, int B8_CB>
+__global__ __launch_bounds__(256, B8_CB == 1 ? (DKDV ? 3 : 4) : 2) void attn_bwd_d128_kernel(const AttnBwdParams p) {
+    constexpr int B8_OWN = 64 * B8_CB;
     __shared__ __attribute__((aligned(16))) char smem[2 * B8_ROWMAJ + 2 * B8_TRANS + 2 * B8_ROWS * 4];
     bf16_t* x0 = reinterpret_cast<bf16_t*>(smem);                        // streamed operand 0 (K | Q), row-major
     bf16_t* x1 = reinterpret_cast<bf16_t*>(smem + B8_ROWMAJ);             // streamed operand 1 (V | dO), row-major
@@ -268,11 +270,15 @@ __global__ __launch_bounds__(256) void attn_bwd_delta128_kernel(const AttnBwdPar
 int attention_bwd_d128_launch(const AttnBwdParams& p, int B, hipStream_t s) {
     hipLaunchKernelGGL(attn_bwd_delta128_kernel, dim3((unsigned)(((int64_t)B * p.Sq + 3) / 4)), dim3(256), 0, s, p, B);
     ADVGRPO_LAUNCH_CHECK();
-    const int64_t nq = (int64_t)((p.Sq + B8_OWN - 1) / B8_OWN) * p.H * B, nk = (int64_t)((p.Skv + B8_OWN - 1) / B8_OWN) * p.H * B;
+    static const int cbq = getenv("B8_CBQ") ? atoi(getenv("B8_CBQ")) : 2, cbk = getenv("B8_CBK") ? atoi(getenv("B8_CBK")) : 2;   // TEMPORARY A/B
+    const int ownq = 64 * cbq, ownk = 64 * cbk;
+    const int64_t nq = (int64_t)((p.Sq + ownq - 1) / ownq) * p.H * B, nk = (int64_t)((p.Skv + ownk - 1) / ownk) * p.H * B;
     ADVGRPO_CHECK(nq < (1ll << 31) && nk < (1ll << 31), "attention_bwd (d128): grid too large");
-    hipLaunchKernelGGL(attn_bwd_d128_kernel<false>, dim3((unsigned)nq), dim3(256), 0, s, p);
+    if (cbq == 1) hipLaunchKernelGGL((attn_bwd_d128_kernel<false, 1>), dim3((unsigned)nq), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_bwd_d128_kernel<false, 2>), dim3((unsigned)nq), dim3(256), 0, s, p);
     ADVGRPO_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_d128_kernel<true>, dim3((unsigned)nk), dim3(256), 0, s, p);
+    if (cbk == 1) hipLaunchKernelGGL((attn_bwd_d128_kernel<true, 1>), dim3((unsigned)nk), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_bwd_d128_kernel<true, 2>), dim3((unsigned)nk), dim3(256), 0, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
