@@ -10,15 +10,13 @@
 // loads with the next tile's global loads in flight during the products; NOT software-pipelined like the head-dim-64 kernel.
 //   dQ    (DKDV = false): a workgroup owns 128 queries (wave = 32, as two 16-row blocks) and streams the keys in tiles of 32:
 //           S^T = K Q^T, P^T = exp2(c S^T - L[q]), dP^T = V dO^T, dS^T = P^T (dP^T - D[q]), dQ^T += K^T dS^T
-//   dK/dV (DKDV = true):  a workgroup owns 128 keys and streams the queries:
+//   dK/dV (DKDV = true):  a workgroup owns 64 keys (wave = 16) and streams the queries:
 //           S = Q K^T, P = exp2(c S - L[q]), dP = dO V^T, dS = P (dP - D[q]), dV^T += dO^T P, dK^T += Q^T dS
 // In both, the OWN side is the B operand of every product (lane & 15 = own row), so the score tile comes out of the matrix unit
 // with C layout "column = own row, rows = streamed rows (lane >> 4) * 4 + r" -- which IS the B-operand layout of the accumulating
 // products once the contraction index is permuted (slot j of k-group g <-> streamed row 16 (j >> 2) + 4 g + (j & 3)): P and dS
 // never leave registers, and the A operand (the streamed tile transposed, [d][32 rows] in LDS) is read with the same permutation
 // as two 8-byte reads.
-#include <stdlib.h>
-
 #include "attention_bwd.hpp"
 
 namespace advgrpo {
@@ -38,8 +36,6 @@ constexpr int B8_ROWMAJ = B8_ROWS * B8_RP * 2, B8_TRANS = B8_HD * B8_TP * 2;    
 
 __device__ __forceinline__ uint32_t b8_pack(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
-// (two waves per SIMD: the dK/dV instantiation would take 314 registers and run one wave per SIMD, 15 % slower than with the few
-// spills this bound costs it)
 template <bool DKDV, int B8_CB>
 __global__ __launch_bounds__(256, B8_CB == 1 ? (DKDV ? 3 : 4) : 2) void attn_bwd_d128_kernel(const AttnBwdParams p) {
     constexpr int B8_OWN = 64 * B8_CB;
@@ -141,6 +137,8 @@ __global__ __launch_bounds__(256, B8_CB == 1 ? (DKDV ? 3 : 4) : 2) void attn_bwd
     };
 
     const int nt = (n_str + B8_ROWS - 1) / B8_ROWS;
+    f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+    asm volatile("" : "+v"(zero4));            // (opaque: stays ONE register quad instead of being re-materialised per use)
     fetch(0);
     for (int t = 0; t < nt; ++t) {
         __syncthreads();                      // everyone is done with the previous tile
@@ -148,20 +146,20 @@ __global__ __launch_bounds__(256, B8_CB == 1 ? (DKDV ? 3 : 4) : 2) void attn_bwd
         __syncthreads();
         if (t + 1 < nt) fetch(t + 1);         // in flight during the products
 
+        const bool last_ragged = t == nt - 1 && nt * B8_ROWS > n_str;       // (uniform: only the last tile of a ragged sequence masks keys)
         // ---- scores and dP of the two 16-row blocks of the tile x the wave's B8_CB own-row blocks
         f32x4_t sc[2][B8_CB], dp[2][B8_CB];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-#pragma unroll
-            for (int cb = 0; cb < B8_CB; ++cb) { sc[rb][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[rb][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(x0 + (rb * 16 + col) * B8_RP + (((ks * 4 + kg) ^ col) * 8));
                 const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(x1 + (rb * 16 + col) * B8_RP + (((ks * 4 + kg) ^ col) * 8));
 #pragma unroll
                 for (int cb = 0; cb < B8_CB; ++cb) {
-                    sc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[cb][ks], sc[rb][cb], 0, 0, 0);
-                    dp[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[cb][ks], dp[rb][cb], 0, 0, 0);
+                    // (the first product starts from ONE zero quad kept outside the tile loop: no per-tile clearing of 32 registers)
+                    sc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[cb][ks], ks == 0 ? zero4 : sc[rb][cb], 0, 0, 0);
+                    dp[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[cb][ks], ks == 0 ? zero4 : dp[rb][cb], 0, 0, 0);
                 }
             }
         }
@@ -177,7 +175,7 @@ __global__ __launch_bounds__(256, B8_CB == 1 ? (DKDV ? 3 : 4) : 2) void attn_bwd
                     const int sr = rb * 16 + kg * 4 + r;
                     float nl, nd;
                     if constexpr (DKDV) { nl = lvec[sr]; nd = dvec[sr]; }
-                    else { nl = (t * B8_ROWS + sr < n_str) ? negL_own[cb] : -INFINITY; nd = negD_own[cb]; }      // a key past the end: P = 0
+                    else { nl = (last_ragged && t * B8_ROWS + sr >= n_str) ? -INFINITY : negL_own[cb]; nd = negD_own[cb]; }   // a key past the end: P = 0
                     const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[rb][cb][r], c, nl));
                     pv[rb * 4 + r] = pe;
                     ds[rb * 4 + r] = pe * (dp[rb][cb][r] + nd);
@@ -270,15 +268,14 @@ __global__ __launch_bounds__(256) void attn_bwd_delta128_kernel(const AttnBwdPar
 int attention_bwd_d128_launch(const AttnBwdParams& p, int B, hipStream_t s) {
     hipLaunchKernelGGL(attn_bwd_delta128_kernel, dim3((unsigned)(((int64_t)B * p.Sq + 3) / 4)), dim3(256), 0, s, p, B);
     ADVGRPO_LAUNCH_CHECK();
-    static const int cbq = getenv("B8_CBQ") ? atoi(getenv("B8_CBQ")) : 2, cbk = getenv("B8_CBK") ? atoi(getenv("B8_CBK")) : 2;   // TEMPORARY A/B
-    const int ownq = 64 * cbq, ownk = 64 * cbk;
-    const int64_t nq = (int64_t)((p.Sq + ownq - 1) / ownq) * p.H * B, nk = (int64_t)((p.Skv + ownk - 1) / ownk) * p.H * B;
+    // dQ: two own-row blocks per wave (234 registers, two waves per SIMD); dK/dV: ONE (two accumulator sets: with two blocks it needs
+    // 314 registers -- one wave per SIMD, or spills that cost 50 % -- with one block 3 waves per SIMD; same-box A/B 17.5 vs 19.0 ms)
+    constexpr int CBQ = 2, CBK = 1;
+    const int64_t nq = (int64_t)((p.Sq + 64 * CBQ - 1) / (64 * CBQ)) * p.H * B, nk = (int64_t)((p.Skv + 64 * CBK - 1) / (64 * CBK)) * p.H * B;
     ADVGRPO_CHECK(nq < (1ll << 31) && nk < (1ll << 31), "attention_bwd (d128): grid too large");
-    if (cbq == 1) hipLaunchKernelGGL((attn_bwd_d128_kernel<false, 1>), dim3((unsigned)nq), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_bwd_d128_kernel<false, 2>), dim3((unsigned)nq), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((attn_bwd_d128_kernel<false, CBQ>), dim3((unsigned)nq), dim3(256), 0, s, p);
     ADVGRPO_LAUNCH_CHECK();
-    if (cbk == 1) hipLaunchKernelGGL((attn_bwd_d128_kernel<true, 1>), dim3((unsigned)nk), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_bwd_d128_kernel<true, 2>), dim3((unsigned)nk), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((attn_bwd_d128_kernel<true, CBK>), dim3((unsigned)nk), dim3(256), 0, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

@@ -9,9 +9,10 @@ fused AdamW -- those methods are SD3TransformerLoRA's own, bound here unchanged.
 
 What differs from the SD3 model:
   * ACTIVATION RECOMPUTATION PER BLOCK.  Sixty blocks at CFG batch 16 and 4224 joint tokens would keep ~7 GB of activations
-    each (440 GB); `forward_train` keeps only the two residual streams entering every block (0.4 GB per block) and `backward`
-    re-runs one block's forward -- the same launches, so the same bits -- before differentiating it: 4/3 of the matrix work
-    for 1/17 of the memory, the whole model + optimiser + checkpoints inside one GPU's 288 GB.
+    each (440 GB); `forward_train` keeps only the two residual streams entering every block and the block's attention output +
+    log-sum-exp (0.8 GB per block) and `backward` re-runs the block's Linears and row kernels -- the same launches, so the same
+    bits; not the attention, not the feed-forward's second Linear -- before differentiating it: ~1.25 x the matrix work for 1/9
+    of the memory, the whole model + optimiser + checkpoints inside one GPU's 288 GB.
   * head dim 128: `attention_bwd_d128.hip`; QK-norm + rotary backward: `advgrpo_qk_norm_rope_bwd` (the forward's in-place kernel
     saves 1/rms per head).
   * every block is a full two-stream block (no dual attention, no context_pre_only last block): the text stream's gradient
@@ -34,6 +35,7 @@ GROUPS = {"qkv": ("to_q", "to_k", "to_v"), "cqkv": ("add_q_proj", "add_k_proj", 
 
 class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
     lora_mode = "merged"
+    keep_attention = True      # the checkpoint of a block also holds its attention output + log-sum-exp (0.42 GB per block at config 5)
 
     def __init__(self, state_dict, cfg, device="cuda", lora_alpha=64, seed=0, lora_state=None):
         super().__init__(state_dict, cfg, device)
@@ -94,8 +96,11 @@ class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
         self.w["proj_out.wT"] = T(self.w["proj_out.w"])
 
     # ------------------------------------------------------------------ one block, bf16 Linears: the launches of __call__
-    def _block(self, i, x, c, mods, rope, B, Ni, Nt, save=None):
-        """In place on x [B * Ni, D], c [B * Nt, D].  `save` (a dict) receives what the block's backward needs."""
+    def _block(self, i, x, c, mods, rope, B, Ni, Nt, save=None, keep_att=None, att_kept=None):
+        """In place on x [B * Ni, D], c [B * Nt, D].  `save` (a dict) receives what the block's backward needs -- the RE-RUN inside
+        backward(): it takes the attention output and log-sum-exp the first run kept (`att_kept`) instead of launching the attention
+        again, and stops after the feed-forward's first Linear (nothing differentiates the block's output).  `keep_att` (a list):
+        the first run appends (att, lse)."""
         cfg, b = self.cfg, self.blocks[i]
         D, H, hd = cfg.dim, cfg.num_heads, cfg.head_dim
         S, Mi, Mt = Ni + Nt, B * Ni, B * Nt
@@ -132,9 +137,14 @@ class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
         linears([(nx_in, "qkv", dict(out=qkv, seg=(Ni, S, 0))), (nc_in, "cqkv", dict(out=qkv, seg=(Nt, S, Ni)))])
         rs = torch.empty(B * S, 2 * H, dtype=torch.float32, device=dev) if save is not None else None
         ops.qk_norm_rope(qkv, S, Ni, 2 * H, hd, b["rms_x"], b["rms_c"], H, rope=rope, eps=1e-6, rs_out=rs)
-        att = torch.empty(B, S, D, dtype=bf16, device=dev)
-        lse = torch.empty(B, H, S, dtype=torch.float32, device=dev) if save is not None else None
-        ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att, lse=lse)
+        if att_kept is not None:
+            att, lse = att_kept
+        else:
+            att = torch.empty(B, S, D, dtype=bf16, device=dev)
+            lse = torch.empty(B, H, S, dtype=torch.float32, device=dev) if (save is not None or keep_att is not None) else None
+            ops.attention(qkv3[:, :, :D], qkv3[:, :, D:2 * D], qkv3[:, :, 2 * D:], H, out=att, lse=lse)
+            if keep_att is not None:
+                keep_att.append((att, lse))
         att2d = att.view(B * S, D)
         if f8 is not None:
             ops.quant_fp8_rows(att2d, out=q_n, split=(Ni, S))
@@ -156,12 +166,16 @@ class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
             h_all = torch.empty(Mi + Mt, 4 * D, dtype=bf16, device=dev)
             linears([(q_n.rows(0, Mi), "ff1", dict(act="gelu_tanh", out=h_all[:Mi], **aux(pre))),
                      (q_n.rows(Mi, Mi + Mt), "cff1", dict(act="gelu_tanh", out=h_all[Mi:], **aux(cpre)))])
+            if save is not None:
+                return
             q_h = ops.quant_fp8_rows(h_all)
             hm = [q_h.rows(0, Mi), q_h.rows(Mi, Mi + Mt)]
         else:
             nx2 = ops.layernorm_mod(x, scale=mod(kx, 4), shift=mod(kx, 3), rows_per_batch=Ni)
             nc2 = ops.layernorm_mod(c, scale=mod(kc, 4), shift=mod(kc, 3), rows_per_batch=Nt)
             hm = linears([(nx2, "ff1", dict(act="gelu_tanh", **aux(pre))), (nc2, "cff1", dict(act="gelu_tanh", **aux(cpre)))])
+        if save is not None:
+            return
         linears([(hm[0], "ff2", dict(gate=mod(kx, 5), gate_rows=Ni, residual=x, out=x)),
                  (hm[1], "cff2", dict(gate=mod(kc, 5), gate_rows=Nt, residual=c, out=c))])
 
@@ -180,11 +194,11 @@ class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
         mods = mods.expand(B, -1) if mods.shape[0] == 1 else mods
         c = self.embed_context(encoder_hidden_states)
         rope = self._rope(hh, ww, Nt)
-        ctx = {"B": B, "Ni": Ni, "Nt": Nt, "h": h, "w": wd, "mods": mods, "rope": rope, "x_in": [], "c_in": []}
+        ctx = {"B": B, "Ni": Ni, "Nt": Nt, "h": h, "w": wd, "mods": mods, "rope": rope, "x_in": [], "c_in": [], "att": []}
         for i in range(cfg.num_layers):
             ctx["x_in"].append(x.clone())
             ctx["c_in"].append(c.clone())
-            self._block(i, x, c, mods, rope, B, Ni, Nt)
+            self._block(i, x, c, mods, rope, B, Ni, Nt, keep_att=ctx["att"] if self.keep_attention else None)
         ctx["x_final"] = x
         o = self.mod_off[("out",)]
         nx = ops.layernorm_mod(x, scale=mods[:, o:o + D], shift=mods[:, o + D:o + 2 * D], rows_per_batch=Ni)
@@ -217,7 +231,7 @@ class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
             b, s = self.blocks[i], {}
             kx, kc = ("x", i), ("c", i)
             x_in, c_in = ctx["x_in"][i], ctx["c_in"][i]
-            self._block(i, x_in.clone(), c_in.clone(), mods, rope, B, Ni, Nt, save=s)
+            self._block(i, x_in.clone(), c_in.clone(), mods, rope, B, Ni, Nt, save=s, att_kept=ctx["att"][i] if ctx["att"] else None)
             # ---- MLPs (the text-stream GEMMs ride in the launches of their image-stream twins, as in the forward)
             dyg, dcyg = ops.gate_mul(dx, mod(kx, 5), Ni), ops.gate_mul(dc, mod(kc, 5), Nt)
             dpres = ops.gemm_grouped([ops.gemm_desc(dyg, b["ff2.wT"], act="dgelu_tanh", aux_in=s["pre"]),
@@ -248,6 +262,8 @@ class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
             dx = ops.layernorm_mod_bwd(x_in, dnx, scale0=mod(kx, 1), dres=dx1, rows_per_batch=Ni)
             dc = ops.layernorm_mod_bwd(c_in, dnc, scale0=mod(kc, 1), dres=dc1, rows_per_batch=Nt)
             ctx["x_in"][i] = ctx["c_in"][i] = None       # the checkpoint is spent
+            if ctx["att"]:
+                ctx["att"][i] = None
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         return dx, dc

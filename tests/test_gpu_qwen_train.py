@@ -151,7 +151,7 @@ def test_qwen_lora_backward_vs_autograd_full_width():
     _lora_case(QwenMMDiTConfig(num_layers=2), 43, B=2, hw=64, Nt=64)
 
 
-def test_qwen_g_step_chain_rollout_replay_loss_backward_adamw():
+def test_qwen_g_step_chain_rollout_replay_loss_backward_adamw(tmp_path):
     """Config 5's loop in small: the SD3 rollout function drives the LoRA model (4 steps, SDE window 2), then every trained timestep
     goes through g_step.micro_step (compute_log_prob TP:233-267 -> GRPO loss TP:1111-1130 -> backward TP:1165): the replayed
     log-probs are the rollout's up to the bf16 cast of the stored latents (importance ratio 1 before the first update), the G-step is bitwise repeatable,
@@ -200,6 +200,24 @@ def test_qwen_g_step_chain_rollout_replay_loss_backward_adamw():
     model.ema_step(1)
     after = g_step.micro_step(model, pipe.scheduler, sample, 0, embeds, None, old[:, 0], adv, step_index=first, **kw)
     assert not torch.equal(after["log_prob"], old[:, 0]) and torch.isfinite(after["log_prob"]).all()
+    # save_ckpt (TP:389-398) in PEFT layout and the lora_path reload (TP:506-509): a fresh model with the saved adapters gives the same bits
+    from adv_grpo_amd import checkpoint
+    model.save_pretrained(str(tmp_path / "ckpt"), use_ema=False)
+    state, meta = checkpoint.load_lora(str(tmp_path / "ckpt"))
+    assert meta["r"] == 32 and meta["lora_alpha"] == 64 and len(state) == 2 * 8 * cfg.num_layers
+    fresh = QwenImageTransformerLoRA({k: v.to(bf16) for k, v in synthetic.qwen_mmdit_weights(cfg, 5).items()}, cfg, "cuda")
+    fresh.load_lora_state(state)
+    x = lat[:2, 0]
+    t = torch.full((2,), 500.0, device="cuda")
+    assert torch.equal(fresh(x, t, embeds[:2])[0], model(x, t, embeds[:2])[0])
+    # without the kept attention outputs (the leaner checkpoint) the gradients are the same bits
+    model.grads.zero_()
+    g_step.micro_step(model, pipe.scheduler, sample, 0, embeds, None, old[:, 0], adv, step_index=first, **kw)
+    g_keep = model.grads.clone()
+    model.grads.zero_()
+    model.keep_attention = False
+    g_step.micro_step(model, pipe.scheduler, sample, 0, embeds, None, old[:, 0], adv, step_index=first, **kw)
+    assert torch.equal(model.grads, g_keep)
 
 
 def test_qwen_lora_backward_fp8_replay_straight_through():
