@@ -59,3 +59,31 @@ def test_decode_shapes_range_and_sample_independence():
     # de-normalisation: z * std + mean per channel
     d = o.denormalise(cfg, z[:, :, None])
     assert torch.allclose(d[0, 3, 0], z[0, 3] * cfg.latents_std[3] + cfg.latents_mean[3], atol=1e-6)
+
+
+def test_flops_decode_counts_the_2d_taps_of_every_weight():
+    """qwen_vae.flops_decode (what bench.py --config c5 credits per decoded image) against a count made from the synthetic state dict
+    itself: every convolution contributes 2 x (spatial taps of ONE temporal slice) x Cin x Cout per output pixel at its resolution."""
+    from adv_grpo_amd.qwen_vae import flops_decode
+    cfg = QwenVaeConfig()
+    W = synthetic.qwen_vae_decoder_weights(cfg)
+    h = w = 16
+    px = {"mid": h * w}
+    total = 0.0
+    res = h * w
+    for name, t in W.items():
+        if not name.endswith(".weight"):
+            continue
+        if name.startswith("decoder.up_blocks."):
+            i = int(name.split(".")[2])
+            n = h * w * 4 ** i
+            if ".upsamplers." in name:
+                n *= 4                                   # the upsampler's convolution runs at the doubled resolution
+        elif name.startswith("decoder.conv_out"):
+            n = h * w * 64
+        else:
+            n = h * w
+        taps = t.shape[-1] * t.shape[-2]
+        total += 2.0 * taps * t.shape[0] * t.shape[1] * n
+    total += 4.0 * (h * w) ** 2 * cfg.dims[0]            # the mid attention's two products
+    assert abs(flops_decode(cfg, h, w) - total) / total < 1e-9
