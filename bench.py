@@ -281,6 +281,38 @@ def full_epoch(device, world=1, rank=0, adversarial=False, qwen=False):
                      "overlaps the next group's rollout, `score` is the wait at the end of the sampling loop")}
 
 
+def shared_gpu_collectives(dist):
+    """ADVGRPO_BENCH_SHARED_GPU=1: every rank on cuda:0, process group over gloo, device tensors staged through the host inside the
+    collectives.  NOT a measurement mode (the ranks share one GPU, the numbers mean nothing): it exists so that the N > 1 branches of
+    this file and of the Trainer (rank partition, reward gather, gradient average, state broadcast, scaling diagnostics, the epoch
+    leg at world 2) can execute end to end on a ONE-GPU box -- RCCL refuses two ranks on one device ("Duplicate GPU detected"), and
+    no multi-GPU box has been available to this build."""
+    dist.init_process_group("gloo")
+    real = {k: getattr(dist, k) for k in ("all_reduce", "all_gather_into_tensor", "broadcast")}
+
+    def all_reduce(t, *a, **kw):
+        if not t.is_cuda:
+            return real["all_reduce"](t, *a, **kw)
+        h = t.cpu()
+        real["all_reduce"](h, *a, **kw)
+        t.copy_(h)
+
+    def all_gather_into_tensor(out, t, *a, **kw):
+        if not t.is_cuda:
+            return real["all_gather_into_tensor"](out, t, *a, **kw)
+        ho, hi = out.cpu(), t.cpu()
+        real["all_gather_into_tensor"](ho, hi, *a, **kw)
+        out.copy_(ho)
+
+    def broadcast(t, *a, **kw):
+        if not t.is_cuda:
+            return real["broadcast"](t, *a, **kw)
+        h = t.cpu()
+        real["broadcast"](h, *a, **kw)
+        t.copy_(h)
+    dist.all_reduce, dist.all_gather_into_tensor, dist.broadcast = all_reduce, all_gather_into_tensor, broadcast
+
+
 def cpu_baseline():
     """BASELINE config 1 on the host cores through the CPU oracle (kind "port": the reference's wheels --
     diffusers / timm / peft -- are not installed, so its own Python cannot run): SD3.5-medium shapes, 256x256,
@@ -426,13 +458,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    shared_gpu = os.environ.get("ADVGRPO_BENCH_SHARED_GPU", "0") == "1"     # integration-test aid, see shared_gpu_collectives()
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or args.spawn:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)      # RCCL over xGMI
+        if shared_gpu:
+            shared_gpu_collectives(dist)
+        else:
+            dist.init_process_group("nccl", device_id=device)      # RCCL over xGMI
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     ranks_seen = 1

@@ -373,6 +373,32 @@ def test_bench_self_spawn_path_at_world_1():
     assert sd["value_at_n1_same_run"] > 0 and 0.8 < sd["value_over_n_times_n1"] < 1.25
 
 
+def test_bench_world_2_end_to_end_on_one_gpu():
+    """The N > 1 branches of bench.py and of the Trainer, executed: two ranks under torch.distributed.run, the rank partition of the
+    sampler, the packed reward all-gather, the scaling diagnostics (per-rank times, both collectives timed, the solo leg) and the epoch
+    leg at world 2 (state broadcast at construction, the 75 MB LoRA-gradient all-reduce before each optimizer step, phases as the maximum
+    over ranks).  RCCL refuses two ranks on one device, so ADVGRPO_BENCH_SHARED_GPU=1 puts both ranks on cuda:0 over gloo with the device
+    tensors staged through the host inside the collectives: an integration test of the code paths, not a measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADVGRPO_BENCH_SHARED_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-pricing"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    sd = line["scaling_diagnostics"]
+    assert len(sd["ms_per_step_by_rank"]["all"]) == 2 and len(sd["solo_ms_per_step_by_rank"]["all"]) == 2
+    assert sd["reward_all_gather_ms"] > 0 and sd["lora_gradient_all_reduce_ms"] > 0 and sd["lora_gradient_bytes"] == 18_776_064 * 4
+    ep = line["epoch"]
+    assert ep["images"] == 32 and ep["phases_are"] == "max over ranks" and ep["g_step_inside"]["grad_all_reduce"]["n"] == 2
+    assert ep["g_step_inside"]["grad_all_reduce"]["mean_ms"] > 0.05         # a real exchange happened (0.01 ms at world 1)
+
+
 def test_full_size_epoch_config2(tmp_path):
     """One whole sample -> score -> gather -> advantage -> G-step epoch at BASELINE config 2's FULL size (SD3.5-medium, 24
     blocks, D = 1536, 512^2, 10 steps, CFG 4.5, G = 8, SDE window 2, fp32-equivalent VAE decode, full CLIP ViT-H PickScore)
