@@ -65,8 +65,11 @@ class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
         self.opt_step = 0
         self.ema_wrapper = EMAModuleWrapper([self.params], decay=0.9, update_step_interval=8, device=dev)
         self.ema = self.ema_wrapper.ema_parameters[0]
-        self.overlap_wgrad = True
-        self._wgrad_stream = ops.concurrent_stream(dev)
+        # adapter gradients on the main stream: at this size the side stream of the SD3 model buys 1.5 % (3.33 vs 3.38 s) and in some
+        # process / allocation histories its kernels starve beside the attention backward -- micro-steps of 5.6 - 6.3 s instead of 2.8 - 3.3
+        # were measured (second micro-step of an epoch, later processes of a box session); off is the robust choice
+        self.overlap_wgrad = False
+        self._wgrad_stream = None
         self._base_T = {}
         self._prepare_transposes()
         self.refresh()
