@@ -4,8 +4,8 @@ The reference has no Qwen-Image code (README.md:75, config/grpo.py:324,330); thi
 mmdit_train.py replaces for SD3 (scripts/train_sd3_fast_pickscore.py:1077-1187: peft LoRA r=32 / alpha=64 on the attention
 projections attn.{to_q,to_k,to_v,to_out.0,add_q_proj,add_k_proj,add_v_proj,to_add_out} (TP:490-511), autograd through the
 transformer call of compute_log_prob (TP:233-267), clip_grad_norm_ + AdamW (TP:1165-1171), EMAModuleWrapper), with the same
-flat parameter / gradient / moment vectors, merged-LoRA forward, token-contracted adapter-gradient GEMMs on a side stream and
-fused AdamW -- those methods are SD3TransformerLoRA's own, bound here unchanged.
+flat parameter / gradient / moment vectors, merged-LoRA forward, token-contracted adapter-gradient GEMMs (on the main stream here,
+see __init__) and fused AdamW -- those methods are SD3TransformerLoRA's own, bound here unchanged.
 
 What differs from the SD3 model:
   * ACTIVATION RECOMPUTATION PER BLOCK.  Sixty blocks at CFG batch 16 and 4224 joint tokens would keep ~7 GB of activations
@@ -98,7 +98,7 @@ class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
             self._base_T[i] = {gk: (b[gk + ".w"].clone(), T(b[gk + ".w"])) for gk in GROUPS}
         self.w["proj_out.wT"] = T(self.w["proj_out.w"])
 
-    # ------------------------------------------------------------------ one block, bf16 Linears: the launches of __call__
+    # ------------------------------------------------------------------ one block: the launches of __call__ (bf16 or fp8 Linears)
     def _block(self, i, x, c, mods, rope, B, Ni, Nt, save=None, keep_att=None, att_kept=None):
         """In place on x [B * Ni, D], c [B * Nt, D].  `save` (a dict) receives what the block's backward needs -- the RE-RUN inside
         backward(): it takes the attention output and log-sum-exp the first run kept (`att_kept`) instead of launching the attention
