@@ -120,6 +120,7 @@ SIGNATURES = {
     "advgrpo_groupnorm_nhwc_f16x2": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, c_float, _P, c_int, _P]),
     "advgrpo_split_f16x2": (c_int, [_P, _P, _P, c_int64, c_int, c_float, _P]),
     "advgrpo_conv3x3_nhwc_f16x2": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_float, _P, _P]),
+    "advgrpo_conv3x3_nhwc_f16x2_pair": (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_float, _P]),
     "advgrpo_conv3x3_nhwc_bf16x2": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_float, _P, _P]),
     "advgrpo_softmax_rows_x3": (c_int, [_P, _P, c_int64, c_int, _P]),
     "advgrpo_layernorm_x3": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P]),

@@ -42,6 +42,9 @@ struct GemmParams {
     // (f32 pairs) over 16 consecutive output pixels x 4 consecutive output channels.  16 divides every image's pixel count, so a
     // block never straddles two images and an image's sums do not depend on its position in the batch
     float* gn_partial;
+    // f16x2 convolution only: INSTEAD of the f32 output, the fp16-pair rows [hi | unwritten | lo] of pair_prescale * y (the operand form of
+    // the next f16x2 convolution when nothing else reads y: a resnet's conv2 in front of an upsampler) -- pair_out [M, 3 N] 16-bit
+    void* pair_out; float pair_prescale;
     int debug;   // experiments only (ADVGRPO_GEMM_DEBUG): bit0 = skip steady-state DMA, bit1 = skip LDS fragment reads
 };
 

@@ -412,6 +412,20 @@ __device__ __forceinline__ void gemm_epilogue_f32io(const GemmParams& p, f32x4 (
                 st[i][j][0] = sv;
                 st[i][j][1] = qv;
             }
+            if (p.pair_out) {     // (uniform) the next convolution's operand rows directly: hi = f16(s y), lo = f16(s y - hi), as split8_f16 (vae.hip)
+                uint32_t hw[2], lw[2];
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const float a = v[e] * p.pair_prescale, b = v[e + 1] * p.pair_prescale;
+                    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+                    const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
+                    hw[e >> 1] = (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
+                    lw[e >> 1] = (uint32_t)__builtin_bit_cast(uint16_t, la) | ((uint32_t)__builtin_bit_cast(uint16_t, lb) << 16);
+                }
+                uint16_t* row = reinterpret_cast<uint16_t*>(p.pair_out) + (int64_t)m * 3 * p.N + n;
+                *reinterpret_cast<uint2*>(row) = uint2{hw[0], hw[1]};
+                *reinterpret_cast<uint2*>(row + 2 * p.N) = uint2{lw[0], lw[1]};
+            } else
             // streaming store: up to 1 GiB of output that the next kernel reads only after it has left every cache
             __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(out + (int64_t)m * p.ldc + n));
         } else {

@@ -26,6 +26,14 @@ import torch
 from . import ops
 
 
+class _PairRows:
+    """fp16-pair operand rows [B,H,W,3C] (thirds [hi | unwritten | lo] of RAW_PRESCALE * y) written by a producing convolution's epilogue."""
+    __slots__ = ("rows",)
+
+    def __init__(self, rows):
+        self.rows = rows
+
+
 class AutoencoderKLDecoder:
     def __init__(self, state_dict, cfg, device="cuda", mode="bf16x3", f16_weights=True):
         """f16_weights (bf16x3 mode): run a 3x3 convolution whose weight tensor is EXACT in fp16 on the two-product f16x2 kernel
@@ -130,10 +138,22 @@ class AutoencoderKLDecoder:
     fused_gn_stats = True            # A/B switch: GroupNorm statistics from the producing convolution's epilogue
     RAW_PRESCALE = 2.0 ** -4         # un-normalised conv inputs (the upsamplers') as fp16 pairs: |x| up to 1e6 stays in range
 
-    def _conv_auto(self, name, x, gn=None, **kw):
+    fused_pair_out = True            # A/B switch: a resnet's conv2 in front of an upsampler writes the upsampler's operand rows itself
+
+    def _conv_auto(self, name, x, gn=None, pair_for=None, **kw):
         """3x3 convolution of f32 NHWC `x` (after GroupNorm `gn` + SiLU when given) in whichever arithmetic its weight allows:
-        fp16-exact weight -> fp16-pair activations, two products (f16x2); otherwise split-bf16, three products."""
+        fp16-exact weight -> fp16-pair activations, two products (f16x2); otherwise split-bf16, three products.
+        `x` may already be fp16-pair rows (a `_PairRows` from a producer called with pair_for=<this convolution's name>): no split pass.
+        pair_for: the ONLY reader of the output is the f16x2 convolution of that name -> return its operand rows, not f32."""
         w = self.w
+        if isinstance(x, _PairRows):                     # operand rows made by the producing convolution's epilogue
+            assert gn is None and name + ".weight@f16" in w
+            return ops.conv3x3_f16x2(x.rows, w[name + ".weight@f16"], bias=w[name + ".bias"], alpha=1.0 / self.RAW_PRESCALE,
+                                     gn_stats=self.fused_gn_stats, **kw)
+        if pair_for is not None and self.fused_pair_out and name + ".weight@f16" in w and pair_for + ".weight@f16" in w and gn is not None:
+            a = ops.groupnorm_nhwc_f16x2(x, w[gn + ".weight"], w[gn + ".bias"], self.G, 1e-6, True,
+                                         tile_stats=getattr(x, "gn_tile_stats", None) if self.fused_gn_stats else None)
+            return _PairRows(ops.conv3x3_f16x2_pair(a, w[name + ".weight@f16"], self.RAW_PRESCALE, bias=w[name + ".bias"], **kw))
         if name + ".weight@f16" in w:
             # (every f16x2 convolution's output is read by a GroupNorm -- the next resnet's norm1 or this resnet's norm2 -- so its
             #  epilogue leaves that norm's per-tile sums (`gn_tile_stats`) and the norm skips its statistics pass over the activations)
@@ -151,14 +171,14 @@ class AutoencoderKLDecoder:
     def _gn3(self, name, x, silu, pair_only=False):
         return ops.groupnorm_nhwc_x3(x, self.w[name + ".weight"], self.w[name + ".bias"], self.G, 1e-6, silu, pair_only)
 
-    def _res3(self, p, x):
+    def _res3(self, p, x, pair_for=None):
         h = self._conv_auto(f"{p}.conv1", x, gn=f"{p}.norm1")
         sc = x
         if f"{p}.conv_shortcut.weight" in self.w:
             B, H, W, C = x.shape
             sc = ops.gemm(ops.split_x3(x).view(-1, 3 * C), self.w[f"{p}.conv_shortcut.weight"], out_dtype=torch.float32
                           ).view(B, H, W, -1)
-        return self._conv_auto(f"{p}.conv2", h, gn=f"{p}.norm2", residual=sc)
+        return self._conv_auto(f"{p}.conv2", h, gn=f"{p}.norm2", residual=sc, pair_for=pair_for)
 
     def _attn3(self, p, x):
         return self._attn3_core(p, self._gn3(f"{p}.group_norm", x, False), x)
@@ -191,10 +211,12 @@ class AutoencoderKLDecoder:
         x = self._res3("decoder.mid_block.resnets.1", x)
         n = len(cfg.block_out_channels)
         for i in range(n):
+            up = f"decoder.up_blocks.{i}.upsamplers.0.conv" if i < n - 1 else None
             for j in range(cfg.layers_per_block + 1):
-                x = self._res3(f"decoder.up_blocks.{i}.resnets.{j}", x)
-            if i < n - 1:
-                x = self._conv_auto(f"decoder.up_blocks.{i}.upsamplers.0.conv", x, upsample=True)
+                # (the block's last resnet feeds the upsampler's convolution and nothing else: its conv2 writes that operand directly)
+                x = self._res3(f"decoder.up_blocks.{i}.resnets.{j}", x, pair_for=up if j == cfg.layers_per_block else None)
+            if up is not None:
+                x = self._conv_auto(up, x, upsample=True)
         y = self._conv3("decoder.conv_out", self._gn3("decoder.conv_norm_out", x, True))
         return ops.image_postprocess(y)
 

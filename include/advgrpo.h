@@ -309,6 +309,12 @@ int advgrpo_latents_mix_to_nhwc(const void* z, int z_dtype, void* out, int x3, i
  * channel count) when C is padded.  out_mode 0: bf16 [pixels, C]; 1: split rows [hi | hi | lo]; 2: [hi | unwritten | lo]. */
 int advgrpo_rmsnorm_nhwc(const void* x, int x_dtype, void* y, const float* gamma, int64_t pixels, int C, float mult, int silu,
                          int out_mode, void* stream);
+/* The same convolution writing, INSTEAD of y, the fp16-pair rows of pair_prescale * y ([B,Hout,Wout,3 Cout] 16-bit, thirds
+ * [hi | unwritten | lo]: advgrpo_split_f16x2 of y, bit for bit) -- the operand of the next f16x2 convolution when nothing else reads y
+ * (a resnet's second convolution in front of an upsampler of the decoder, PF:667-670): saves the f32 round trip and the split pass. */
+int advgrpo_conv3x3_nhwc_f16x2_pair(const void* x2, const void* w16, void* pair_out, float pair_prescale, int B, int Hout, int Wout,
+                                    int Cin3, int Cout, int upsample, const float* bias, int act, const float* residual,
+                                    const void* zero_page, float alpha, void* stream);
 /* "bf16x2": the same two-product convolution for weights that are EXACT in bf16 (the released Qwen-Image VAE is a bf16
  * checkpoint; BASELINE config 5's decode, see advgrpo_rmsnorm_nhwc): x2 = split rows [hi | unwritten | lo] of bf16 pieces
  * (advgrpo_split_bf16x3 order 2, advgrpo_rmsnorm_nhwc out_mode 2), w16 = ONE bf16 piece [Cout, 9 C]; x_hi w + x_lo w on the bf16

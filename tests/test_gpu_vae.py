@@ -397,3 +397,33 @@ def test_groupnorm_statistics_from_the_conv_epilogue(B, H, W, C, Co, up):
     ref = torch.nn.functional.silu(torch.nn.functional.group_norm(y.permute(0, 3, 1, 2).double(), 32, gw2.double(), gb2.double(), 1e-6)).permute(0, 2, 3, 1)
     assert (value(n_fused).double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
     assert (value(n_fused) - value(n_plain)).abs().max().item() < 2e-6 * ref.abs().max().item()
+
+
+def test_pair_output_epilogue_equals_the_split_pass():
+    """The f16x2 convolution that writes its output directly as the next convolution's fp16-pair operand rows (a resnet's conv2 in front
+    of an upsampler) against the f32 output + split_f16x2 pass it replaces: the rows bit for bit, and the decoded image bit for bit with
+    the switch on and off."""
+    from adv_grpo_amd import ops, synthetic
+    from adv_grpo_amd.model_configs import VaeConfig
+    from adv_grpo_amd.vae import AutoencoderKLDecoder
+    g = torch.Generator(device="cuda").manual_seed(21)
+    B, H, W, Ci, Co = 2, 12, 20, 128, 256
+    x = torch.randn(B, H, W, Ci, device="cuda", generator=g) * 3
+    wt = (torch.randn(Co, Ci, 3, 3, device="cuda", generator=g) / (3 * Ci ** 0.5)).half()
+    bias = torch.randn(Co, device="cuda", generator=g)
+    res = torch.randn(B, H, W, Co, device="cuda", generator=g) * 50
+    w16 = wt.permute(0, 2, 3, 1).reshape(Co, -1).contiguous()
+    a = ops.split_f16x2(x, prescale=1.0)
+    y = ops.conv3x3_f16x2(a, w16, bias=bias, residual=res)
+    want = ops.split_f16x2(y, prescale=2.0 ** -4).view(torch.int16).view(B, H, W, 3, Co)
+    got = ops.conv3x3_f16x2_pair(a, w16, 2.0 ** -4, bias=bias, residual=res).view(torch.int16).view(B, H, W, 3, Co)
+    assert torch.equal(got[:, :, :, 0], want[:, :, :, 0]) and torch.equal(got[:, :, :, 2], want[:, :, :, 2])
+    cfg = VaeConfig()
+    dec = AutoencoderKLDecoder(synthetic.vae_decoder_weights(cfg, 99, fp16_checkpoint=True), cfg, "cuda", mode="bf16x3")
+    lat = torch.randn(3, 16, 24, 24, device="cuda", generator=g).to(torch.bfloat16)
+    dec.fused_pair_out = True
+    on = dec.decode_to_image(lat)
+    dec.fused_pair_out = False
+    off = dec.decode_to_image(lat)
+    torch.cuda.synchronize()
+    assert torch.equal(on, off)
