@@ -685,7 +685,7 @@ def main():
         # launch's HIP-event duration includes the other stream's kernels, so the per-kernel roofline is only defined for
         # the serial schedule above.
         overlap = None
-        if not c3 and not c4 and not c5 and world == 1 and not args.no_pricing:
+        if not c3 and not c4 and world == 1 and not args.no_pricing:
             streams = [torch.cuda.Stream(), torch.cuda.Stream()]
             from concurrent.futures import ThreadPoolExecutor
             pool = ThreadPoolExecutor(2)
