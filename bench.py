@@ -168,7 +168,7 @@ def pmc_traffic(kernel, config="c2"):
     return None, None
 
 
-def full_epoch(device, world=1, rank=0, adversarial=False, qwen=False):
+def full_epoch(device, world=1, rank=0, adversarial=False, qwen=False, large=False):
     """the whole sample -> score -> gather -> advantage -> G-step loop and its phases, outside the timed
     region of the headline metric: config 2 (pickscore_cotrain_sd3_fast preset, 8 images per prompt so that one rank
     holds whole groups), 2 prompt groups per epoch = 16 images, 2 optimizer steps; the second epoch is reported.
@@ -185,18 +185,22 @@ def full_epoch(device, world=1, rank=0, adversarial=False, qwen=False):
     from adv_grpo_amd.pipeline import SD3Pipeline
     from adv_grpo_amd.trainer import SyntheticData, Trainer
     from adv_grpo_amd.vae import AutoencoderKLDecoder
-    cfg = get_config("dino_cotrain_sd3_patch_fast" if adversarial else "pickscore_cotrain_sd3_fast", gpu_number=world)
+    cfg = get_config("pickscore_sd3_fast" if large else ("dino_cotrain_sd3_patch_fast" if adversarial else "pickscore_cotrain_sd3_fast"),
+                     gpu_number=world)
     cfg.sample.num_image_per_prompt = 8
     cfg.sample.num_batches_per_epoch = 1 if qwen else 2
     cfg.train.gradient_accumulation_steps = 1
     if qwen:
         cfg.resolution = 1024
         cfg.linear_dtype = "fp8"
+    if large:      # config 4: SD3.5-large 1024^2, G = 4, the PickScore + OCR multi-reward preset (config/grpo.py:379-427), no discriminator
+        cfg.resolution = 1024
+        cfg.sample.num_image_per_prompt = cfg.sample.mini_num_image_per_prompt = 4
     if adversarial:
         cfg.d_times = 2                      # D epoch, G epoch, D epoch, ... (the shipped preset: 9 D epochs per G epoch, TD:1097)
     else:
         cfg.train_d = False                  # G epochs only (the D/G gate depends on random rewards here)
-    mcfg = MMDiTConfig()
+    mcfg = MMDiTConfig(num_layers=38, num_heads=38, dual_attention_layers=(), pos_embed_max_size=192) if large else MMDiTConfig()
     head = None
     with synthetic.on_device(device):
         if qwen:
@@ -209,7 +213,12 @@ def full_epoch(device, world=1, rank=0, adversarial=False, qwen=False):
         else:
             tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, device, seed=cfg.seed)
             vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321, fp16_checkpoint=True), VaeConfig(), device)
-        if adversarial:
+        if large:
+            from adv_grpo_amd import rewards
+            rewards.configure_pickscore(synthetic.clip_weights(ClipConfig(), 777), ClipConfig())
+            rewards.configure_ocr(lambda img: "prompt")        # PaddleOCR is not in the image: the host plugin runs with a stand-in recogniser
+            scorer = None
+        elif adversarial:
             from adv_grpo_amd import vit
             from adv_grpo_amd.d_step import DinoHeadTrainable
             from adv_grpo_amd.model_configs import DinoConfig
@@ -252,6 +261,11 @@ def full_epoch(device, world=1, rank=0, adversarial=False, qwen=False):
         dist.all_reduce(pm, op=dist.ReduceOp.MAX)
         phases = dict(zip(keys, pm.tolist()))
     images = world * cfg.sample.num_batches_per_epoch * cfg.sample.mini_num_image_per_prompt * len(epoch_s)
+    if large:
+        adv_note = {"peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                    "config4_note": "SD3.5-large (38 blocks, D = 2432) LoRA, 1024^2, two groups of G = 4 per epoch, reward = 0.5 PickScore (fp32-equivalent "
+                                    "scorer) + 0.5 OCR (host plugin, stand-in recogniser), no discriminator: sample + 4 micro-steps at CFG batch 8 + 2 "
+                                    "optimizer steps"}
     adv = {}
     if adversarial:      # the shipped preset runs 9 D epochs per G epoch (d_times = 10): the blended rate of this rank's timings
         d_s = next(t for ph, t in epoch_s if ph == "D")
@@ -267,6 +281,8 @@ def full_epoch(device, world=1, rank=0, adversarial=False, qwen=False):
                                "1024^2, ONE group of 8 images per epoch: G epoch = sampling + 2 SDE timesteps x (forward with one checkpoint "
                                "per block + backward with per-block recomputation) at CFG batch 16 + clip + AdamW + EMA; fp8 Linears in the "
                                "rollout and in the replay (straight-through backward)")
+    if large:
+        adv.update(adv_note)
     return {"images": images, "seconds": round(dt, 3), "images_per_s_full_epoch": round(images / dt, 3), **adv,
             "phases_s": {k: round(v, 4) for k, v in phases.items()}, "phases_are": "max over ranks" if world > 1 else "rank 0",
             "g_step_inside": g_inside, "g_step_inside_is": "HIP events on the launch stream around each call, this rank, in situ (after the "
@@ -764,7 +780,7 @@ def main():
                      "ms_per_step": lora_ms,
                      "value_if_side": round(world * G / (lora_ms["side"] * 1e-3), 3) if "side" in lora_ms else None},
         }
-    run_epoch = not c4 and not args.no_epoch       # at every N: for N > 1 this is the leg with the LoRA-gradient all-reduce (TP:1165)
+    run_epoch = not args.no_epoch                  # at every N: for N > 1 this is the leg with the LoRA-gradient all-reduce (TP:1165)
     if run_epoch:                                   # every rank takes part (LoRA-gradient all-reduce, reward gather)
         if c3 or c5:
             del dino, dino_head
@@ -772,7 +788,7 @@ def main():
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        ep = full_epoch(device, world, rank, adversarial=c3 or c5, qwen=c5)
+        ep = full_epoch(device, world, rank, adversarial=c3 or c5, qwen=c5, large=c4)
         if rank == 0:
             res["epoch"] = ep
     if rank == 0:
