@@ -195,6 +195,55 @@ extern "C" int advgrpo_clip_pair_loss(const void* image_embs, const void* text_e
     return 0;
 }
 
+// Softmax forward + backward over materialised score rows (the general tune_layer path: 257 keys, one (image, head, query) per row):
+//   P = softmax(sc[r, :n_valid]),  dS = scale * P (dP - sum_j P_j dP_j);  columns >= n_valid and rows whose query index (r % n) >= n_valid
+// are written as zeros (the padding the batched GEMMs around this kernel contract over).  One wave per row, n <= 512.
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ sc, const float* __restrict__ dp,
+                                                               bf16_t* __restrict__ p16, bf16_t* __restrict__ ds16, int64_t rows, int n,
+                                                               int n_valid, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const bool pad_row = (int)(r % n) >= n_valid;
+    float s[8], d[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        const bool ok = c < n_valid && !pad_row;
+        s[i] = ok ? sc[r * n + c] : -INFINITY;
+        d[i] = ok ? dp[r * n + c] : 0.f;
+        mx = fmaxf(mx, s[i]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] = pad_row ? 0.f : __expf(s[i] - mx); sum += s[i]; }
+    sum = wave_sum(sum);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] *= inv; dot += s[i] * d[i]; }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c < n) {
+            p16[r * n + c] = f2bf(s[i]);
+            ds16[r * n + c] = f2bf(scale * s[i] * (d[i] - dot));
+        }
+    }
+}
+
+extern "C" int advgrpo_softmax_bwd_rows(const float* sc, const float* dp, void* p16, void* ds16, int64_t rows, int n, int n_valid,
+                                        float scale, void* stream) {
+    ADVGRPO_CHECK(sc && dp && p16 && ds16 && rows > 0 && n > 0 && n <= 512 && n_valid > 0 && n_valid <= n, "softmax_bwd_rows: bad argument (n=%d)", n);
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), sc, dp, (bf16_t*)p16,
+                       (bf16_t*)ds16, rows, n, n_valid, scale);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int advgrpo_colsum_bf16(const void* x, int64_t ld, int R, int C, float* out, void* stream) {
     ADVGRPO_CHECK(x && out && R > 0 && C > 0, "colsum: bad argument");
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, (R + 63) / 64), dim3(256), 0, as_stream(stream),

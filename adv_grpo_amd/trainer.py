@@ -20,7 +20,7 @@ import torch
 from . import distributed as D
 from . import g_step, ops, rewards, stat_tracking
 from .d_step import train_dino
-from .d_step_pickscore import ClipLastLayerTrainable, train_pickscore
+from .d_step_pickscore import ClipLastLayerTrainable, ClipLayersTrainable, train_pickscore
 from .diffusers_patch.sd3_pipeline_with_logprob_fast import pipeline_with_logprob_random
 from .sampler import DistributedKRepeatSampler
 
@@ -176,12 +176,14 @@ class Trainer:
             pipeline.transformer.enable_fp8()
         self.clip_trainable = None
         if self.variant == "pickscore" and c.get("train_d", False):
-            if c.tune_layer != -1:
-                raise NotImplementedError("PickScore D-step is built for tune_layer = -1 (the shipped config)")
+            if not isinstance(c.tune_layer, int) or c.tune_layer >= 0:
+                raise NotImplementedError(f"tune_layer = {c.tune_layer!r}: TP:1016-1020 slices encoder.layers[tune_layer:]; a negative layer "
+                                          "count is what that supports (the tuple values sit in DINO configs that never read the key)")
             if getattr(scorer, "compute_dtype", "bf16") != "bf16":
                 raise ValueError("the co-trained PickScore scorer is the bf16 one (TP:514): build it with "
                                  "PickScoreScorer(dtype=torch.bfloat16, ...); dtype=torch.float32 is the frozen reward scorer")
-            self.clip_trainable = ClipLastLayerTrainable(scorer.model)                    # TP:1016-1020
+            self.clip_trainable = (ClipLastLayerTrainable(scorer.model) if c.tune_layer == -1 else
+                                   ClipLayersTrainable(scorer.model, c.tune_layer))       # TP:1016-1020
         if world > 1:
             # every trainable state starts identical on all ranks: rank 0's values are broadcast, as DDP / DeepSpeed do
             # at construction (TD:749, TP:554-561); afterwards only all-reduced gradients change them

@@ -505,6 +505,12 @@ int advgrpo_cls_attention_bwd(const void* qkv, const float* probs, const void* d
  * w.r.t. the un-normalised image embeddings e [2B,P]; == CLIPCriterion.calc_loss with label_0 = 1, label_1 = 0. */
 int advgrpo_clip_pair_loss(const void* image_embs, const void* text_embs, int B, int P, float logit_scale_exp,
                            float* loss, void* d_image_embs, void* stream);
+/* tune_layer = -k, k > 1 (TP:1016-1020): softmax forward + backward over materialised attention-score rows of the trainable CLIP layers
+ * (autograd of F.scaled_dot_product_attention inside CLIPModel.vision_model, reached from train_pickscore TP:151-183): sc / dp f32 [rows, n]
+ * (scaled scores, dO V^T) -> p16 = softmax over the first n_valid columns, ds16 = scale * P (dP - sum P dP), bf16; padding rows (query
+ * index r % n >= n_valid) and columns come out zero. */
+int advgrpo_softmax_bwd_rows(const float* sc, const float* dp, void* p16, void* ds16, int64_t rows, int n, int n_valid, float scale,
+                             void* stream);
 int advgrpo_colsum_bf16(const void* x, int64_t ld, int R, int C, float* out /* += */, void* stream);
 int advgrpo_ln_affine_grads(const void* x, int64_t ldx, const void* dy, int64_t lddy, int M, int D, float eps,
                             float* grad_w /* += */, float* grad_b /* += */, void* stream);

@@ -92,6 +92,21 @@ def test_pickscore_variant_d_step_gate():
         assert not torch.equal(model.params, p0)
 
 
+def test_pickscore_variant_d_step_with_tune_layer_minus_2():
+    """config.tune_layer = -2 through the Trainer (TP:1016-1020): the discriminator update reaches the last TWO vision layers; a
+    non-negative or tuple value is refused with the reason."""
+    from adv_grpo_amd.d_step_pickscore import ClipLayersTrainable
+    tr_, model, _ = _build("pickscore", train_d=True, tune_layer=-2)
+    assert isinstance(tr_.clip_trainable, ClipLayersTrainable) and tr_.clip_trainable.k == 2
+    layers = tr_.scorer.model.v_enc.layers
+    w0 = [L["fc1.w"].clone() for L in layers[-2:]]
+    phases = [tr_.run_epoch()["phase"] for _ in range(3)]
+    if "D" in phases:
+        assert all(not torch.equal(L["fc1.w"], w) for L, w in zip(layers[-2:], w0))
+    with pytest.raises(NotImplementedError):
+        _build("pickscore", train_d=True, tune_layer=(11,))
+
+
 def test_eval_loop_is_deterministic_swaps_ema_and_checkpoint_round_trips(tmp_path):
     """eval() (TP:269-382) + save_ckpt (TP:389-398) + lora_path reload (TP:506-509) on the reduced stack."""
     from adv_grpo_amd import checkpoint
