@@ -76,6 +76,8 @@ SIGNATURES = {
     "advgrpo_rmsnorm_heads": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int, c_float, c_int, c_int64, c_int64,
                                       _P, _P]),
     "advgrpo_rmsnorm_rows": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int, c_float, _P]),
+    "advgrpo_rope_half": (c_int, [_P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "advgrpo_softmax_rows_causal": (c_int, [_P, _P, c_int64, c_int, _P]),
     "advgrpo_qk_norm_rope": (c_int, [_P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_float, _P, _P, _P]),
     "advgrpo_attention_fwd_bias": (c_int, [_P, _P, _P, _P] + [c_int64] * 8 + [c_int] * 5 + [c_float, c_int, _P, _P]),
     "advgrpo_gemm_bf16_train": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_int, _P, c_int,

@@ -280,6 +280,54 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
     }
 }
 
+// Rotary embedding in the "rotate_half" form (pairs (i, i + HD / 2)) of the Qwen2.5-VL language model, in place on the nheads heads at
+// columns [col0, col0 + nheads * HD) of token rows [rows, ld]: out[i] = x[i] cos_i - x[i + h] sin_i, out[i + h] = x[i + h] cos_i + x[i] sin_i
+// (= q * cos + rotate_half(q) * sin with the duplicated-halves tables of Qwen2RotaryEmbedding); cs [T, HD / 2] holds (cos, sin) pairs f32,
+// position = row % T.  One wave per token row, one lane per pair of a 128-wide head.
+__global__ __launch_bounds__(256) void rope_half_kernel(bf16_t* __restrict__ buf, int64_t ld, int rows, int T, int col0, int nheads, int hd,
+                                                        const float* __restrict__ cs) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int half = hd >> 1, t = row % T;
+    bf16_t* r = buf + (int64_t)row * ld + col0;
+    for (int i = lane; i < half; i += 64) {
+        const float co = cs[((int64_t)t * half + i) * 2], si = cs[((int64_t)t * half + i) * 2 + 1];
+        for (int h = 0; h < nheads; ++h) {
+            const float a = bf2f(r[h * hd + i]), b = bf2f(r[h * hd + half + i]);
+            r[h * hd + i] = f2bf(a * co - b * si);
+            r[h * hd + half + i] = f2bf(b * co + a * si);
+        }
+    }
+}
+
+// softmax over the first (r % n) + 1 columns of score row r (causal attention over materialised scores, query index = r % n); the
+// other columns are written as zeros.  One wave per row, n <= 512.
+__global__ __launch_bounds__(256) void softmax_rows_causal_kernel(const float* __restrict__ sc, bf16_t* __restrict__ p16, int64_t rows, int n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int last = (int)(r % n);
+    float s[8], mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        s[i] = c <= last ? sc[r * n + c] : -INFINITY;
+        mx = fmaxf(mx, s[i]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] = __expf(s[i] - mx); sum += s[i]; }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c < n) p16[r * n + c] = f2bf(s[i] * inv);
+    }
+}
+
 // sinusoidal timestep embedding, diffusers get_timestep_embedding(t, 256, flip_sin_to_cos=True,
 // downscale_freq_shift=0): [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(1e4) i / 128); optional SiLU-free.
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, int B, int dim) {
@@ -450,6 +498,21 @@ extern "C" int advgrpo_rmsnorm_heads(void* buf, int64_t ld, int M, int col0, int
     return 0;
 }
 
+
+extern "C" int advgrpo_rope_half(void* buf, int64_t ld, int rows, int T, int col0, int nheads, int head_dim, const float* cos_sin, void* stream) {
+    ADVGRPO_CHECK(buf && cos_sin && rows > 0 && T > 0 && nheads > 0 && head_dim > 0 && head_dim % 2 == 0, "rope_half: bad argument");
+    hipLaunchKernelGGL(rope_half_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), (bf16_t*)buf, ld, rows, T, col0, nheads, head_dim,
+                       cos_sin);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_softmax_rows_causal(const float* sc, void* p16, int64_t rows, int n, void* stream) {
+    ADVGRPO_CHECK(sc && p16 && rows > 0 && n > 0 && n <= 512, "softmax_rows_causal: bad argument (n=%d)", n);
+    hipLaunchKernelGGL(softmax_rows_causal_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), sc, (bf16_t*)p16, rows, n);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int advgrpo_qk_norm_rope(void* buf, int64_t ld, int rows, int S, int n_first, int col0, int nheads, int head_dim,
                                     const void* w_first, const void* w_rest, int heads_per_weight, float eps,

@@ -98,3 +98,19 @@ class QwenVaeConfig:  # Qwen/Qwen-Image vae (diffusers AutoencoderKLQwenImage: W
         """(input width, output width, has upsampler) of decoder.up_blocks[i]: every upsampler halves the width."""
         d = self.dims
         return (d[i] if i == 0 else d[i] // 2), d[i + 1], i != len(self.dim_mult) - 1
+
+
+@dataclass
+class QwenTextConfig:  # Qwen/Qwen-Image text_encoder = Qwen2.5-VL-7B-Instruct's language model (transformers Qwen2_5_VLTextModel; BASELINE config 5)
+    vocab_size: int = 152064
+    hidden_size: int = 3584
+    intermediate_size: int = 18944
+    num_layers: int = 28
+    num_heads: int = 28
+    num_kv_heads: int = 4
+    rms_eps: float = 1e-6
+    rope_theta: float = 1e6
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_heads

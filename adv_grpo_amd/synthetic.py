@@ -185,6 +185,27 @@ def vae_decoder_weights(cfg, seed=4321, fp16_checkpoint=False):
     return W
 
 
+def qwen_text_weights(cfg, seed=1357, dtype=None):
+    """Weights keyed like transformers' Qwen2_5_VLTextModel.state_dict() (created on torch's default device: use on_device)."""
+    g = _gen(seed)
+    W = {"embed_tokens.weight": _randn(cfg.vocab_size, cfg.hidden_size, generator=g), "norm.weight": 1 + 0.1 * _randn(cfg.hidden_size, generator=g)}
+    D, hd = cfg.hidden_size, cfg.head_dim
+    for i in range(cfg.num_layers):
+        p, a = f"layers.{i}", f"layers.{i}.self_attn"
+        for n, out_f in (("q_proj", cfg.num_heads * hd), ("k_proj", cfg.num_kv_heads * hd), ("v_proj", cfg.num_kv_heads * hd)):
+            W[f"{a}.{n}.weight"] = _randn(out_f, D, generator=g) / math.sqrt(D)
+            W[f"{a}.{n}.bias"] = 0.1 * _randn(out_f, generator=g)
+        W[f"{a}.o_proj.weight"] = _randn(D, cfg.num_heads * hd, generator=g) / math.sqrt(D)
+        W[f"{p}.mlp.gate_proj.weight"] = _randn(cfg.intermediate_size, D, generator=g) / math.sqrt(D)
+        W[f"{p}.mlp.up_proj.weight"] = _randn(cfg.intermediate_size, D, generator=g) / math.sqrt(D)
+        W[f"{p}.mlp.down_proj.weight"] = _randn(D, cfg.intermediate_size, generator=g) / math.sqrt(cfg.intermediate_size)
+        W[f"{p}.input_layernorm.weight"] = 1 + 0.1 * _randn(D, generator=g)
+        W[f"{p}.post_attention_layernorm.weight"] = 1 + 0.1 * _randn(D, generator=g)
+    if dtype is not None:
+        W = {k: v.to(dtype) for k, v in W.items()}
+    return W
+
+
 def qwen_vae_decoder_weights(cfg, seed=2468, dtype=None):
     """fp32 CPU weights keyed like diffusers AutoencoderKLQwenImage.state_dict() (post_quant_conv + decoder.*; the upsamplers'
     `time_conv`, which a still image never runs, is left out).  3-D kernels [Co, Ci, kt, kh, kw]; dtype: round every tensor

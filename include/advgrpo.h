@@ -192,6 +192,14 @@ int advgrpo_rmsnorm_heads(void* buf, int64_t ld, int M, int col0, int nheads, co
 int advgrpo_qk_norm_rope(void* buf, int64_t ld, int rows, int S, int n_first, int col0, int nheads, int head_dim,
                          const void* w_first, const void* w_rest, int heads_per_weight, float eps,
                          const float* rope, float* rs_out, void* stream);
+/* Prompt encoder of BASELINE config 5 (the Qwen2.5-VL language model on text-only input behind QwenImagePipeline's `encode_prompt`;
+ * the Qwen-Image twin of scripts/train_dreambooth_lora_sd3.py:98-144 as used at TP:628-651 -- the reference names the config at
+ * config/grpo.py:324,330 and ships no code for it):
+ *   rope_half: Qwen2's rotary embedding (pairs (i, i + head_dim / 2)) in place on nheads heads at columns [col0, ...) of token rows
+ *     [rows, ld] bf16; cos_sin [T, head_dim / 2, 2] f32, position = row % T.
+ *   softmax_rows_causal: row r of materialised scores sc f32 [rows, n] -> bf16 softmax over columns <= r % n, zeros after (n <= 512). */
+int advgrpo_rope_half(void* buf, int64_t ld, int rows, int T, int col0, int nheads, int head_dim, const float* cos_sin, void* stream);
+int advgrpo_softmax_rows_causal(const float* sc, void* p16, int64_t rows, int n, void* stream);
 /* diffusers Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0): t f32 [B] -> bf16 [B, dim]. */
 int advgrpo_timestep_embedding(const float* t, void* out, int B, int dim, void* stream);
 /* y = act(x [+ x2]) on bf16, n % 8 == 0 (act 0 none, 3 SiLU). */
