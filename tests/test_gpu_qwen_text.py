@@ -81,3 +81,37 @@ def test_text_encoder_real_width_two_layers():
     e_hip, e_torch = _rel(out, ref), _rel(tb, ref)
     print("qwen text real width: rel err hip", e_hip, "torch-bf16", e_torch)
     assert out.shape == (2, 60, 3584) and e_hip < max(2 * e_torch, 1e-2), (e_hip, e_torch)
+
+
+def test_prompt_encoder_feeds_the_rollout():
+    """Config 5 end to end in small: tokens -> Qwen2.5-VL text tower (template dropped) -> the SD3 rollout function driving the Qwen-Image
+    MMDiT -> Qwen-Image VAE decode: finite images and log-probs, bit-reproducible."""
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.diffusers_patch.sd3_pipeline_with_logprob_fast import pipeline_with_logprob_random
+    from adv_grpo_amd.model_configs import QwenTextConfig, QwenVaeConfig
+    from adv_grpo_amd.pipeline import SD3Pipeline
+    from adv_grpo_amd.qwen_mmdit import QwenImageTransformer2DModel
+    from adv_grpo_amd.qwen_text_encoder import Qwen25VLTextEncoder
+    from adv_grpo_amd.qwen_vae import AutoencoderKLQwenImageDecoder
+    from oracle.qwen_mmdit import QwenMMDiTConfig
+    tcfg = QwenTextConfig(vocab_size=400, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=2, num_kv_heads=1)
+    enc = Qwen25VLTextEncoder({k: v.to(bf16) for k, v in synthetic.qwen_text_weights(tcfg, 3).items()}, tcfg, "cuda")
+    g = torch.Generator().manual_seed(6)
+    ids = torch.randint(0, 400, (2, 34 + 21), generator=g)           # (prompt, negative prompt) after the chat template
+    mask = torch.ones(2, 55, dtype=torch.long)
+    mask[1, 50:] = 0
+    emb, msk = enc.encode_prompt(ids.cuda(), mask)
+    assert emb.shape == (2, 21, 256) and msk[1].sum().item() == 16
+    mcfg = QwenMMDiTConfig(num_layers=2, num_heads=4, joint_attention_dim=256)
+    tr = QwenImageTransformer2DModel({k: v.to(bf16) for k, v in synthetic.qwen_mmdit_weights(mcfg, 3).items()}, mcfg, "cuda")
+    vcfg = QwenVaeConfig()
+    vae = AutoencoderKLQwenImageDecoder(synthetic.qwen_vae_decoder_weights(vcfg, 7, dtype=bf16), vcfg, "cuda", mode="bf16")
+    pipe = SD3Pipeline(tr, vae, "cuda")
+    pooled = torch.zeros(1, 8, dtype=bf16, device="cuda")
+    kw = dict(prompt_embeds=emb[:1], pooled_prompt_embeds=pooled, negative_prompt_embeds=emb[1:], negative_pooled_prompt_embeds=pooled,
+              num_inference_steps=4, guidance_scale=4.0, height=256, width=256, noise_level=0.8, mini_num_image_per_prompt=2,
+              train_num_steps=2, process_index=0, sample_num_steps=4, random_timestep=0)
+    img, lats, lps, _ = pipeline_with_logprob_random(pipe, seed=5, **kw)
+    img2, lats2, lps2, _ = pipeline_with_logprob_random(pipe, seed=5, **kw)
+    assert img.shape == (2, 3, 256, 256) and torch.isfinite(img).all() and all(torch.isfinite(lp).all() for lp in lps)
+    assert torch.equal(img, img2) and all(torch.equal(a, b) for a, b in zip(lps, lps2))
