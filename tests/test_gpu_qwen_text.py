@@ -12,12 +12,13 @@ def _rel(a, b):
     return ((a.float() - b.float()).norm() / b.float().norm()).item()
 
 
-def test_rope_half_and_causal_softmax_kernels():
+@pytest.mark.parametrize("hd", [128, 64])
+def test_rope_half_and_causal_softmax_kernels(hd):
     from adv_grpo_amd import _lib
     from oracle import qwen_text as o
     lib = _lib.load()
     g = torch.Generator(device="cuda").manual_seed(3)
-    B, T, H, KV, hd = 2, 37, 6, 2, 128
+    B, T, H, KV = 2, 37, 6, 2
     cfg = o.QwenTextConfig(hidden_size=H * hd, num_heads=H, num_kv_heads=KV)
     qkv = torch.randn(B * T, (H + 2 * KV) * hd, device="cuda", generator=g).to(bf16)
     cos, sin = o.rotary_tables(cfg, T, "cuda")
@@ -115,3 +116,38 @@ def test_prompt_encoder_feeds_the_rollout():
     img2, lats2, lps2, _ = pipeline_with_logprob_random(pipe, seed=5, **kw)
     assert img.shape == (2, 3, 256, 256) and torch.isfinite(img).all() and all(torch.isfinite(lp).all() for lp in lps)
     assert torch.equal(img, img2) and all(torch.equal(a, b) for a, b in zip(lps, lps2))
+
+
+@pytest.mark.parametrize("n,rows_per", [(64, 64), (320, 320), (512, 512)])
+def test_causal_softmax_sizes(n, rows_per):
+    """Row lengths from one 64-lane pass to the 512-column maximum (one wave per row, eight columns per lane)."""
+    from adv_grpo_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(n)
+    sc = torch.randn(2 * rows_per, n, device="cuda", generator=g) * 4
+    p16 = torch.empty(2 * rows_per, n, dtype=bf16, device="cuda")
+    _lib.check(lib.advgrpo_softmax_rows_causal(sc.data_ptr(), p16.data_ptr(), 2 * rows_per, n, _lib.stream_ptr()))
+    mask = torch.full((n, n), float("-inf"), device="cuda").triu(1).repeat(2, 1)
+    assert (p16.float() - torch.softmax(sc + mask, dim=-1)).abs().max().item() < 4e-3
+    with pytest.raises(Exception):
+        _lib.check(lib.advgrpo_softmax_rows_causal(sc.data_ptr(), p16.data_ptr(), 4, 576, _lib.stream_ptr()))
+
+
+def test_softmax_bwd_rows_matches_autograd():
+    """advgrpo_softmax_bwd_rows (the materialised attention backward of the tune_layer = -k discriminator path): P and scale * dS against
+    torch autograd of softmax over the valid columns; padding rows and columns come out zero."""
+    from adv_grpo_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    n, nv, blocks = 320, 257, 3
+    sc = (torch.randn(blocks * n, n, device="cuda", generator=g) * 2).requires_grad_(True)
+    dp = torch.randn(blocks * n, n, device="cuda", generator=g)
+    p16 = torch.empty(blocks * n, n, dtype=bf16, device="cuda")
+    ds16 = torch.empty_like(p16)
+    _lib.check(lib.advgrpo_softmax_bwd_rows(sc.data_ptr(), dp.data_ptr(), p16.data_ptr(), ds16.data_ptr(), blocks * n, n, nv, 0.25, _lib.stream_ptr()))
+    P = torch.softmax(sc[:, :nv], dim=-1)
+    (P * dp[:, :nv]).sum().backward()
+    valid = (torch.arange(blocks * n, device="cuda") % n) < nv
+    assert (p16.float()[valid][:, :nv] - P.detach()[valid]).abs().max().item() < 4e-3
+    assert (ds16.float()[valid][:, :nv] - 0.25 * sc.grad[valid][:, :nv]).abs().max().item() < 4e-3
+    assert (p16[~valid] == 0).all() and (ds16[~valid] == 0).all() and (p16[:, nv:] == 0).all() and (ds16[:, nv:] == 0).all()
