@@ -523,9 +523,32 @@ def main():
     G, STEPS, T, RES = (4, 10, 2, 1024) if c4 else ((8, 10, 2, 1024) if c5 else (8, 10, 2, 512))
     sampler = DistributedKRepeatSampler(range(25432), 1, 1, world, rank, seed=42)   # k = 1: one group per rank
     # synthetic prompts: one embedding set per dataset index is not needed for timing; a fixed set per rank
+    text_tower = None
     if c5:     # Qwen-Image: 3584-wide text states, no pooled vector (a dummy one travels through the rollout's signature)
         pe, ppe, npe, nppe = (t.to(device=device, dtype=torch.bfloat16)
                               for t in synthetic.prompt_embeddings(7 + rank, n_tokens=C5_TEXT_TOKENS, ctx_dim=3584, pooled_dim=8))
+        if rank == 0 and not args.no_pricing:
+            # the prompt encoder itself (Qwen2.5-VL language model, 28 layers, random weights), OUTSIDE the timed region as for every
+            # config (inputs are resident when the step starts): its states replace the random ones, its time is reported
+            from adv_grpo_amd.model_configs import QwenTextConfig
+            from adv_grpo_amd.qwen_text_encoder import DROP_IDX, Qwen25VLTextEncoder
+            tcfg = QwenTextConfig()
+            with synthetic.on_device(device):
+                enc = Qwen25VLTextEncoder(synthetic.qwen_text_weights(tcfg, 1357, dtype=torch.bfloat16), tcfg, device)
+            tok = torch.randint(0, tcfg.vocab_size, (2, DROP_IDX + C5_TEXT_TOKENS), generator=torch.Generator().manual_seed(11)).to(device)
+            tmask = torch.ones(2, DROP_IDX + C5_TEXT_TOKENS, dtype=torch.long)
+            enc.encode_prompt(tok, tmask)
+            torch.cuda.synchronize()
+            tt = time.perf_counter()
+            for _ in range(3):
+                emb, _m = enc.encode_prompt(tok, tmask)
+            torch.cuda.synchronize()
+            text_tower = {"ms_per_prompt_pair": round((time.perf_counter() - tt) / 3 * 1e3, 2), "tokens": DROP_IDX + C5_TEXT_TOKENS,
+                          "note": "Qwen2.5-VL language model (28 layers, 3584 wide, random weights) on (prompt, negative prompt) token ids "
+                                  "after the chat template; the first 34 template tokens dropped; outside the timed step"}
+            pe, npe = emb[:1].contiguous(), emb[1:].contiguous()
+            del enc, emb
+            torch.cuda.empty_cache()
     else:
         pe, ppe, npe, nppe = (t.to(device=device, dtype=torch.bfloat16) for t in synthetic.prompt_embeddings(7 + rank))
     # one prompt per group (TP:813-817 repeat the group's prompt G times): the scorers see G equal prompts
@@ -738,7 +761,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if c5 else "bf16", "data": "synthetic",
             "config": {"workload": ("BASELINE config 5 shapes: Qwen-Image MMDiT (60 blocks, 24 heads x 128, D=3072; block Linears on fp8 e4m3 operands, "
                                     "per-token x per-channel scales, f32 accumulation; attention / norms / embedders bf16) 1024x1024 = 4096 packed "
-                                    f"latent positions + {C5_TEXT_TOKENS} synthetic text tokens (3584-wide), 10 steps, CFG 4.5 as u + s (t - u) "
+                                    f"latent positions + {C5_TEXT_TOKENS} text tokens (3584-wide states of the Qwen2.5-VL text tower on synthetic token ids), 10 steps, CFG 4.5 as u + s (t - u) "
                                     "(the rollout function's combine, PF:640-642, not QwenImagePipeline's norm-rescaled one), G=8, SDE window 2 @ noise 0.8 on "
                                     "the SD3 sigma table (shift 3), VAE decode (" + pipe.vae.mode + ") with Qwen-Image's own decoder (AutoencoderKLQwenImage on one "
                                     "frame: widths 384 / 192 / 96, per-pixel RMS norm), DINOv2-B/14 patch reward + head (RW:375-434), reward all-gather + group advantage")
@@ -771,7 +794,7 @@ def main():
             "clock_and_power": power.summary(),
             "overlap": overlap,
             "fp8_linears": fp8,
-            **({"bf16_linears": bf16_linears} if c5 else {}),
+            **({"bf16_linears": bf16_linears, "text_tower": text_tower} if c5 else {}),
             "lora": None if c5 else {"mode": "merged",
                      "modes": {"merged": "W_eff = bf16(W + s B A) in the rollout and training forward (the timed configuration)",
                                "side": "PEFT's y = W x + s B (A x) as K + 192 / K + 64 extra columns of the adapted Linears: the "
