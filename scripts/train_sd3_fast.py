@@ -2,6 +2,8 @@
 """Launcher of the Adv-GRPO epoch loop (stand-in for scripts/train_sd3_fast_{pickscore,dino_patch}.py upstream):
 
   python scripts/train_sd3_fast.py --config config/grpo.py:dino_cotrain_sd3_patch_fast [--epochs N] [--layers L]
+  python scripts/train_sd3_fast.py --config config/grpo.py:dino_cotrain_sd3_patch_fast --model Qwen/Qwen-Image --resolution 1024 \
+         --linear-dtype fp8 --images-per-prompt 8 --batches 1          (BASELINE config 5)
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_sd3_fast.py --config ...
 
 No checkpoints / tokenizers / reference images exist on this platform: models get seeded synthetic weights of the
@@ -37,6 +39,11 @@ def main():
                          "path; needs --lora-mode merged); the backward stays bf16 (straight-through)")
     ap.add_argument("--vae-mode", default="bf16x3", choices=["bf16", "bf16x3"],
                     help="decoder arithmetic: bf16 (default) or the fp32-equivalent split-bf16 mode (the reference decodes in fp32, TP:481)")
+    ap.add_argument("--model", default=None,
+                    help="override config.pretrained.model (config/grpo.py:324): stabilityai/stable-diffusion-3.5-medium (default of the presets), "
+                         "stabilityai/stable-diffusion-3.5-large (BASELINE config 4) or Qwen/Qwen-Image (BASELINE config 5: Qwen-Image MMDiT with "
+                         "LoRA + per-block recomputation, Qwen-Image VAE decoder, 3584-wide prompt states)")
+    ap.add_argument("--resolution", type=int, default=None, help="override config.resolution (config/grpo.py:330)")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
@@ -56,6 +63,7 @@ def main():
     cfg = parse_config_flag(args.config, gpu_number=world)
     if args.images_per_prompt:
         cfg.sample.num_image_per_prompt = args.images_per_prompt
+        cfg.sample.mini_num_image_per_prompt = min(cfg.sample.mini_num_image_per_prompt, args.images_per_prompt)     # G = 4 (config 4)
     if args.groups_in_flight:
         cfg.sample.groups_in_flight = args.groups_in_flight
     if args.no_train_d:
@@ -63,11 +71,30 @@ def main():
     if args.batches:
         cfg.sample.num_batches_per_epoch = args.batches
         cfg.train.gradient_accumulation_steps = max(1, args.batches // 2)
-    mcfg = MMDiTConfig() if args.layers is None else MMDiTConfig(num_layers=args.layers,
-                                                                 dual_attention_layers=tuple(range(min(13, args.layers))))
+    if args.model:
+        cfg.pretrained.model = args.model
+    if args.resolution:
+        cfg.resolution = args.resolution
+    name = str(cfg.pretrained.model).lower()
+    qwen, large = "qwen" in name, "3.5-large" in name
+    if qwen and args.lora_mode != "merged":
+        raise SystemExit("Qwen-Image: --lora-mode merged only")
+    mcfg = MMDiTConfig(num_layers=38, num_heads=38, dual_attention_layers=(), pos_embed_max_size=192) if large else MMDiTConfig()
+    if args.layers is not None:
+        mcfg = MMDiTConfig(num_layers=args.layers, num_heads=mcfg.num_heads, pos_embed_max_size=mcfg.pos_embed_max_size,
+                           dual_attention_layers=() if large else tuple(range(min(13, args.layers))))
     with synthetic.on_device(device):
-        tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, device, seed=cfg.seed, lora_mode=args.lora_mode)
-        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321, fp16_checkpoint=True), VaeConfig(), device, mode=args.vae_mode)
+        if qwen:
+            from adv_grpo_amd.model_configs import QwenMMDiTConfig, QwenVaeConfig
+            from adv_grpo_amd.qwen_mmdit_train import QwenImageTransformerLoRA
+            from adv_grpo_amd.qwen_vae import AutoencoderKLQwenImageDecoder
+            qcfg = QwenMMDiTConfig() if args.layers is None else QwenMMDiTConfig(num_layers=args.layers)
+            tr = QwenImageTransformerLoRA(synthetic.qwen_mmdit_weights(qcfg, 4242, dtype=torch.bfloat16), qcfg, device, seed=cfg.seed)
+            vae = AutoencoderKLQwenImageDecoder(synthetic.qwen_vae_decoder_weights(QwenVaeConfig(), 2468, dtype=torch.bfloat16), QwenVaeConfig(),
+                                                device, mode=args.vae_mode)
+        else:
+            tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, device, seed=cfg.seed, lora_mode=args.lora_mode)
+            vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321, fp16_checkpoint=True), VaeConfig(), device, mode=args.vae_mode)
         head = None
         if any(k.startswith("dino") for k in cfg.reward_fn.keys()):
             scorer = vit.DinoV2(synthetic.dino_weights(DinoConfig(), 888), DinoConfig(), device)
@@ -91,7 +118,8 @@ def main():
         except ImportError:
             rewards.configure_ocr(lambda img: "")      # no recogniser in this image: every OCR reward is the empty-read score
     pipe = SD3Pipeline(tr, vae, device)
-    data = SyntheticData(resolution=cfg.resolution, device=device)
+    data = SyntheticData(n_tokens=128, ctx_dim=3584, pooled_dim=8, resolution=cfg.resolution, device=device) if qwen else \
+        SyntheticData(resolution=cfg.resolution, device=device)
     if cfg.train.lora_path:                                                      # TP:506-509
         from adv_grpo_amd import checkpoint
         tr.load_lora_state(checkpoint.load_lora(cfg.train.lora_path)[0])
