@@ -5,9 +5,10 @@
 // (scripts/train_sd3_fast_pickscore.py:233-267, loss.backward() :1165) for the Qwen-Image model the reference names but does not
 // ship (README.md:75, config/grpo.py:324,330).
 //
-// FIRST VERSION: correct, deterministic (no atomics; probabilities recomputed from the forward's base-2 log-sum-exp, the same
-// two-pass arithmetic as attention_bwd_pipe.hip) and simple -- v_mfma_f32_16x16x32_bf16, operand tiles staged through LDS by plain
-// loads with the next tile's global loads in flight during the products; NOT software-pipelined like the head-dim-64 kernel.
+// Deterministic (no atomics; probabilities recomputed from the forward's base-2 log-sum-exp, the same two-pass arithmetic as
+// attention_bwd_pipe.hip); operand tiles staged through LDS by plain loads with the next tile's global loads in flight during the
+// products; NOT software-pipelined like the head-dim-64 kernel.  Two kernels: the 16x16x32-MFMA one below (dQ, and the dK/dV
+// fallback) and the 32x32x16-MFMA one after it (dK/dV: half the LDS bytes per product).
 //   dQ    (DKDV = false): a workgroup owns 128 queries (wave = 32, as two 16-row blocks) and streams the keys in tiles of 32:
 //           S^T = K Q^T, P^T = exp2(c S^T - L[q]), dP^T = V dO^T, dS^T = P^T (dP^T - D[q]), dQ^T += K^T dS^T
 //   dK/dV (DKDV = true):  a workgroup owns 64 keys (wave = 16) and streams the queries:
@@ -34,7 +35,10 @@ constexpr int B8_TP = B8_ROWS + 4;    // transposed tile pitch (elements): 72 by
                                       // stores hit are 576 bytes apart: four bank groups (80 bytes put them on two)
 constexpr int B8_ROWMAJ = B8_ROWS * B8_RP * 2, B8_TRANS = B8_HD * B8_TP * 2;      // bytes
 
-__device__ __forceinline__ uint32_t b8_pack(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2(f32x2_t v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v_t)); }   // v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t b8_pack(float lo, float hi) { return pack2(f32x2_t{lo, hi}); }
 
 template <bool DKDV, int B8_CB>
 __global__ __launch_bounds__(256, B8_CB == 1 ? (DKDV ? 3 : 4) : 2) void attn_bwd_d128_kernel(const AttnBwdParams p) {
@@ -89,22 +93,27 @@ __global__ __launch_bounds__(256, B8_CB == 1 ? (DKDV ? 3 : 4) : 2) void attn_bwd
     const int lrow = tid >> 3, lch = tid & 7;
     uint4 g0[2], g1[2];
     float gl = 0.f, gd = 0.f;
+    // (uniform base + 32-bit byte offset per lane -- the launcher checks rows * ld * 2 < 2^31: 64-bit per-lane pointers cost registers
+    // that spilled into the tile loop)
+    const uint32_t ldb0 = (uint32_t)ld_s0 * 2u, ldb1 = (uint32_t)ld_s1 * 2u;
     auto fetch = [&](int t) {
-        const int r = min(t * B8_ROWS + lrow, n_str - 1);
+        const uint32_t r = (uint32_t)min(t * B8_ROWS + lrow, n_str - 1);
+        const char* q0 = reinterpret_cast<const char*>(s0p) + (size_t)(r * ldb0 + (uint32_t)lch * 16u);
+        const char* q1 = reinterpret_cast<const char*>(s1p) + (size_t)(r * ldb1 + (uint32_t)lch * 16u);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            g0[i] = *reinterpret_cast<const uint4*>(s0p + (int64_t)r * ld_s0 + (lch + 8 * i) * 8);
-            g1[i] = *reinterpret_cast<const uint4*>(s1p + (int64_t)r * ld_s1 + (lch + 8 * i) * 8);
+            g0[i] = *reinterpret_cast<const uint4*>(q0 + 128 * i);
+            g1[i] = *reinterpret_cast<const uint4*>(q1 + 128 * i);
         }
         if constexpr (DKDV) {
             if (tid < B8_ROWS) {
-                const int q = t * B8_ROWS + tid;
-                gl = q < n_str ? -Lp[q] : -INFINITY;       // a query past the end: P = 0 exactly
-                gd = q < n_str ? -Dp[q] : 0.f;
+                const int q = min(t * B8_ROWS + tid, n_str - 1);
+                gl = Lp[q];                     // (raw: negated / masked in commit, so that nothing waits on these loads here)
+                gd = Dp[q];
             }
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int ch = lch + 8 * i;
@@ -132,7 +141,11 @@ __global__ __launch_bounds__(256, B8_CB == 1 ? (DKDV ? 3 : 4) : 2) void attn_bwd
             }
         }
         if constexpr (DKDV) {
-            if (tid < B8_ROWS) { lvec[tid] = gl; dvec[tid] = gd; }
+            if (tid < B8_ROWS) {
+                const bool in = t * B8_ROWS + tid < n_str;
+                lvec[tid] = in ? -gl : -INFINITY;       // a query past the end: P = 0 exactly
+                dvec[tid] = in ? -gd : 0.f;
+            }
         }
     };
 
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(256, B8_CB == 1 ? (DKDV ? 3 : 4) : 2) void attn_bwd
     fetch(0);
     for (int t = 0; t < nt; ++t) {
         __syncthreads();                      // everyone is done with the previous tile
-        commit();
+        commit(t);
         __syncthreads();
         if (t + 1 < nt) fetch(t + 1);         // in flight during the products
 
@@ -234,6 +247,274 @@ __global__ __launch_bounds__(256, B8_CB == 1 ? (DKDV ? 3 : 4) : 2) void attn_bwd
     }
 }
 
+// dK/dV on v_mfma_f32_32x32x16_bf16: a workgroup owns 128 keys (wave = 32) and streams the queries in the same 32-row tiles (same LDS
+// images, same loader) as the kernel above.  Per operand byte read from LDS the 32x32 product does twice the arithmetic of the 16x16 one:
+// with one 16-key block per wave the kernel above reads 32 KB of LDS per wave and tile for 32 MFMA-16 (LDS : matrix time 2 : 1), this one
+// 32 KB for 32 MFMA-32 (1 : 1).  Same algebra and the same register-resident P / dS trick: S = Q K^T leaves the matrix unit with
+// C layout "column = own key (lane & 31), rows = queries 8 (r >> 2) + 4 (lane >> 5) + (r & 3)", which is the B operand of the
+// accumulating products when k-slot j of k-step s and group g = lane >> 5 stands for query 16 s + 8 (j >> 2) + 4 g + (j & 3) = C
+// register 8 s + j; the A operand (the transposed tile) is read with that permutation as two 8-byte reads 8 queries apart.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+template <bool DKDV, int AHEAD = 0, bool LATE = false>
+__global__ __launch_bounds__(256, 2) void attn_bwd_d128_w32_kernel(const AttnBwdParams p) {
+    constexpr int OWN = 128;
+    // LDS: streamed tile row-major x 2 | transposed x0 (| transposed x1 | -L, -D of the tile's queries | the workgroup's own V rows)
+    constexpr int OFF_T0 = 2 * B8_ROWMAJ, OFF_T1 = OFF_T0 + B8_TRANS, OFF_LD = OFF_T1 + B8_TRANS, OFF_XV = OFF_LD + 2 * B8_ROWS * 4;
+    __shared__ __attribute__((aligned(16))) char smem[DKDV ? OFF_XV + OWN * B8_RP * 2 : OFF_T1];
+    bf16_t* x0 = reinterpret_cast<bf16_t*>(smem);                        // streamed operand 0 (Q | K), row-major, swizzled chunks
+    bf16_t* x1 = reinterpret_cast<bf16_t*>(smem + B8_ROWMAJ);             // streamed operand 1 (dO | V)
+    bf16_t* x0t = reinterpret_cast<bf16_t*>(smem + OFF_T0);               // operand 0 transposed [d][row]
+    bf16_t* x1t = reinterpret_cast<bf16_t*>(smem + (DKDV ? OFF_T1 : 0));  // (dK/dV only)
+    float* lvec = reinterpret_cast<float*>(smem + (DKDV ? OFF_LD : 0));   // (dK/dV only)
+    float* dvec = lvec + B8_ROWS;
+    bf16_t* xv = reinterpret_cast<bf16_t*>(smem + (DKDV ? OFF_XV : 0));   // (dK/dV only)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, hi = lane >> 5;
+    const int n_own = DKDV ? p.Skv : p.Sq, n_str = DKDV ? p.Sq : p.Skv;
+    int blk, h, b;
+    xcd_local_bh((n_own + OWN - 1) / OWN, p.H, (int)gridDim.x, p.xcd_local, blk, h, b);
+    const int own0 = blk * OWN + wave * 32;
+    const int64_t bh = (int64_t)b * p.H + h;
+    const bf16_t* s0p = (DKDV ? p.q + (int64_t)b * p.bsq : p.k + (int64_t)b * p.bsk) + h * B8_HD;
+    const bf16_t* s1p = (DKDV ? p.d_o + (int64_t)b * p.bsdo : p.v + (int64_t)b * p.bsv) + h * B8_HD;
+    const int64_t ld_s0 = DKDV ? p.ldq : p.ldk, ld_s1 = DKDV ? p.lddo : p.ldv;
+    const float* Lp = p.lse + bh * p.Sq;
+    const float* Dp = p.vec + bh * p.Sq;
+    const float c = p.scale_log2e;
+
+    // own-side B fragments: row own0 + col, k = d = ks * 16 + hi * 8 .. + 7.  dK/dV: K stays in registers; V (32 more registers: with
+    // both, and two accumulator sets, the kernel spills at two waves per SIMD) is read from an LDS image written once.  dQ: Q and dO in
+    // registers (one accumulator set)
+    bf16x8_t b0[8], b1r[DKDV ? 1 : 8];
+    float negL_own = 0.f, negD_own = 0.f;
+    {
+        const int own_r = min(own0 + col, n_own - 1);
+        const bf16_t* o0p = (DKDV ? p.k + (int64_t)b * p.bsk + (int64_t)own_r * p.ldk : p.q + (int64_t)b * p.bsq + (int64_t)own_r * p.ldq) + h * B8_HD + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) b0[ks] = *reinterpret_cast<const bf16x8_t*>(o0p + ks * 16);
+        if constexpr (DKDV) {
+#pragma unroll
+            for (int i = 0; i < OWN * 16 / 256; ++i) {
+                const int e = tid + 256 * i, r = e >> 4, ch = e & 15;
+                const int vr = min(blk * OWN + r, n_own - 1);
+                *reinterpret_cast<uint4*>(xv + r * B8_RP + ((ch ^ (r & 15)) * 8)) =
+                    *reinterpret_cast<const uint4*>(p.v + (int64_t)b * p.bsv + (int64_t)vr * p.ldv + h * B8_HD + ch * 8);
+            }
+        } else {
+            const bf16_t* o1p = p.d_o + (int64_t)b * p.bsdo + (int64_t)own_r * p.lddo + h * B8_HD + hi * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) b1r[ks] = *reinterpret_cast<const bf16x8_t*>(o1p + ks * 16);
+            negL_own = -Lp[own_r];
+            negD_own = -Dp[own_r];
+        }
+    }
+    const bf16_t* xv_own = xv + (wave * 32 + col) * B8_RP;
+    f32x16_t acc0[4], acc1[DKDV ? 4 : 1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[i][r] = 0.f; if constexpr (DKDV) acc1[i][r] = 0.f; }
+
+    const int lrow = tid >> 3, lch = tid & 7;
+    uint4 g0[2], g1[2];
+    float gl = 0.f, gd = 0.f;
+    // (uniform base + 32-bit byte offset per lane: the launcher checks rows * ld * 2 < 2^31.  64-bit per-lane pointers cost the registers
+    // whose spilling put two scratch round trips into every tile)
+    const uint32_t ldb0 = (uint32_t)ld_s0 * 2u, ldb1 = (uint32_t)ld_s1 * 2u;
+    auto fetch = [&](int t) {
+        const uint32_t r = (uint32_t)min(t * B8_ROWS + lrow, n_str - 1);
+        const char* q0 = reinterpret_cast<const char*>(s0p) + (size_t)(r * ldb0 + (uint32_t)lch * 16u);
+        const char* q1 = reinterpret_cast<const char*>(s1p) + (size_t)(r * ldb1 + (uint32_t)lch * 16u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            g0[i] = *reinterpret_cast<const uint4*>(q0 + 128 * i);
+            g1[i] = *reinterpret_cast<const uint4*>(q1 + 128 * i);
+        }
+        if constexpr (DKDV) {
+            if (tid < B8_ROWS) {
+                const int q = min(t * B8_ROWS + tid, n_str - 1);
+                gl = Lp[q];                     // (raw: negated / masked in commit, so that nothing waits on these loads here)
+                gd = Dp[q];
+            }
+        }
+    };
+    auto commit = [&](int t) {   // (the loader of the kernel above: row-major image + transposed image by DPP-paired 4-byte stores)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = lch + 8 * i;
+            *reinterpret_cast<uint4*>(x0 + lrow * B8_RP + ((ch ^ (lrow & 15)) * 8)) = g0[i];
+            *reinterpret_cast<uint4*>(x1 + lrow * B8_RP + ((ch ^ (lrow & 15)) * 8)) = g1[i];
+            const uint32_t w0[4] = {g0[i].x, g0[i].y, g0[i].z, g0[i].w}, w1[4] = {g1[i].x, g1[i].y, g1[i].z, g1[i].w};
+            const int odd = lrow & 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t mine0 = odd ? w0[j + 2] : w0[j], give0 = odd ? w0[j] : w0[j + 2];
+                const uint32_t got0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give0, 0x128, 0xf, 0xf, true);
+                const uint32_t ev0 = odd ? got0 : mine0, od0 = odd ? mine0 : got0;
+                const int d = ch * 8 + 4 * odd + 2 * j;
+                *reinterpret_cast<uint32_t*>(x0t + d * B8_TP + (lrow & ~1)) = (ev0 & 0xffffu) | (od0 << 16);
+                *reinterpret_cast<uint32_t*>(x0t + (d + 1) * B8_TP + (lrow & ~1)) = (ev0 >> 16) | (od0 & 0xffff0000u);
+                if constexpr (DKDV) {
+                    const uint32_t mine1 = odd ? w1[j + 2] : w1[j], give1 = odd ? w1[j] : w1[j + 2];
+                    const uint32_t got1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give1, 0x128, 0xf, 0xf, true);
+                    const uint32_t ev1 = odd ? got1 : mine1, od1 = odd ? mine1 : got1;
+                    *reinterpret_cast<uint32_t*>(x1t + d * B8_TP + (lrow & ~1)) = (ev1 & 0xffffu) | (od1 << 16);
+                    *reinterpret_cast<uint32_t*>(x1t + (d + 1) * B8_TP + (lrow & ~1)) = (ev1 >> 16) | (od1 & 0xffff0000u);
+                }
+            }
+        }
+        if constexpr (DKDV) {
+            if (tid < B8_ROWS) {
+                const bool in = t * B8_ROWS + tid < n_str;
+                lvec[tid] = in ? -gl : -INFINITY;       // a query past the end: P = 0 exactly
+                dvec[tid] = in ? -gd : 0.f;
+            }
+        }
+    };
+
+    const int nt = (n_str + B8_ROWS - 1) / B8_ROWS;
+    fetch(0);
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();
+        commit(t);
+        __syncthreads();
+        if (!LATE && t + 1 < nt) fetch(t + 1);
+        const bool last_ragged = t == nt - 1 && nt * B8_ROWS > n_str;       // (uniform; dQ: only the last tile of a ragged sequence masks keys)
+
+        // ---- scores and dP: the tile's 32 rows x the wave's 32 own rows, k = d in 8 steps of 16
+        f32x16_t sc, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+        if constexpr (AHEAD > 0) {
+            // fragments AHEAD k-steps ahead of the products (the tile loads are issued AFTER this phase, so their 16 registers are free here)
+            bf16x8_t fa0[8], fa1[8], fb1[DKDV ? 8 : 1];
+            auto rd = [&](int ks) {
+                fa0[ks] = *reinterpret_cast<const bf16x8_t*>(x0 + col * B8_RP + (((ks * 2 + hi) ^ (col & 15)) * 8));
+                fa1[ks] = *reinterpret_cast<const bf16x8_t*>(x1 + col * B8_RP + (((ks * 2 + hi) ^ (col & 15)) * 8));
+                if constexpr (DKDV) fb1[ks] = *reinterpret_cast<const bf16x8_t*>(xv_own + (((ks * 2 + hi) ^ (col & 15)) * 8));
+            };
+            constexpr int NRD = DKDV ? 3 : 2;
+#pragma unroll
+            for (int ks = 0; ks < AHEAD; ++ks) rd(ks);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks + AHEAD < 8) rd(ks + AHEAD);
+                const int left = NRD * (7 - ks < AHEAD ? 7 - ks : AHEAD);     // reads that may still be in flight: those of later steps
+                if (left == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                else if (left == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                else if (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else if (left == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                else if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                bf16x8_t b1;
+                if constexpr (DKDV) b1 = fb1[ks]; else b1 = b1r[ks];
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[ks], b0[ks], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[ks], b1, dp, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(x0 + col * B8_RP + (((ks * 2 + hi) ^ (col & 15)) * 8));
+                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(x1 + col * B8_RP + (((ks * 2 + hi) ^ (col & 15)) * 8));
+                bf16x8_t b1;
+                if constexpr (DKDV) b1 = *reinterpret_cast<const bf16x8_t*>(xv_own + (((ks * 2 + hi) ^ (col & 15)) * 8));
+                else b1 = b1r[ks];
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0[ks], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, dp, 0, 0, 0);
+            }
+        }
+        // ---- P and dS in registers: C register r = streamed row 8 (r >> 2) + 4 hi + (r & 3) of the tile, own row own0 + col
+        bf16x8_t pf[2], dsf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint32_t pw[4], dw[4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {                       // C registers 8 s + 4 u .. + 3 = streamed rows 16 s + 8 u + 4 hi + 0..3
+                f32x4_t nl, nd;
+                if constexpr (DKDV) {
+                    nl = *reinterpret_cast<const f32x4_t*>(lvec + 16 * s + 8 * u + 4 * hi);
+                    nd = *reinterpret_cast<const f32x4_t*>(dvec + 16 * s + 8 * u + 4 * hi);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        nl[v] = (last_ragged && t * B8_ROWS + 16 * s + 8 * u + 4 * hi + v >= n_str) ? -INFINITY : negL_own;   // a key past the end: P = 0
+                        nd[v] = negD_own;
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const int r = 8 * s + 4 * u + 2 * v;
+                    f32x2_t pe, dd;
+                    pe.x = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c, nl[2 * v]));
+                    pe.y = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r + 1], c, nl[2 * v + 1]));
+                    dd.x = dp[r] + nd[2 * v];
+                    dd.y = dp[r + 1] + nd[2 * v + 1];
+                    dd = dd * pe;
+                    if constexpr (DKDV) pw[2 * u + v] = pack2(pe);
+                    dw[2 * u + v] = pack2(dd);
+                }
+            }
+            uint4 dsw, pww;
+            dsw.x = dw[0]; dsw.y = dw[1]; dsw.z = dw[2]; dsw.w = dw[3];
+            dsf[s] = __builtin_bit_cast(bf16x8_t, dsw);
+            if constexpr (DKDV) {
+                pww.x = pw[0]; pww.y = pw[1]; pww.z = pw[2]; pww.w = pw[3];
+                pf[s] = __builtin_bit_cast(bf16x8_t, pww);
+            }
+        }
+        if (LATE && t + 1 < nt) fetch(t + 1);
+        // ---- accumulating products (dK^T += Q^T dS, dV^T += dO^T P | dQ^T += K^T dS^T): A = transposed tile rows d = db * 32 + col,
+        //      k = streamed rows in the permuted order
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16_t* r0 = x0t + (db * 32 + col) * B8_TP + 16 * s + 4 * hi;
+                const uint2 lo0 = *reinterpret_cast<const uint2*>(r0), up0 = *reinterpret_cast<const uint2*>(r0 + 8);
+                uint4 aw;
+                aw.x = lo0.x; aw.y = lo0.y; aw.z = up0.x; aw.w = up0.y;
+                acc0[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, aw), dsf[s], acc0[db], 0, 0, 0);
+                if constexpr (DKDV) {
+                    const bf16_t* r1 = x1t + (db * 32 + col) * B8_TP + 16 * s + 4 * hi;
+                    const uint2 lo1 = *reinterpret_cast<const uint2*>(r1), up1 = *reinterpret_cast<const uint2*>(r1 + 8);
+                    uint4 bw;
+                    bw.x = lo1.x; bw.y = lo1.y; bw.z = up1.x; bw.w = up1.y;
+                    acc1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bw), pf[s], acc1[db], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- store: acc[db][r] = (own row own0 + col, d = db * 32 + 8 (r >> 2) + 4 hi + (r & 3)): four consecutive d = 8 bytes
+    const int orow = own0 + col;
+    if (orow < n_own) {
+        bf16_t* o0 = (DKDV ? p.dk : p.dq) + (int64_t)b * p.bsdq + (int64_t)orow * p.lddq + h * B8_HD;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint2 v;
+                v.x = pack2(f32x2_t{acc0[db][4 * q] * p.scale, acc0[db][4 * q + 1] * p.scale});
+                v.y = pack2(f32x2_t{acc0[db][4 * q + 2] * p.scale, acc0[db][4 * q + 3] * p.scale});
+                *reinterpret_cast<uint2*>(o0 + db * 32 + 8 * q + 4 * hi) = v;
+            }
+        if constexpr (DKDV) {
+            bf16_t* o1 = p.dv + (int64_t)b * p.bsdq + (int64_t)orow * p.lddq + h * B8_HD;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint2 w;
+                    w.x = pack2(f32x2_t{acc1[db][4 * q], acc1[db][4 * q + 1]});
+                    w.y = pack2(f32x2_t{acc1[db][4 * q + 2], acc1[db][4 * q + 3]});
+                    *reinterpret_cast<uint2*>(o1 + db * 32 + 8 * q + 4 * hi) = w;
+                }
+        }
+    }
+}
+
 // D[b, h, q] = sum_d O[q, d] dO[q, d]: one wave per (b, q) row, 16 lanes per head
 __global__ __launch_bounds__(256) void attn_bwd_delta128_kernel(const AttnBwdParams p, int B) {
     const int lane = threadIdx.x & 63;
@@ -268,14 +549,24 @@ __global__ __launch_bounds__(256) void attn_bwd_delta128_kernel(const AttnBwdPar
 int attention_bwd_d128_launch(const AttnBwdParams& p, int B, hipStream_t s) {
     hipLaunchKernelGGL(attn_bwd_delta128_kernel, dim3((unsigned)(((int64_t)B * p.Sq + 3) / 4)), dim3(256), 0, s, p, B);
     ADVGRPO_LAUNCH_CHECK();
-    // dQ: two own-row blocks per wave (234 registers, two waves per SIMD); dK/dV: ONE (two accumulator sets: with two blocks it needs
-    // 314 registers -- one wave per SIMD, or spills that cost 50 % -- with one block 3 waves per SIMD; same-box A/B 17.5 vs 19.0 ms)
+    // dQ: the 16x16 kernel with two own-row blocks per wave (227 registers, two waves per SIMD).  dK/dV: the 32x32 kernel (254 registers, two
+    // waves per SIMD).  Same-box kernel times at 16 x 24 x 4224 (rocprofv3; scripts/probes/attn_bwd_d128_variants.sh):
+    //   dK/dV  16x16 one block per wave 9.96 ms | 32x32 7.9 - 8.1 ms | 32x32 with the tile loads issued after the score phase 9.8 ms (spills)
+    //   dQ     16x16 two blocks 6.6 - 6.9 ms    | 32x32 8.4 ms       | 32x32, tile loads after the score phase, fragments 2 steps ahead 7.0 - 7.6 ms
+    // ADVGRPO_ATTN_BWD_D128 (A/B switch, read once): dQ variant << 4 | dK/dV variant; 0 = 16x16, 1 = 32x32 (dQ: the late-load form).  Default 0x01.
     constexpr int CBQ = 2, CBK = 1;
+    static const int variant = [] { const char* e = getenv("ADVGRPO_ATTN_BWD_D128"); return e ? atoi(e) : 1; }();
+    const bool fits32 = (int64_t)p.Sq * p.ldq * 2 < (1ll << 31) && (int64_t)p.Sq * p.lddo * 2 < (1ll << 31) &&
+                        (int64_t)p.Skv * p.ldk * 2 < (1ll << 31) && (int64_t)p.Skv * p.ldv * 2 < (1ll << 31);
     const int64_t nq = (int64_t)((p.Sq + 64 * CBQ - 1) / (64 * CBQ)) * p.H * B, nk = (int64_t)((p.Skv + 64 * CBK - 1) / (64 * CBK)) * p.H * B;
     ADVGRPO_CHECK(nq < (1ll << 31) && nk < (1ll << 31), "attention_bwd (d128): grid too large");
-    hipLaunchKernelGGL((attn_bwd_d128_kernel<false, CBQ>), dim3((unsigned)nq), dim3(256), 0, s, p);
+    ADVGRPO_CHECK(fits32, "attention_bwd (d128): rows * row stride must stay below 2^30 elements (32-bit byte offsets)");
+    const dim3 gq((unsigned)((int64_t)((p.Sq + 127) / 128) * p.H * B)), gk((unsigned)((int64_t)((p.Skv + 127) / 128) * p.H * B));
+    if ((variant >> 4) & 1) hipLaunchKernelGGL((attn_bwd_d128_w32_kernel<false, 2, true>), gq, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_bwd_d128_kernel<false, CBQ>), dim3((unsigned)nq), dim3(256), 0, s, p);
     ADVGRPO_LAUNCH_CHECK();
-    hipLaunchKernelGGL((attn_bwd_d128_kernel<true, CBK>), dim3((unsigned)nk), dim3(256), 0, s, p);
+    if (variant & 1) hipLaunchKernelGGL((attn_bwd_d128_w32_kernel<true, 0, false>), gk, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_bwd_d128_kernel<true, CBK>), dim3((unsigned)nk), dim3(256), 0, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }
