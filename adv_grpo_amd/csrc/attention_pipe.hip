@@ -116,14 +116,18 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
     // ---- DMA sources.  Instruction jj (0..7) of a tile fills LDS rows 8 jj .. 8 jj + 7; this wave issues jj = wave, wave + 4.
     // Uniform (SGPR) tile base + 32-bit per-lane byte offset: the builtin form keeps a 64-bit pointer per lane and instruction.
     const int lrow = lane >> 3, pch = lane & 7;
-    uint32_t k_lo[2], v_lo[2];               // byte offsets of this lane's 16 bytes inside an interior tile
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int R = (wave + 4 * i) * 8 + lrow;              // LDS row
+    // byte offset of this lane's 16 bytes inside an interior tile for instruction jj = wave; instruction wave + 4 is 32 LDS rows = 32 tile
+    // rows further on with the same swizzle term (R + 32 keeps bit 4, bits 0..2 and bit 1 of R), so it uses the SAME per-lane offset with
+    // the uniform base moved by 32 rows: one register each for K and V (with two, the pair was spilled and reloaded -- scratch_load +
+    // s_waitcnt vmcnt(0), i.e. a wait for the tile DMA just issued -- in every ring step)
+    uint32_t k_lo, v_lo;
+    {
+        const int R = wave * 8 + lrow;                        // LDS row
         const int rk = R ^ ((R >> 4) & 1);                    // tile row held by that LDS row (K)
-        k_lo[i] = (uint32_t)rk * (uint32_t)(p.ldk * 2) + (uint32_t)((pch ^ (rk & 7)) * 16);
-        v_lo[i] = (uint32_t)R * (uint32_t)(p.ldv * 2) + (uint32_t)((pch ^ (((R >> 1) & 1) << 2)) * 16);
+        k_lo = (uint32_t)rk * (uint32_t)(p.ldk * 2) + (uint32_t)((pch ^ (rk & 7)) * 16);
+        v_lo = (uint32_t)R * (uint32_t)(p.ldv * 2) + (uint32_t)((pch ^ (((R >> 1) & 1) << 2)) * 16);
     }
+    const int64_t k_half = (int64_t)32 * p.ldk * 2, v_half = (int64_t)32 * p.ldv * 2;
     const int64_t k_step = (int64_t)ATT_KB * p.ldk * 2, v_step = (int64_t)ATT_KB * p.ldv * 2;      // bytes per tile
     const uint32_t k_lds = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)(Kr)) + wave * 1024;
     const uint32_t v_lds = k_lds + 3 * TILE_B;
@@ -145,8 +149,8 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
                 dma(base, (uint32_t)r * (uint32_t)(p.ldk * 2) + (uint32_t)((pch ^ (rk & 7)) * 16), lds + i * 4096);
             }
         } else {
-            dma(base, k_lo[0], lds);
-            dma(base, k_lo[1], lds + 4096);
+            dma(base, k_lo, lds);
+            dma(base + k_half, k_lo, lds + 4096);
         }
     };
     auto stage_v = [&](int slot, int t) __attribute__((always_inline)) {
@@ -161,8 +165,8 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
                 dma(base, (uint32_t)r * (uint32_t)(p.ldv * 2) + (uint32_t)((pch ^ (((R >> 1) & 1) << 2)) * 16), lds + i * 4096);
             }
         } else {
-            dma(base, v_lo[0], lds);
-            dma(base, v_lo[1], lds + 4096);
+            dma(base, v_lo, lds);
+            dma(base + v_half, v_lo, lds + 4096);
         }
     };
 
