@@ -200,12 +200,28 @@ __global__ __launch_bounds__(256, B8_CB == 1 ? (DKDV ? 3 : 4) : 2) void attn_bwd
             pf[cb] = __builtin_bit_cast(bf16x8_t, pw);
         }
         // ---- accumulating products: A = transposed streamed tile, rows d = db * 16 + col, k slots in the permuted order
+        uint4 awv[DKDV ? 1 : 8];
+        if constexpr (!DKDV) {
+            // dQ: all eight A fragments requested up front (the score registers are dead by now): left to itself the compiler issues
+            // read, wait, two products, eight times over -- an exposed LDS latency per pair of products
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                const bf16_t* r0 = x0t + (db * 16 + col) * B8_TP + kg * 4;
+                const uint2 lo = *reinterpret_cast<const uint2*>(r0), up = *reinterpret_cast<const uint2*>(r0 + 16);
+                awv[db].x = lo.x; awv[db].y = lo.y; awv[db].z = up.x; awv[db].w = up.y;
+            }
+            __builtin_amdgcn_sched_barrier(0);       // (keeps the machine scheduler from sinking the reads back to their uses)
+        }
 #pragma unroll
         for (int db = 0; db < 8; ++db) {
-            const bf16_t* r0 = x0t + (db * 16 + col) * B8_TP + kg * 4;
             uint4 aw;
-            const uint2 lo = *reinterpret_cast<const uint2*>(r0), up = *reinterpret_cast<const uint2*>(r0 + 16);
-            aw.x = lo.x; aw.y = lo.y; aw.z = up.x; aw.w = up.y;
+            if constexpr (!DKDV) {
+                aw = awv[db];
+            } else {
+                const bf16_t* r0 = x0t + (db * 16 + col) * B8_TP + kg * 4;
+                const uint2 lo = *reinterpret_cast<const uint2*>(r0), up = *reinterpret_cast<const uint2*>(r0 + 16);
+                aw.x = lo.x; aw.y = lo.y; aw.z = up.x; aw.w = up.y;
+            }
 #pragma unroll
             for (int cb = 0; cb < B8_CB; ++cb)
                 acc0[cb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw), dsf[cb], acc0[cb][db], 0, 0, 0);
@@ -310,7 +326,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_d128_w32_kernel(const AttnBwd
             negD_own = -Dp[own_r];
         }
     }
-    const bf16_t* xv_own = xv + (wave * 32 + col) * B8_RP;
     f32x16_t acc0[4], acc1[DKDV ? 4 : 1];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -383,6 +398,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_d128_w32_kernel(const AttnBwd
         if (!LATE && t + 1 < nt) fetch(t + 1);
         const bool last_ragged = t == nt - 1 && nt * B8_ROWS > n_str;       // (uniform; dQ: only the last tile of a ragged sequence masks keys)
 
+        // fragment address of k-step ks = (row base + swizzled chunk of k-step 0) ^ (ks << 5): chunk (2 ks + hi) ^ (col & 15) = (2 ks) ^
+        // (hi ^ (col & 15)), and the row base is a multiple of 256.  The base is made opaque once per tile so that the eight addresses
+        // are ONE register and an XOR each instead of sixteen loop-invariant registers (they were what pushed this kernel into spilling)
+        uint32_t fbase = (uint32_t)(col * (B8_RP * 2) + ((hi ^ (col & 15)) << 4));
+        asm volatile("" : "+v"(fbase));
+        const char* x0c = reinterpret_cast<const char*>(x0);
+        const char* xvc = reinterpret_cast<const char*>(xv) + (wave * 32) * (B8_RP * 2);
         // ---- scores and dP: the tile's 32 rows x the wave's 32 own rows, k = d in 8 steps of 16
         f32x16_t sc, dp;
 #pragma unroll
@@ -391,9 +413,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_d128_w32_kernel(const AttnBwd
             // fragments AHEAD k-steps ahead of the products (the tile loads are issued AFTER this phase, so their 16 registers are free here)
             bf16x8_t fa0[8], fa1[8], fb1[DKDV ? 8 : 1];
             auto rd = [&](int ks) {
-                fa0[ks] = *reinterpret_cast<const bf16x8_t*>(x0 + col * B8_RP + (((ks * 2 + hi) ^ (col & 15)) * 8));
-                fa1[ks] = *reinterpret_cast<const bf16x8_t*>(x1 + col * B8_RP + (((ks * 2 + hi) ^ (col & 15)) * 8));
-                if constexpr (DKDV) fb1[ks] = *reinterpret_cast<const bf16x8_t*>(xv_own + (((ks * 2 + hi) ^ (col & 15)) * 8));
+                fa0[ks] = *reinterpret_cast<const bf16x8_t*>(x0c + (fbase ^ (uint32_t)(ks << 5)));
+                fa1[ks] = *reinterpret_cast<const bf16x8_t*>(x0c + B8_ROWMAJ + (fbase ^ (uint32_t)(ks << 5)));
+                if constexpr (DKDV) fb1[ks] = *reinterpret_cast<const bf16x8_t*>(xvc + (fbase ^ (uint32_t)(ks << 5)));
             };
             constexpr int NRD = DKDV ? 3 : 2;
 #pragma unroll
@@ -416,10 +438,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_d128_w32_kernel(const AttnBwd
         } else {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(x0 + col * B8_RP + (((ks * 2 + hi) ^ (col & 15)) * 8));
-                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(x1 + col * B8_RP + (((ks * 2 + hi) ^ (col & 15)) * 8));
+                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(x0c + (fbase ^ (uint32_t)(ks << 5)));
+                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(x0c + B8_ROWMAJ + (fbase ^ (uint32_t)(ks << 5)));
                 bf16x8_t b1;
-                if constexpr (DKDV) b1 = *reinterpret_cast<const bf16x8_t*>(xv_own + (((ks * 2 + hi) ^ (col & 15)) * 8));
+                if constexpr (DKDV) b1 = *reinterpret_cast<const bf16x8_t*>(xvc + (fbase ^ (uint32_t)(ks << 5)));
                 else b1 = b1r[ks];
                 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0[ks], sc, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, dp, 0, 0, 0);
@@ -467,21 +489,47 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_d128_w32_kernel(const AttnBwd
         if (LATE && t + 1 < nt) fetch(t + 1);
         // ---- accumulating products (dK^T += Q^T dS, dV^T += dO^T P | dQ^T += K^T dS^T): A = transposed tile rows d = db * 32 + col,
         //      k = streamed rows in the permuted order
+        if constexpr (DKDV) {
+            // fragments of d-block db + 2 are requested while the products of block db issue (ping-pong register sets, the order pinned by
+            // sched_barrier: left alone the compiler issues read, wait, product one after the other)
+            uint4 fq[2][4];
+            auto rdq = [&](int db, uint4* f) {
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16_t* r0 = x0t + (db * 32 + col) * B8_TP + 16 * s + 4 * hi;
-                const uint2 lo0 = *reinterpret_cast<const uint2*>(r0), up0 = *reinterpret_cast<const uint2*>(r0 + 8);
-                uint4 aw;
-                aw.x = lo0.x; aw.y = lo0.y; aw.z = up0.x; aw.w = up0.y;
-                acc0[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, aw), dsf[s], acc0[db], 0, 0, 0);
-                if constexpr (DKDV) {
+                for (int s = 0; s < 2; ++s) {
+                    const bf16_t* r0 = x0t + (db * 32 + col) * B8_TP + 16 * s + 4 * hi;
                     const bf16_t* r1 = x1t + (db * 32 + col) * B8_TP + 16 * s + 4 * hi;
+                    const uint2 lo0 = *reinterpret_cast<const uint2*>(r0), up0 = *reinterpret_cast<const uint2*>(r0 + 8);
                     const uint2 lo1 = *reinterpret_cast<const uint2*>(r1), up1 = *reinterpret_cast<const uint2*>(r1 + 8);
-                    uint4 bw;
-                    bw.x = lo1.x; bw.y = lo1.y; bw.z = up1.x; bw.w = up1.y;
-                    acc1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bw), pf[s], acc1[db], 0, 0, 0);
+                    f[2 * s].x = lo0.x; f[2 * s].y = lo0.y; f[2 * s].z = up0.x; f[2 * s].w = up0.y;
+                    f[2 * s + 1].x = lo1.x; f[2 * s + 1].y = lo1.y; f[2 * s + 1].z = up1.x; f[2 * s + 1].w = up1.y;
+                }
+            };
+            rdq(0, fq[0]);
+            rdq(1, fq[1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    acc0[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fq[db & 1][2 * s]), dsf[s], acc0[db], 0, 0, 0);
+                    acc1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fq[db & 1][2 * s + 1]), pf[s], acc1[db], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (db + 2 < 4) {
+                    rdq(db + 2, fq[db & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16_t* r0 = x0t + (db * 32 + col) * B8_TP + 16 * s + 4 * hi;
+                    const uint2 lo0 = *reinterpret_cast<const uint2*>(r0), up0 = *reinterpret_cast<const uint2*>(r0 + 8);
+                    uint4 aw;
+                    aw.x = lo0.x; aw.y = lo0.y; aw.z = up0.x; aw.w = up0.y;
+                    acc0[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, aw), dsf[s], acc0[db], 0, 0, 0);
                 }
             }
         }
@@ -552,7 +600,10 @@ int attention_bwd_d128_launch(const AttnBwdParams& p, int B, hipStream_t s) {
     // dQ: the 16x16 kernel with two own-row blocks per wave (227 registers, two waves per SIMD).  dK/dV: the 32x32 kernel (254 registers, two
     // waves per SIMD).  Same-box kernel times at 16 x 24 x 4224 (rocprofv3; scripts/probes/attn_bwd_d128_variants.sh):
     //   dK/dV  16x16 one block per wave 9.96 ms | 32x32 7.9 - 8.1 ms | 32x32 with the tile loads issued after the score phase 9.8 ms (spills)
-    //   dQ     16x16 two blocks 6.6 - 6.9 ms    | 32x32 8.4 ms       | 32x32, tile loads after the score phase, fragments 2 steps ahead 7.0 - 7.6 ms
+    //          | 32x32 + pinned ping-pong fragment reads in the accumulating phase + one-register XOR fragment addresses 7.8 - 7.9 (prev. 7.97)
+    //          | the same + score-phase fragments one k-step ahead 8.1 - 8.2
+    //   dQ     16x16 two blocks 6.9 ms -> 6.55 ms with the eight accumulating-phase fragments requested up front
+    //          | 32x32 8.4 ms | 32x32, tile loads after the score phase, fragments 2 steps ahead 7.0 - 7.6 ms
     // ADVGRPO_ATTN_BWD_D128 (A/B switch, read once): dQ variant << 4 | dK/dV variant; 0 = 16x16, 1 = 32x32 (dQ: the late-load form).  Default 0x01.
     constexpr int CBQ = 2, CBK = 1;
     static const int variant = [] { const char* e = getenv("ADVGRPO_ATTN_BWD_D128"); return e ? atoi(e) : 1; }();
