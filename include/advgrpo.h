@@ -238,7 +238,10 @@ int advgrpo_attention_fwd_bias(const void* q, const void* k, const void* v, void
  * scripts/train_sd3_fast_pickscore.py:233-267, reached from loss.backward() at :1165).  head_dim 64.
  * d_o: gradient w.r.t. o (same view convention, pitch lddo / bsdo); lse from the forward; work: f32 scratch of
  * B * H * ceil(Sq / 32) * 64 elements (filled here: per block of 32 queries, -lse / (scale log2 e) and -rowsum(o * d_o));
- * dq/dk/dv: bf16 views with pitches lddq / bsdq (one packed buffer).  All pointers and pitches 16-byte aligned. */
+ * dq/dk/dv: bf16 views with pitches lddq / bsdq (one packed buffer).  All pointers and pitches 16-byte aligned.
+ * head_dim 128 (the Qwen-Image MMDiT, BASELINE config 5): the same call; work holds B * H * Sq f32 (rowsum(o * d_o)); the tile
+ * loaders address with 32-bit byte offsets from a per-(b, h) base, so Sq * ldq, Sq * lddo, Skv * ldk and Skv * ldv must each
+ * stay below 2^30 elements (checked; the call fails otherwise). */
 int advgrpo_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                           const float* lse, float* work, void* dq, void* dk, void* dv,
                           int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,

@@ -42,6 +42,26 @@ def test_attention_backward_d128_matches_autograd(B, H, Sq, Skv):
     assert torch.equal(again, dqkv)
 
 
+def test_attention_backward_d128_refuses_rows_beyond_32_bit_offsets():
+    """The head-dim-128 backward addresses its tiles with 32-bit byte offsets from a per-(b, h) base: a view whose rows * row pitch
+    reaches 2^30 elements must fail loudly (include/advgrpo.h), not wrap around."""
+    from adv_grpo_amd import ops
+    from adv_grpo_amd._lib import AdvGrpoError
+    D, H, S = 128, 1, 64
+    ld = (1 << 24) + 128                                      # 64 rows x 2^24 elements = 2^30
+    big = torch.zeros(S * ld, dtype=bf16, device="cuda")      # 2 GiB
+    q = big.as_strided((1, S, H * D), (S * ld, ld, 1))
+    k = torch.randn(1, S, H * D, device="cuda").to(bf16)
+    v = torch.randn(1, S, H * D, device="cuda").to(bf16)
+    lse = torch.empty(1, H, S, dtype=torch.float32, device="cuda")
+    o = ops.attention(q.contiguous(), k, v, H, lse=lse)
+    d_o = torch.randn(1, S, H * D, device="cuda").to(bf16)
+    dq, dk, dv = (torch.empty(1, S, H * D, dtype=bf16, device="cuda") for _ in range(3))
+    with pytest.raises(AdvGrpoError, match="2\^30"):
+        ops.attention_bwd(q, k, v, o, d_o, lse, H, dq, dk, dv)
+    ops.attention_bwd(k, k, v, o, d_o, lse, H, dq, dk, dv)    # (the same call on ordinary views goes through)
+
+
 @pytest.mark.parametrize("hd,H,Ni,Nt,B", [(128, 24, 100, 13, 2), (128, 4, 64, 7, 3), (64, 6, 50, 5, 2)])
 def test_qk_norm_rope_backward_matches_autograd(hd, H, Ni, Nt, B):
     """In-place gradient of per-head RMSNorm (image / text weights) + rotary embedding on the q | k part of the joint buffer,
