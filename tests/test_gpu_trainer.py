@@ -388,6 +388,25 @@ def test_bench_self_spawn_path_at_world_1():
     assert sd["value_at_n1_same_run"] > 0 and 0.8 < sd["value_over_n_times_n1"] < 1.25
 
 
+@pytest.mark.parametrize("model,preset,extra", [
+    ("Qwen/Qwen-Image", "dino_cotrain_sd3_patch_fast", ["--linear-dtype", "fp8", "--images-per-prompt", "8", "--no-train-d"]),
+    ("stabilityai/stable-diffusion-3.5-large", "pickscore_sd3_fast", ["--images-per-prompt", "4"])])
+def test_launcher_selects_the_model_by_pretrained_name(tmp_path, model, preset, extra):
+    """scripts/train_sd3_fast.py --model overrides config.pretrained.model, the field by which the reference selects BASELINE configs 4
+    and 5 (config/grpo.py:324,330): a reduced-depth run of each goes through sampling, scoring and one G epoch."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    log = tmp_path / "train.jsonl"
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "train_sd3_fast.py"), "--config",
+                        os.path.join(root, "config", "grpo.py") + ":" + preset, "--model", model, "--resolution", "256", "--layers", "2",
+                        "--batches", "1", "--epochs", "1", "--log", str(log)] + extra, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["phase"] == "G" and line["global_step"] == 1
+
+
 def test_bench_world_2_end_to_end_on_one_gpu():
     """The N > 1 branches of bench.py and of the Trainer, executed: two ranks under torch.distributed.run, the rank partition of the
     sampler, the packed reward all-gather, the scaling diagnostics (per-rank times, both collectives timed, the solo leg) and the epoch
