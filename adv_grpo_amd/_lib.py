@@ -102,6 +102,7 @@ SIGNATURES = {
     "advgrpo_cls_attention_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "advgrpo_cls_attention_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "advgrpo_clip_pair_loss": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
+    "advgrpo_clip_pair_loss_labels": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P, _P, _P]),
     "advgrpo_softmax_bwd_rows": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_float, _P]),
     "advgrpo_colsum_bf16": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
     "advgrpo_ln_affine_grads": (c_int, [_P, c_int64, _P, c_int64, c_int, c_int, c_float, _P, _P, _P]),

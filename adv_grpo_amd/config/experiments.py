@@ -61,6 +61,8 @@ EXPERIMENTS = {
         "wandb_init": True, "d_times": 10, "d_lr": 1e-4, "tune_layer": -2, "limit": None,
         "case_name": "fast_dino_cotrain_16_8_patch", "save_dir": "logs/dino/sd3.5-M-fast_dino_cotrain_16_8_patch",
         "reward_fn": {"dino_patch_cotrain": 1}, "eval_reward_fn": {"pickscore": 1, "image_similarity": 1}}),
+    # (kept because config/grpo.py ships it; its reward `dino_multi_cotrain` is NOT built -- rewards.multi_score raises a KeyError that says
+    #  why -- and the launcher refuses it before any model is built: see rewards._WHY_NOT)
     "dino_cotrain_sd3_multi_fast": (8, 8, {
         "wandb_init": False, "d_times": 10, "d_lr": 1e-4, "tune_layer": (11,), "temperature": 2,
         "case_name": "fast_dino_cotrain_multi", "save_dir": "logs/dino/sd3.5-M-fast_dino_cotrain_multi",

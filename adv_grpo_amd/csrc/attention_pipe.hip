@@ -38,7 +38,8 @@
 #include "attention.hpp"
 
 // timing-only ablations (scripts/ablate_attention.sh; results are WRONG with any bit set): 1 = no wait + barrier, 2 = v_exp ->
-// v_mul, 4 = no LDS fragment reads in the slots, 8 = no DMA, 16 = (unused), 32 = clock probe into lse[0..1], 64 = no row sums, 128 = never take the fallback
+// v_mul, 4 = no LDS fragment reads in the slots, 8 = no DMA, 16 = (unused), 32 = clock probe into lse[0..1], 64 = no row sums, 128 = never take the fallback,
+// 256 = seven s_memrealtime stamps + HW_ID of every workgroup's wave 0 into lse (as 8 x u64 per workgroup; scripts/probes/attn_stamps.py)
 #ifndef ATT_ABL
 #define ATT_ABL 0
 #endif
@@ -93,6 +94,9 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
     const int ql = lane & 31, hi = lane >> 5;
     [[maybe_unused]] unsigned long long clk0 = 0, rt0 = 0;
     if constexpr ((ATT_ABL & 32) != 0) { clk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    [[maybe_unused]] unsigned long long stamp[7];
+#define ATT_STAMP(i) if constexpr ((ATT_ABL & 256) != 0) { asm volatile("" ::: "memory"); stamp[i] = __builtin_amdgcn_s_memrealtime(); asm volatile("" ::: "memory"); }
+    ATT_STAMP(0)
     int qblk, h, b;
     xcd_local_bh(p.nqb, p.H, p.nwg, p.xcd_local, qblk, h, b);
     const int q0 = qblk * ATT_QB + wave * 32;
@@ -100,19 +104,7 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
     const bf16_t* kp = p.k + (int64_t)b * p.bsk + h * HD;
     const bf16_t* vp = p.v + (int64_t)b * p.bsv + h * HD;
 
-    // ---- Q fragments (B operand of K Q^T: lane = query, 8 consecutive d at ks*16 + hi*8), unscaled: the softmax scale is applied in f32
-    bf16x8_t qf[4];
-    {
-        int qr = q0 + ql;
-        qr = qr < p.Sq ? qr : p.Sq - 1;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8_t raw = *reinterpret_cast<const bf16x8_t*>(qp + (int64_t)qr * p.ldq + ks * 16 + hi * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qf[ks][e] = raw[e];
-        }
-    }
-
+    bf16x8_t qf[4];          // Q fragments: loaded in the prologue, behind the first DMA requests
     // ---- DMA sources.  Instruction jj (0..7) of a tile fills LDS rows 8 jj .. 8 jj + 7; this wave issues jj = wave, wave + 4.
     // Uniform (SGPR) tile base + 32-bit per-lane byte offset: the builtin form keeps a 64-bit pointer per lane and instruction.
     const int lrow = lane >> 3, pch = lane & 7;
@@ -205,20 +197,66 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
     const f32x2 c2 = {p.scale_log2e, p.scale_log2e};
     f32x2 nm2 = {0.f, 0.f};              // -m_ref twice: addend of the packed multiply-add in front of the exponentials
 
-    // the Q fragments must have arrived, in the compiler's own bookkeeping, before the first DMA is issued (its waits for them
-    // would otherwise sit behind the -- to it invisible -- DMA instructions and drain the ring)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[ks]));
+    // ---- a wave whose 32 queries all lie past the end of the sequence (the last query block of a (batch, head) when Sq is not a
+    // multiple of 128: wave 3 of every tenth workgroup at Sq = 1229) only keeps the workgroup's protocol -- its two DMA instructions per
+    // tile and every barrier -- and leaves its SIMD's matrix and vector issue slots to the two other workgroups resident there
+    if (q0 >= p.Sq) {
+        stage_k(0, 0);
+        if (nt > 1) stage_k(1, 1);
+        if (nt > 2) stage_k(2, 2);
+        stage_v(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int j = 0; j + 1 < nt; ++j) {
+            if (j + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (j + 3 < nt) stage_k(j % 3, j + 3);
+            if (j + 1 < nt) stage_v((j + 1) % 3, j + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                            // the tail's barrier
+        if (lane == 0) wg_flag[wave] = 0;
+        __syncthreads();
+        if ((ATT_ABL & 128) == 0 && (wg_flag[0] | wg_flag[1] | wg_flag[2] | wg_flag[3])) {      // the others take the fallback loop
+            for (int t = 0; t < nt; ++t) {
+                __builtin_amdgcn_s_barrier();
+                stage_k(0, t);
+                stage_v(0, t);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
 
     // ---- prologue: K0 | K1 | K2, V0 ; S_0 = K0 Q^T ; reference maximum = row maximum of tile 0
     stage_k(0, 0);
     if (nt > 1) stage_k(1, 1);
     if (nt > 2) stage_k(2, 2);
     stage_v(0, 0);
-    if (nt > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    ATT_STAMP(1)
+    // ---- Q fragments (B operand of K Q^T: lane = query, 8 consecutive d at ks*16 + hi*8), unscaled: the softmax scale is applied in f32.
+    // Requested BEHIND the first tiles' DMA (round 5; before: loaded and waited for in front of it, two memory latencies in a row -- 1.5 +
+    // 0.95 us of a workgroup's 31 us at 16 x 24 x 1229, scripts/probes/attn_stamps.py): memory operations of a wave complete in order, so
+    // the compiler's own wait for these four loads -- placed right here by the empty asm uses: left to itself it would sit in front of
+    // the first MFMA of some later slot and drain the ring there -- covers the older DMA requests as well.
+    {
+        int qr = q0 + ql;
+        qr = qr < p.Sq ? qr : p.Sq - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8_t raw = *reinterpret_cast<const bf16x8_t*>(qp + (int64_t)qr * p.ldq + ks * 16 + hi * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[ks][e] = raw[e];
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[ks]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    ATT_STAMP(2)
     f32x16 sA[2], sB[2];
     u32x4 pA[4], pB[4];
     sA[0] = zero16; sA[1] = zero16;
@@ -289,6 +327,7 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
     };
     m_ref = row_max(sA) * p.scale_log2e;      // (a row of tile 0 always holds a real key: finite)
     nm2 = f32x2{-m_ref, -m_ref};
+    ATT_STAMP(3)
 
     // One steady-state iteration j (0 <= j <= nt - 2), j = PH (mod 3): probabilities of tile j (raw scores sc -> pn), Q K^T
     // of tile j + 1 into sn, P V of tile j - 1 (probabilities pp).  16 MFMA slots: 0..7 = Q K^T (key blocks alternate, so no MFMA
@@ -382,12 +421,37 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
     // now: the last tile's raw scores in sB, the probabilities of tile nt - 2 (if any) in pA
 
     // ---- tail: P V of tile nt - 2, probabilities of the (possibly ragged) last tile, its P V
+    ATT_STAMP(4)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (nt > 1) tile_pv((3 + (nt - 2) % 3) * TILE_B, pA);
     mask_tail(sB, (nt - 1) * ATT_KB);
-    tile_probs(sB, pB);
-    tile_pv((3 + (nt - 1) % 3) * TILE_B, pB);
+    {
+        // a ragged last tile only pays for the 16-key steps that hold real keys (13 of 64 at Skv = 1229: one step -- 4 of the 16 score
+        // pairs, 2 of the 8 products; the masked scores would have come out as exact zeros: same sums, same bits)
+        const int steps = (p.Skv - (nt - 1) * ATT_KB + 15) >> 4;         // 1 .. 4, uniform
+        const int vt = (3 + (nt - 1) % 3) * TILE_B;
+        if (steps >= 4) {
+            tile_probs(sB, pB);
+            tile_pv(vt, pB);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                if (kk < steps) {
+#pragma unroll
+                    for (int i = 4 * kk; i < 4 * kk + 4; ++i) {
+                        const f32x2 e = pair_exp(pair_x(sB, i));
+                        pB[kk][i & 3] = att_cvt_pk(e[0], e[1]);
+                        lsum[i & 1] += e;
+                    }
+                    const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pB[kk]);
+                    o[0] = ATT_MFMA32(vfrag(vt + kk * 2048, 0), pb, o[0]);
+                    o[1] = ATT_MFMA32(vfrag(vt + kk * 2048, 1), pb, o[1]);
+                }
+            }
+        }
+    }
+    ATT_STAMP(5)
 
     // ---- the window check.  Every probability was taken relative to the row maximum of tile 0 and nothing was rescaled
     // on the way: exact as long as no 2^(s - m_ref) left the f32 / bf16 exponent range.  A row sum that is zero, huge or
@@ -448,7 +512,7 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
     }
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     const int qi = q0 + ql;
-    if ((ATT_ABL & 32) == 0 && p.lse && hi == 0 && qi < p.Sq) p.lse[((int64_t)b * p.H + h) * p.Sq + qi] = m_ref + __builtin_amdgcn_logf(l);
+    if ((ATT_ABL & (32 | 256)) == 0 && p.lse && hi == 0 && qi < p.Sq) p.lse[((int64_t)b * p.H + h) * p.Sq + qi] = m_ref + __builtin_amdgcn_logf(l);
     char* ob = Kr + wave * 4096;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -467,6 +531,17 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
         const uint4 v = *reinterpret_cast<const uint4*>(ob + r * 128 + ((c ^ (r & 7)) << 4));
         const int qo = q0 + r;
         if (qo < p.Sq) *reinterpret_cast<uint4*>(p.o + (int64_t)b * p.bso + (int64_t)qo * p.ldo + h * HD + c * 8) = v;
+    }
+    if constexpr ((ATT_ABL & 256) != 0) {
+        ATT_STAMP(6)
+        if (tid == 0 && p.lse) {
+            unsigned long long* dst = (unsigned long long*)p.lse + (size_t)blockIdx.x * 8;
+            for (int i = 0; i < 7; ++i) dst[i] = stamp[i];
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            dst[7] = ((unsigned long long)xcc << 32) | hw;
+        }
     }
 }
 

@@ -102,8 +102,13 @@ __global__ __launch_bounds__(64) void cls_attention_bwd_kernel(const bf16_t* __r
 
 // e: [2B, P] image embeddings (real rows first), t: [B, P] text embeddings, both un-normalised bf16.
 // loss = mean_i softplus(s * (t^_i . e^1_i - t^_i . e^0_i)); de = d loss / d e (bf16).  One wave per pair.
+// With per-pair labels (CLIPCriterion.calc_loss, pick_score_training.py:172-186, in_batch_negatives = False): z = s (cos1 - cos0),
+// loss_i = label_0 softplus(z) + label_1 softplus(-z) + [label_0 == label_1] log(0.5); lab0 == nullptr means (1, 0), the only pair
+// the reference's caller passes (TP:170-171).
 __global__ __launch_bounds__(64) void clip_pair_loss_kernel(const bf16_t* __restrict__ e, const bf16_t* __restrict__ t, int B,
-                                                            int P, float s, float* __restrict__ loss, bf16_t* __restrict__ de) {
+                                                            int P, float s, const float* __restrict__ lab0,
+                                                            const float* __restrict__ lab1, float* __restrict__ loss,
+                                                            bf16_t* __restrict__ de) {
     const int i = blockIdx.x, lane = threadIdx.x;
     const bf16_t* e0 = e + (int64_t)i * P;
     const bf16_t* e1 = e + (int64_t)(B + i) * P;
@@ -119,8 +124,15 @@ __global__ __launch_bounds__(64) void clip_pair_loss_kernel(const bf16_t* __rest
     const float z = s * (d1 - d0);
     const float sp = z > 20.f ? z : log1pf(__expf(z));
     const float sig = 1.0f / (1.0f + __expf(-z));
-    if (lane == 0) atomicAdd(loss, sp / (float)B);
-    const float g = sig * s / (float)B;              // d loss / d cos1 ; d loss / d cos0 = -g
+    float li = sp, gz = sig;
+    if (lab0) {
+        const float l0 = lab0[i], l1 = lab1[i];
+        const float spn = -z > 20.f ? -z : log1pf(__expf(-z));          // softplus(-z): cross entropy against image 1
+        li = l0 * sp + l1 * spn + (l0 == l1 ? -0.6931471805599453f : 0.f);
+        gz = l0 * sig - l1 * (1.0f - sig);
+    }
+    if (lane == 0) atomicAdd(loss, li / (float)B);
+    const float g = gz * s / (float)B;               // d loss / d cos1 ; d loss / d cos0 = -g
     for (int k = lane; k < P; k += 64) {
         const float a = bf2f(e0[k]) / n0, c = bf2f(e1[k]) / n1, u = bf2f(ti[k]) / nt;
         // d cos / d e = (t^ - e^ cos) / |e|
@@ -190,7 +202,20 @@ extern "C" int advgrpo_clip_pair_loss(const void* image_embs, const void* text_e
     hipStream_t s = as_stream(stream);
     if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) { set_error("clip_pair_loss: memset failed"); return -2; }
     hipLaunchKernelGGL(clip_pair_loss_kernel, dim3(B), dim3(64), 0, s, (const bf16_t*)image_embs, (const bf16_t*)text_embs,
-                       B, P, logit_scale_exp, loss, (bf16_t*)d_image_embs);
+                       B, P, logit_scale_exp, (const float*)nullptr, (const float*)nullptr, loss, (bf16_t*)d_image_embs);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int advgrpo_clip_pair_loss_labels(const void* image_embs, const void* text_embs, int B, int P, float logit_scale_exp,
+                                             const float* label_0, const float* label_1, float* loss, void* d_image_embs,
+                                             void* stream) {
+    ADVGRPO_CHECK(image_embs && text_embs && loss && d_image_embs && B > 0 && P > 0, "clip_pair_loss_labels: bad argument");
+    ADVGRPO_CHECK((label_0 == nullptr) == (label_1 == nullptr), "clip_pair_loss_labels: label_0 and label_1 come as a pair");
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) { set_error("clip_pair_loss_labels: memset failed"); return -2; }
+    hipLaunchKernelGGL(clip_pair_loss_kernel, dim3(B), dim3(64), 0, s, (const bf16_t*)image_embs, (const bf16_t*)text_embs,
+                       B, P, logit_scale_exp, label_0, label_1, loss, (bf16_t*)d_image_embs);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

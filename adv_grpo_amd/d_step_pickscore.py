@@ -46,6 +46,7 @@ class ClipLastLayerTrainable:
         self.exp_avg_sq = torch.zeros_like(self.params)
         self.opt_step = 0
         self.layer = L
+        clip_model.trainable = self                # what CLIPCriterion(model, batch) finds when handed scorer.model (TP:177)
 
     def view(self, src, k):
         a, b = self.offs[k]
@@ -53,8 +54,9 @@ class ClipLastLayerTrainable:
 
     # ------------------------------------------------------------------ forward/backward of the criterion
     @torch.no_grad()
-    def loss_and_grads(self, pixel_patches, input_ids):
-        """pixel_patches: [2B*256, 640] patch rows of (real images, then fake images); input_ids [B,77].
+    def loss_and_grads(self, pixel_patches, input_ids, labels=None):
+        """pixel_patches: [2B*256, 640] patch rows of (real images, then fake images); input_ids [B,77]; labels: None for
+        (label_0, label_1) = (1, 0) (TP:170-171) or a pair of device f32 [B] vectors (CLIPCriterion's batch labels).
         Accumulates grads; returns the loss (device scalar)."""
         lib = _lib.load()
         m, cfg, L = self.m, self.cfg, self.layer
@@ -96,8 +98,9 @@ class ClipLastLayerTrainable:
         # ---- criterion + gradient w.r.t. e
         loss = torch.empty(1, dtype=f32, device=dev)
         de = torch.empty_like(e)
-        _lib.check(lib.advgrpo_clip_pair_loss(e.data_ptr(), text.data_ptr(), B, e.shape[1], float(m.logit_scale.exp()),
-                                              loss.data_ptr(), de.data_ptr(), _lib.stream_ptr()))
+        l0, l1 = labels if labels is not None else (None, None)
+        _lib.check(lib.advgrpo_clip_pair_loss_labels(e.data_ptr(), text.data_ptr(), B, e.shape[1], float(m.logit_scale.exp()),
+                                                     _lib.ptr(l0), _lib.ptr(l1), loss.data_ptr(), de.data_ptr(), _lib.stream_ptr()))
         # ---- backward
         g = lambda k: self.view(self.grads, k)
         T = ops.transpose
@@ -178,6 +181,7 @@ class ClipLayersTrainable(ClipLastLayerTrainable):
         self.exp_avg_sq = torch.zeros_like(self.params)
         self.opt_step = 0
         self.layers = layers
+        clip_model.trainable = self
 
     # ------------------------------------------------------------------ attention backward, materialised (S = 257, head dim 80)
     def _attention_bwd(self, qkv, d_o, Bt, S, H, hd):
@@ -209,7 +213,7 @@ class ClipLayersTrainable(ClipLastLayerTrainable):
         return dqkv
 
     @torch.no_grad()
-    def loss_and_grads(self, pixel_patches, input_ids):
+    def loss_and_grads(self, pixel_patches, input_ids, labels=None):
         lib = _lib.load()
         m, cfg = self.m, self.cfg
         P = (cfg.image_size // cfg.patch) ** 2
@@ -251,8 +255,9 @@ class ClipLayersTrainable(ClipLastLayerTrainable):
         e = ops.gemm(pooled, m.v_proj)
         loss = torch.empty(1, dtype=f32, device=dev)
         de = torch.empty_like(e)
-        _lib.check(lib.advgrpo_clip_pair_loss(e.data_ptr(), text.data_ptr(), B, e.shape[1], float(m.logit_scale.exp()),
-                                              loss.data_ptr(), de.data_ptr(), _lib.stream_ptr()))
+        l0, l1 = labels if labels is not None else (None, None)
+        _lib.check(lib.advgrpo_clip_pair_loss_labels(e.data_ptr(), text.data_ptr(), B, e.shape[1], float(m.logit_scale.exp()),
+                                                     _lib.ptr(l0), _lib.ptr(l1), loss.data_ptr(), de.data_ptr(), _lib.stream_ptr()))
         # ---- backward
         T = ops.transpose
         colsum = lambda t, out: _lib.check(lib.advgrpo_colsum_bf16(t.data_ptr(), t.stride(0), t.shape[0], t.shape[1],

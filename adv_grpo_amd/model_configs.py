@@ -51,6 +51,35 @@ class ClipConfig:  # yuvalkirstain/PickScore_v1 = CLIP ViT-H/14
 
 
 @dataclass
+class ClipTextConfig:  # SD3's text_encoder (CLIP ViT-L/14 text tower, the defaults) / text_encoder_2 (OpenCLIP bigG: ClipTextConfig.bigg())
+    hidden: int = 768
+    layers: int = 12
+    heads: int = 12
+    mlp: int = 3072
+    proj: int = 768
+    vocab: int = 49408
+    max_pos: int = 77
+    act: str = "quick_gelu"
+    eos_token_id: int = 2          # the released config.json says 2; pooling then takes argmax(input_ids) (text_encoders.py)
+
+    @classmethod
+    def bigg(cls):
+        return cls(hidden=1280, layers=32, heads=20, mlp=5120, proj=1280, act="gelu")
+
+
+@dataclass
+class T5Config:  # SD3's text_encoder_3: google/t5-v1_1-xxl encoder
+    d_model: int = 4096
+    layers: int = 24
+    heads: int = 64
+    d_kv: int = 64
+    d_ff: int = 10240
+    vocab: int = 32128
+    num_buckets: int = 32
+    max_distance: int = 128
+
+
+@dataclass
 class DinoConfig:  # timm vit_base_patch14_dinov2.lvd142m
     hidden: int = 768
     layers: int = 12

@@ -16,6 +16,12 @@ from . import vit
 _OUT_OF_SCOPE = ("deqa", "video_ocr", "imagereward", "qwenvl", "aesthetic", "jpeg_compressibility", "unifiedreward",
                  "geneval", "clipscore", "image_similarity_eval", "constractive_external", "discriminator",
                  "pickscore_patch", "dino_multi_cotrain", "siglip_cotrain", "siglip_image_similarity")
+# scorers a shipped experiment of config/grpo.py names although they are outside SURVEY.md 8's six: why, per name
+_WHY_NOT = {
+    "dino_multi_cotrain": "the multi-layer DINOv2 fusion scorer (adv_grpo/rewards.py:1032, config/grpo.py `dino_cotrain_sd3_multi_fast`, tune_layer = (11,), "
+                          "temperature 2) has no trainer among the two shipped hot loops (train_sd3_fast_{pickscore,dino_patch}.py index "
+                          "rewards['pickscore_cotrain' | 'dino_patch_cotrain'] only) and is not one of SURVEY.md 8's six scorers: not built",
+}
 
 class PromptBatch(list):
     """The ``prompts`` argument of the scorer plugins when both faces of a prompt are needed: a list of the prompt STRINGS
@@ -167,8 +173,9 @@ def multi_score(device, score_dict):
     for name in score_dict:
         if name not in score_functions:
             if name in _OUT_OF_SCOPE:
-                raise KeyError(f"scorer '{name}' is outside the accelerated hot path (SURVEY.md section 2.1 row 5); "
-                               "register a host implementation with rewards.register_scorer")
+                raise KeyError(f"scorer '{name}' is outside the accelerated hot path (SURVEY.md section 2.1 row 5)"
+                               + (f": {_WHY_NOT[name]}" if name in _WHY_NOT else "") +
+                               "; register a host implementation with rewards.register_scorer")
             raise KeyError(name)
         fac = score_functions[name]
         score_fns[name] = fac(device) if "device" in inspect.signature(fac).parameters else fac()

@@ -32,12 +32,28 @@ class on_device:
         _DEVICE = self.prev
 
 
+class _ShapeOnly:
+    """Stand-in generator of the "meta" device: the builders then produce tensors with shapes and no storage."""
+    device = torch.device("meta")
+
+
 def _gen(seed):
+    if str(_DEVICE) == "meta":
+        return _ShapeOnly()
     return torch.Generator(device=_DEVICE).manual_seed(seed)
 
 
 def _randn(*shape, generator):
+    if generator.device.type == "meta":
+        return torch.empty(*shape, device="meta")
     return torch.randn(*shape, generator=generator, device=generator.device)
+
+
+def shapes(builder, *args, **kwargs):
+    """{key: shape} of what ``builder(*args, **kwargs)`` (one of the *_weights functions below) would create, without creating it:
+    the architecture's state-dict layout as a checklist (adv_grpo_amd/hub.py validates checkpoints against it)."""
+    with on_device("meta"):
+        return {k: tuple(v.shape) for k, v in builder(*args, **kwargs).items()}
 
 
 def linear_(W, name, out_f, in_f, g, bias=True, std=None):
@@ -244,6 +260,45 @@ def qwen_vae_decoder_weights(cfg, seed=2468, dtype=None):
     conv3d("decoder.conv_out", 3, d[-1], 3)
     if dtype is not None:
         W = {k: v.to(dtype).float() for k, v in W.items()}
+    return W
+
+
+def clip_text_weights(cfg, seed=555):
+    """fp32 weights keyed like transformers CLIPTextModelWithProjection.state_dict() (SD3's text_encoder / text_encoder_2)."""
+    g = _gen(seed)
+    D = cfg.hidden
+    W = {"text_model.embeddings.token_embedding.weight": _randn(cfg.vocab, D, generator=g) * 0.5,
+         "text_model.embeddings.position_embedding.weight": _randn(cfg.max_pos, D, generator=g) * 0.1}
+    for i in range(cfg.layers):
+        p = f"text_model.encoder.layers.{i}"
+        _ln(W, f"{p}.layer_norm1", D, g); _ln(W, f"{p}.layer_norm2", D, g)
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            linear_(W, f"{p}.self_attn.{nm}", D, D, g)
+        linear_(W, f"{p}.mlp.fc1", cfg.mlp, D, g)
+        linear_(W, f"{p}.mlp.fc2", D, cfg.mlp, g)
+    _ln(W, "text_model.final_layer_norm", D, g)
+    linear_(W, "text_projection", cfg.proj, D, g, bias=False)
+    return W
+
+
+def t5_encoder_weights(cfg, seed=666):
+    """fp32 weights keyed like transformers T5EncoderModel.state_dict() (T5 v1.1: gated GELU, no biases; SD3's text_encoder_3).
+    ``encoder.embed_tokens.weight`` is the tied copy of ``shared.weight`` a checkpoint may or may not carry: not listed."""
+    g = _gen(seed)
+    D, inner = cfg.d_model, cfg.heads * cfg.d_kv
+    W = {"shared.weight": _randn(cfg.vocab, D, generator=g),
+         "encoder.final_layer_norm.weight": 1 + 0.1 * _randn(D, generator=g),
+         "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight": _randn(cfg.num_buckets, cfg.heads, generator=g)}
+    for i in range(cfg.layers):
+        p = f"encoder.block.{i}.layer"
+        W[f"{p}.0.layer_norm.weight"] = 1 + 0.1 * _randn(D, generator=g)
+        W[f"{p}.1.layer_norm.weight"] = 1 + 0.1 * _randn(D, generator=g)
+        for n in ("q", "k", "v"):
+            W[f"{p}.0.SelfAttention.{n}.weight"] = _randn(inner, D, generator=g) * ((D * cfg.d_kv) ** -0.5 if n == "q" else D ** -0.5)
+        W[f"{p}.0.SelfAttention.o.weight"] = _randn(D, inner, generator=g) * inner ** -0.5
+        W[f"{p}.1.DenseReluDense.wi_0.weight"] = _randn(cfg.d_ff, D, generator=g) * D ** -0.5
+        W[f"{p}.1.DenseReluDense.wi_1.weight"] = _randn(cfg.d_ff, D, generator=g) * D ** -0.5
+        W[f"{p}.1.DenseReluDense.wo.weight"] = _randn(D, cfg.d_ff, generator=g) * cfg.d_ff ** -0.5
     return W
 
 

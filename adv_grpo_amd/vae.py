@@ -132,6 +132,20 @@ class AutoencoderKLDecoder:
             pre = k[:-len(".conv_shortcut.bias")]
             w[pre + ".conv2.bias"] = w[pre + ".conv2.bias"] + w[k]
 
+    def arithmetic(self):
+        """What the 3x3 convolutions of this decoder instance run on, as decided per weight tensor at load time:
+        {"f16x2": n, "bf16x3": n, "bf16": n, "total": n, "text": "f16x2 (31/33 convs), bf16x3 (2/33)"} (bench.py prints it)."""
+        if self.mode == "bf16":
+            n = sum(1 for k, v in self.w.items() if k.endswith(".weight") and ".conv" in k and "shortcut" not in k and v.dim() == 2 and
+                    v.shape[1] % 9 == 0 and "to_" not in k)
+            return {"f16x2": 0, "bf16x3": 0, "bf16": n, "total": n, "text": f"bf16 ({n}/{n} convs)"}
+        f16 = sum(1 for k in self.w if k.endswith(".weight@f16"))
+        x3 = sum(1 for k, v in self.w.items() if k.endswith(".weight") and v.dim() == 2 and ("conv_in" in k or "conv_out" in k or ".conv1." in k or
+                                                                                            ".conv2." in k or ".upsamplers." in k))
+        tot = f16 + x3
+        parts = [f"{name} ({n}/{tot}{' convs' if i == 0 else ''})" for i, (name, n) in enumerate(p for p in (("f16x2", f16), ("bf16x3", x3)) if p[1])]
+        return {"f16x2": f16, "bf16x3": x3, "bf16": 0, "total": tot, "text": ", ".join(parts)}
+
     def _conv3(self, name, x3, **kw):
         return ops.conv3x3_x3(x3, self.w[name + ".weight"], bias=self.w[name + ".bias"], **kw)
 

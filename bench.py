@@ -664,6 +664,21 @@ def main():
             torch.cuda.synchronize()
             vae_ms[mode] = (time.perf_counter() - tv) / 3 * 1e3
             del dec
+        # the same fp32-equivalent decode when the checkpoint's weights are NOT exact in fp16 (every convolution then takes the three
+        # split-bf16 products): the timed decoder assumes the released SD3 / SD3.5 VAE, an fp16 checkpoint upcast at TP:481
+        vae_ran = pipe.vae.arithmetic()["text"] if hasattr(pipe.vae, "arithmetic") else pipe.vae.mode
+        if not c5 and pipe.vae.mode == "bf16x3" and not args.no_pricing:
+            with synthetic.on_device(device):
+                dec = AutoencoderKLDecoder(synthetic.vae_decoder_weights(pipe.vae.cfg, 4321, fp16_checkpoint=False), pipe.vae.cfg, device, mode="bf16x3")
+            assert dec.arithmetic()["f16x2"] == 0
+            dec.decode_to_image(lat)
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(3):
+                dec.decode_to_image(lat)
+            torch.cuda.synchronize()
+            vae_ms["bf16x3_every_conv"] = (time.perf_counter() - tv) / 3 * 1e3
+            del dec
         step_ms = dt / args.steps * 1e3
         # the rollout with PEFT's LoRA arithmetic (side path as a K-extension of the adapted Linears, mmdit_train.py) instead
         # of LoRA merged into the bf16 weights: same step, other transformer object
@@ -766,10 +781,11 @@ def main():
                                     "the SD3 sigma table (shift 3), VAE decode (" + pipe.vae.mode + ") with Qwen-Image's own decoder (AutoencoderKLQwenImage on one "
                                     "frame: widths 384 / 192 / 96, per-pixel RMS norm), DINOv2-B/14 patch reward + head (RW:375-434), reward all-gather + group advantage")
                                    if c5 else (("BASELINE config 4 shapes: SD3.5-large (38 blocks, D=2432) LoRA-merged 1024x1024, 10 steps, CFG 4.5, "
-                                    "G=4, SDE window 2 @ noise 0.8, VAE decode (" + pipe.vae.mode + "), fp32-equivalent PickScore reward (the OCR half of the reward is a "
-                                    "host plugin outside the timed path), reward all-gather + group advantage") if c4 else
+                                    "G=4, SDE window 2 @ noise 0.8, VAE decode (fp32-equivalent; 3x3 convolutions: " + vae_ran + "), fp32-equivalent PickScore reward (ocr: stand-in "
+                                    "recogniser -- no PaddleOCR in this image, the OCR half of the reward is a constant and its host-side recognition costs nothing here), "
+                                    "reward all-gather + group advantage") if c4 else
                                    ("BASELINE config " + ("3" if c3 else "2") + ": SD3.5-medium LoRA-merged 512x512, 10 steps, CFG 4.5, G=8, "
-                                    "SDE window 2 @ noise 0.8, VAE decode (" + pipe.vae.mode + "), " +
+                                    "SDE window 2 @ noise 0.8, VAE decode (fp32-equivalent; 3x3 convolutions: " + vae_ran + "), " +
                                     ("co-trained DINOv2 ViT-B/14 @ 518 patch discriminator + head as reward (RW:375-434)" if c3 else
                                      "PickScore (CLIP ViT-H/14) reward") + ", reward all-gather + group advantage")), "global_batch": world * G,
                        "transformer_batch_per_gpu": 2 * G, "parallelism": f"dp{world} (prompt groups sharded)"},
@@ -780,10 +796,21 @@ def main():
                                  "time at those peaks / measured time"} if c5 else {}),
             "roofline": roofline,
             "vae": {"mode": pipe.vae.mode,
+                    "mode_ran": vae_ran,
+                    "assumption": None if c5 else "the released SD3 / SD3.5 VAE is an fp16 checkpoint, upcast by vae.to(torch.float32) (TP:447,481): a 3x3 convolution whose "
+                                  "weight tensor is exact in fp16 (checked per tensor at load time) runs as two fp16 products per f32 product (f16x2), the others "
+                                  "as three bf16 products (bf16x3); synthetic weights are rounded through fp16 to model that checkpoint",
                     "modes": {"bf16": "bf16 operands and activations, f32 accumulate",
-                              "bf16x3": "split-bf16 (hi+lo) operands, 3 MFMA products per f32 product, f32 between kernels: "
-                                        "image within 3e-5 of the fp32 decode (tests/test_gpu_vae.py)"},
+                              "bf16x3": "the fp32-equivalent decoder: f32 between kernels; per 3x3 convolution either f16x2 (fp16-exact weight: activations as an "
+                                        "fp16 hi+lo pair, 2 MFMA products per f32 product) or bf16x3 (split-bf16 hi+lo operands, 3 MFMA products); image within "
+                                        "3e-5 of the fp32 decode either way (tests/test_gpu_vae.py)",
+                              "bf16x3_every_conv": "the same decoder on weights that are NOT exact in fp16: every 3x3 convolution on three bf16 products"},
                     "ms_per_group_decode": {k: round(v, 2) for k, v in vae_ms.items()},
+                    "value_if_weights_not_fp16_exact": round(images / (dt + args.steps * (vae_ms["bf16x3_every_conv"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)
+                    if "bf16x3_every_conv" in vae_ms else None,
+                    "frac_of_bf16_mfma_peak_if_weights_not_fp16_exact":
+                        round(per_image_tflop * images / (dt + args.steps * (vae_ms["bf16x3_every_conv"] - vae_ms[pipe.vae.mode]) * 1e-3) / world / BF16_DENSE_PEAK_TFLOPS, 4)
+                        if "bf16x3_every_conv" in vae_ms else None,
                     "share_of_step_time": round(vae_ms[pipe.vae.mode] / step_ms, 4),
                     # what the headline would be with the other decoder swapped in (only the decode time changes)
                     "value_if_bf16x3": round(images / (dt + args.steps * (vae_ms["bf16x3"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)
@@ -794,6 +821,8 @@ def main():
             "clock_and_power": power.summary(),
             "overlap": overlap,
             "fp8_linears": fp8,
+            **({"ocr": "stand-in recogniser (constant reward half): PaddleOCR is not in this image, adv_grpo_amd.ocr.OcrScorer runs with a callable that "
+                       "returns a fixed string, so half of config 4's reward is a constant and the recognition phase costs nothing in this line"} if c4 else {}),
             **({"bf16_linears": bf16_linears, "text_tower": text_tower} if c5 else {}),
             "lora": None if c5 else {"mode": "merged",
                      "modes": {"merged": "W_eff = bf16(W + s B A) in the rollout and training forward (the timed configuration)",

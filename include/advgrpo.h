@@ -516,6 +516,11 @@ int advgrpo_cls_attention_bwd(const void* qkv, const float* probs, const void* d
  * w.r.t. the un-normalised image embeddings e [2B,P]; == CLIPCriterion.calc_loss with label_0 = 1, label_1 = 0. */
 int advgrpo_clip_pair_loss(const void* image_embs, const void* text_embs, int B, int P, float logit_scale_exp,
                            float* loss, void* d_image_embs, void* stream);
+/* The same criterion with the batch's labels (CLIPCriterion.forward, adv_grpo/pick_score_training.py:205-224 -> calc_loss :118-199,
+ * in_batch_negatives = False): label_0 / label_1 device f32 [B] (a 0-dim label of the reference broadcast by the caller), or both NULL
+ * for (1, 0).  loss = mean_i label_0 softplus(z_i) + label_1 softplus(-z_i) + [label_0 == label_1] log(0.5), z = s (cos(t, e1) - cos(t, e0)). */
+int advgrpo_clip_pair_loss_labels(const void* image_embs, const void* text_embs, int B, int P, float logit_scale_exp,
+                                  const float* label_0, const float* label_1, float* loss, void* d_image_embs, void* stream);
 /* tune_layer = -k, k > 1 (TP:1016-1020): softmax forward + backward over materialised attention-score rows of the trainable CLIP layers
  * (autograd of F.scaled_dot_product_attention inside CLIPModel.vision_model, reached from train_pickscore TP:151-183): sc / dp f32 [rows, n]
  * (scaled scores, dO V^T) -> p16 = softmax over the first n_valid columns, ds16 = scale * P (dP - sum P dP), bf16; padding rows (query

@@ -6,8 +6,12 @@
          --linear-dtype fp8 --images-per-prompt 8 --batches 1          (BASELINE config 5)
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_sd3_fast.py --config ...
 
-No checkpoints / tokenizers / reference images exist on this platform: models get seeded synthetic weights of the
-real architecture and data comes from trainer.SyntheticData."""
+  python scripts/train_sd3_fast.py --config ... --weights <local snapshot of config.pretrained.model> \
+         --pickscore-weights <PickScore_v1 dir> | --dino-weights <timm vit_base_patch14_dinov2 dir>      (real checkpoints, adv_grpo_amd/hub.py)
+
+No checkpoints / tokenizers / reference images exist on this platform: without --weights the models get seeded synthetic weights of the
+real architecture and data comes from trainer.SyntheticData.  With --weights every component's config.json and every tensor
+name / shape is validated against the architecture before anything is loaded (a mismatch is an error, hub.HubError)."""
 import argparse
 import json
 import os
@@ -44,15 +48,25 @@ def main():
                          "stabilityai/stable-diffusion-3.5-large (BASELINE config 4) or Qwen/Qwen-Image (BASELINE config 5: Qwen-Image MMDiT with "
                          "LoRA + per-block recomputation, Qwen-Image VAE decoder, 3584-wide prompt states)")
     ap.add_argument("--resolution", type=int, default=None, help="override config.resolution (config/grpo.py:330)")
+    ap.add_argument("--weights", default=None,
+                    help="local Hugging Face snapshot directory of config.pretrained.model (model_index.json, transformer/, vae/, ...): what "
+                         "StableDiffusion3Pipeline.from_pretrained (TP:447-449) would have downloaded; validated and loaded by adv_grpo_amd/hub.py")
+    ap.add_argument("--pickscore-weights", default=None, help="local directory of yuvalkirstain/PickScore_v1 (a transformers CLIPModel; pickscore_scorer.py:8-14)")
+    ap.add_argument("--dino-weights", default=None, help="local timm directory of vit_base_patch14_dinov2.lvd142m (TD:589)")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    from adv_grpo_amd.config.experiments import parse_config_flag
+    cfg = parse_config_flag(args.config, gpu_number=world)
+    from adv_grpo_amd import rewards as _rw                      # (before any device is touched: a refused experiment costs nothing)
+    for rname in list(cfg.reward_fn.keys()):
+        if rname in _rw._OUT_OF_SCOPE:
+            raise SystemExit(f"{args.config}: reward '{rname}': " + _rw._WHY_NOT.get(rname, "outside the accelerated hot path (SURVEY.md 2.1 row 5)"))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
     from adv_grpo_amd import synthetic, vit
-    from adv_grpo_amd.config.experiments import parse_config_flag
     from adv_grpo_amd.d_step import DinoHeadTrainable
     from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
     from adv_grpo_amd.model_configs import ClipConfig, DinoConfig, MMDiTConfig, VaeConfig
@@ -60,7 +74,6 @@ def main():
     from adv_grpo_amd.pipeline import SD3Pipeline
     from adv_grpo_amd.trainer import SyntheticData, Trainer
     from adv_grpo_amd.vae import AutoencoderKLDecoder
-    cfg = parse_config_flag(args.config, gpu_number=world)
     if args.images_per_prompt:
         cfg.sample.num_image_per_prompt = args.images_per_prompt
         cfg.sample.mini_num_image_per_prompt = min(cfg.sample.mini_num_image_per_prompt, args.images_per_prompt)     # G = 4 (config 4)
@@ -77,6 +90,18 @@ def main():
         cfg.resolution = args.resolution
     name = str(cfg.pretrained.model).lower()
     qwen, large = "qwen" in name, "3.5-large" in name
+    snap = None
+    if args.weights is None and os.path.isdir(str(cfg.pretrained.model)):          # from_pretrained(<local directory>), TP:447-449
+        args.weights = str(cfg.pretrained.model)
+    if args.weights:
+        from adv_grpo_amd import hub
+        snap = hub.load_pipeline(args.weights)
+        if args.weights == str(cfg.pretrained.model):
+            qwen = snap["kind"] == "qwen"
+        if (snap["kind"] == "qwen") != qwen:
+            raise SystemExit(f"--weights {args.weights} holds a {snap['kind']} pipeline but config.pretrained.model is {cfg.pretrained.model!r}")
+        if args.layers is not None:
+            raise SystemExit("--layers reduces the depth of a synthetic model; a checkpoint is loaded as it is")
     if qwen and args.lora_mode != "merged":
         raise SystemExit("Qwen-Image: --lora-mode merged only")
     mcfg = MMDiTConfig(num_layers=38, num_heads=38, dual_attention_layers=(), pos_embed_max_size=192) if large else MMDiTConfig()
@@ -89,18 +114,32 @@ def main():
             from adv_grpo_amd.qwen_mmdit_train import QwenImageTransformerLoRA
             from adv_grpo_amd.qwen_vae import AutoencoderKLQwenImageDecoder
             qcfg = QwenMMDiTConfig() if args.layers is None else QwenMMDiTConfig(num_layers=args.layers)
-            tr = QwenImageTransformerLoRA(synthetic.qwen_mmdit_weights(qcfg, 4242, dtype=torch.bfloat16), qcfg, device, seed=cfg.seed)
-            vae = AutoencoderKLQwenImageDecoder(synthetic.qwen_vae_decoder_weights(QwenVaeConfig(), 2468, dtype=torch.bfloat16), QwenVaeConfig(),
-                                                device, mode=args.vae_mode)
+            tw, qcfg = snap["transformer"] if snap else (synthetic.qwen_mmdit_weights(qcfg, 4242, dtype=torch.bfloat16), qcfg)
+            vw, vcfg = snap["vae"] if snap else (synthetic.qwen_vae_decoder_weights(QwenVaeConfig(), 2468, dtype=torch.bfloat16), QwenVaeConfig())
+            tr = QwenImageTransformerLoRA(tw, qcfg, device, seed=cfg.seed)
+            vae = AutoencoderKLQwenImageDecoder(vw, vcfg, device, mode=args.vae_mode)
         else:
-            tr = SD3TransformerLoRA(synthetic.mmdit_weights(mcfg, 1234), mcfg, device, seed=cfg.seed, lora_mode=args.lora_mode)
-            vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 4321, fp16_checkpoint=True), VaeConfig(), device, mode=args.vae_mode)
+            tw, mcfg = snap["transformer"] if snap else (synthetic.mmdit_weights(mcfg, 1234), mcfg)
+            vw, vcfg = snap["vae"] if snap else (synthetic.vae_decoder_weights(VaeConfig(), 4321, fp16_checkpoint=True), VaeConfig())
+            tr = SD3TransformerLoRA(tw, mcfg, device, seed=cfg.seed, lora_mode=args.lora_mode)
+            vae = AutoencoderKLDecoder(vw, vcfg, device, mode=args.vae_mode)
+        snap = None                                              # the host copies of a 2 - 20 B parameter checkpoint are not kept
         head = None
         if any(k.startswith("dino") for k in cfg.reward_fn.keys()):
-            scorer = vit.DinoV2(synthetic.dino_weights(DinoConfig(), 888), DinoConfig(), device)
+            if args.dino_weights:
+                from adv_grpo_amd import hub
+                dw, dcfg = hub.load_timm_dinov2(args.dino_weights)
+            else:
+                dw, dcfg = synthetic.dino_weights(DinoConfig(), 888), DinoConfig()
+            scorer = vit.DinoV2(dw, dcfg, device)
             head = DinoHeadTrainable(device=device, seed=cfg.seed)
         else:
-            scorer = PickScoreScorer(device, dtype=torch.bfloat16, model_sd=synthetic.clip_weights(ClipConfig(), 777), clip_cfg=ClipConfig())
+            if args.pickscore_weights:
+                from adv_grpo_amd import hub
+                pw, pcfg = hub.load_pickscore(args.pickscore_weights)
+            else:
+                pw, pcfg = synthetic.clip_weights(ClipConfig(), 777), ClipConfig()
+            scorer = PickScoreScorer(device, dtype=torch.bfloat16, model_sd=pw, clip_cfg=pcfg)
     if args.linear_dtype == "fp8":
         tr.enable_fp8()
     # reward factories that need a backbone (adv_grpo.rewards builds them from checkpoints; none can be downloaded here): the fp32

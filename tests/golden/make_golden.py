@@ -239,6 +239,27 @@ def gold_losses():
                           torch.tensor(1.0))
     out["clip/text"], out["clip/img0"], out["clip/img1"] = (a.numpy() for a in f)
     out["clip/loss"] = loss.numpy()
+    # ---- the same criterion with the batch's labels, through CLIPCriterion.forward(model, batch) (pick_score_training.py:205-224) on a
+    # stand-in model that returns fixed, bf16-exact, UN-normalised features (forward normalises them, :103-104): real-vs-fake (1, 0),
+    # reversed (0, 1), a tie (0.5, 0.5: the log(0.5) offset of :181-183) and per-example labels
+    g = torch.Generator().manual_seed(11)
+    B, P = 5, 48
+    raw = [(torch.randn(B, P, generator=g) * 3).to(torch.bfloat16).float() for _ in range(3)]
+
+    class Feat:
+        logit_scale = torch.tensor(2.0).log()
+        def get_text_features(self, input_ids): return raw[0]
+        def get_image_features(self, pixel_values): return torch.cat([raw[1], raw[2]])[:pixel_values.shape[0]]
+    out["clipl/text"], out["clipl/img0"], out["clipl/img1"] = (a.numpy() for a in raw)
+    out["clipl/logit_scale_exp"] = np.array(2.0, dtype=np.float32)
+    cases = {"real_fake": (torch.tensor(1.0), torch.tensor(0.0)), "fake_real": (torch.tensor(0.0), torch.tensor(1.0)),
+             "tie": (torch.tensor(0.5), torch.tensor(0.5)),
+             "mixed": (torch.tensor([1.0, 0.0, 0.5, 1.0, 0.25]), torch.tensor([0.0, 1.0, 0.5, 0.0, 0.75]))}
+    for name, (l0, l1) in cases.items():
+        batch = {"input_ids": torch.zeros(B, 77, dtype=torch.long), "pixels_0": torch.zeros(B, 3, 2, 2), "pixels_1": torch.zeros(B, 3, 2, 2),
+                 "label_0": l0, "label_1": l1, "num_examples_per_prompt": torch.tensor(1.0)}
+        out[f"clipl/{name}/label_0"], out[f"clipl/{name}/label_1"] = l0.numpy(), l1.numpy()
+        out[f"clipl/{name}/loss"] = crit(Feat(), batch).numpy()
     # ---- train_dino (TD:156-232) with a stand-in backbone returning fixed features
     from PIL import Image
     from oracle.losses import DinoHead

@@ -427,3 +427,18 @@ def test_pair_output_epilogue_equals_the_split_pass():
     off = dec.decode_to_image(lat)
     torch.cuda.synchronize()
     assert torch.equal(on, off)
+
+
+def test_decoder_reports_the_arithmetic_it_runs():
+    """AutoencoderKLDecoder.arithmetic(): what bench.py prints as vae.mode_ran -- fp16-exact weights put 31 of the 33 3x3 convolutions on
+    the two-product kernel (conv_in has 16 input channels, conv_out 3 output channels: three products), other weights none."""
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.model_configs import VaeConfig
+    from adv_grpo_amd.vae import AutoencoderKLDecoder
+    cfg = VaeConfig()
+    a = AutoencoderKLDecoder(synthetic.vae_decoder_weights(cfg, 4321, fp16_checkpoint=True), cfg, "cuda", mode="bf16x3").arithmetic()
+    assert (a["f16x2"], a["bf16x3"], a["total"]) == (31, 2, 33) and a["text"] == "f16x2 (31/33 convs), bf16x3 (2/33)"
+    b = AutoencoderKLDecoder(synthetic.vae_decoder_weights(cfg, 4321), cfg, "cuda", mode="bf16x3").arithmetic()
+    assert (b["f16x2"], b["bf16x3"]) == (0, 33) and b["text"] == "bf16x3 (33/33 convs)"
+    c = AutoencoderKLDecoder(synthetic.vae_decoder_weights(cfg, 4321), cfg, "cuda", mode="bf16").arithmetic()
+    assert c["bf16"] == 33 and c["text"] == "bf16 (33/33 convs)"
