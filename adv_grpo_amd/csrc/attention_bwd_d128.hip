@@ -595,6 +595,12 @@ __global__ __launch_bounds__(256) void attn_bwd_delta128_kernel(const AttnBwdPar
 }  // namespace
 
 int attention_bwd_d128_launch(const AttnBwdParams& p, int B, hipStream_t s) {
+    // every operand is addressed with 32-bit byte offsets from a per-(batch, head) base: checked for ALL of them -- q, dO, o, k, v and the
+    // dq / dk / dv pitch -- and BEFORE the first launch (the delta kernel reads o and dO with the same arithmetic)
+    auto fits = [](int64_t rows, int64_t ld) { return rows * ld * 2 < (1ll << 31); };
+    const bool fits32 = fits(p.Sq, p.ldq) && fits(p.Sq, p.lddo) && fits(p.Sq, p.ldo) && fits(p.Skv, p.ldk) && fits(p.Skv, p.ldv) &&
+                        fits(p.Sq > p.Skv ? p.Sq : p.Skv, p.lddq);
+    ADVGRPO_CHECK(fits32, "attention_bwd (d128): rows * row stride must stay below 2^30 elements (32-bit byte offsets)");
     hipLaunchKernelGGL(attn_bwd_delta128_kernel, dim3((unsigned)(((int64_t)B * p.Sq + 3) / 4)), dim3(256), 0, s, p, B);
     ADVGRPO_LAUNCH_CHECK();
     // dQ: the 16x16 kernel with two own-row blocks per wave (227 registers, two waves per SIMD).  dK/dV: the 32x32 kernel (254 registers, two
@@ -604,14 +610,15 @@ int attention_bwd_d128_launch(const AttnBwdParams& p, int B, hipStream_t s) {
     //          | the same + score-phase fragments one k-step ahead 8.1 - 8.2
     //   dQ     16x16 two blocks 6.9 ms -> 6.55 ms with the eight accumulating-phase fragments requested up front
     //          | 32x32 8.4 ms | 32x32, tile loads after the score phase, fragments 2 steps ahead 7.0 - 7.6 ms
-    // ADVGRPO_ATTN_BWD_D128 (A/B switch, read once): dQ variant << 4 | dK/dV variant; 0 = 16x16, 1 = 32x32 (dQ: the late-load form).  Default 0x01.
+    // ADVGRPO_ATTN_BWD_D128 (A/B switch of the EXPERIMENTS build, read once): dQ variant << 4 | dK/dV variant; 0 = 16x16, 1 = 32x32 (dQ: the late-load form).  Default 0x01.
     constexpr int CBQ = 2, CBK = 1;
+#ifdef ADVGRPO_EXPERIMENTS
     static const int variant = [] { const char* e = getenv("ADVGRPO_ATTN_BWD_D128"); return e ? atoi(e) : 1; }();
-    const bool fits32 = (int64_t)p.Sq * p.ldq * 2 < (1ll << 31) && (int64_t)p.Sq * p.lddo * 2 < (1ll << 31) &&
-                        (int64_t)p.Skv * p.ldk * 2 < (1ll << 31) && (int64_t)p.Skv * p.ldv * 2 < (1ll << 31);
+#else
+    constexpr int variant = 1;                 // (the product library reads no environment: Makefile)
+#endif
     const int64_t nq = (int64_t)((p.Sq + 64 * CBQ - 1) / (64 * CBQ)) * p.H * B, nk = (int64_t)((p.Skv + 64 * CBK - 1) / (64 * CBK)) * p.H * B;
     ADVGRPO_CHECK(nq < (1ll << 31) && nk < (1ll << 31), "attention_bwd (d128): grid too large");
-    ADVGRPO_CHECK(fits32, "attention_bwd (d128): rows * row stride must stay below 2^30 elements (32-bit byte offsets)");
     const dim3 gq((unsigned)((int64_t)((p.Sq + 127) / 128) * p.H * B)), gk((unsigned)((int64_t)((p.Skv + 127) / 128) * p.H * B));
     if ((variant >> 4) & 1) hipLaunchKernelGGL((attn_bwd_d128_w32_kernel<false, 2, true>), gq, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((attn_bwd_d128_kernel<false, CBQ>), dim3((unsigned)nq), dim3(256), 0, s, p);

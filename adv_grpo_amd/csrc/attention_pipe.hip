@@ -95,7 +95,11 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
     [[maybe_unused]] unsigned long long clk0 = 0, rt0 = 0;
     if constexpr ((ATT_ABL & 32) != 0) { clk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     [[maybe_unused]] unsigned long long stamp[7];
-#define ATT_STAMP(i) if constexpr ((ATT_ABL & 256) != 0) { asm volatile("" ::: "memory"); stamp[i] = __builtin_amdgcn_s_memrealtime(); asm volatile("" ::: "memory"); }
+#ifndef ATT_FENCE
+#define ATT_FENCE 0
+#endif
+#define ATT_STAMP(i) if constexpr ((ATT_ABL & 256) != 0) { asm volatile("" ::: "memory"); stamp[i] = __builtin_amdgcn_s_memrealtime(); asm volatile("" ::: "memory"); } \
+                     else if constexpr (((ATT_FENCE >> (i)) & 1) != 0) { asm volatile("" ::: "memory"); }
     ATT_STAMP(0)
     int qblk, h, b;
     xcd_local_bh(p.nqb, p.H, p.nwg, p.xcd_local, qblk, h, b);
@@ -133,6 +137,9 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
         const uint32_t lds = k_lds + slot * TILE_B;
         if ((t + 1) * ATT_KB > p.Skv) {
             asm volatile("; ragged K tile" ::: "memory");
+            int rl;                           // (fresh lane id: see the epilogue)
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(rl));
+            const int lrow = rl >> 3, pch = rl & 7;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int R = (wave + 4 * i) * 8 + lrow;
@@ -150,6 +157,9 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
         const uint32_t lds = v_lds + slot * TILE_B;
         if ((t + 1) * ATT_KB > p.Skv) {
             asm volatile("; ragged V tile" ::: "memory");
+            int rl;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(rl));
+            const int lrow = rl >> 3, pch = rl & 7;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int R = (wave + 4 * i) * 8 + lrow;
@@ -193,7 +203,9 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     o[0] = zero16; o[1] = zero16;
     f32x2 lsum[2] = {{0.f, 0.f}, {0.f, 0.f}};    // this lane's share of the row sum (two packed accumulators)
-    float m_ref = 0.f;                   // reference maximum (log2 units): the row maximum of tile 0
+    // (the reference maximum m_ref -- log2 units, the row maximum of tile 0 -- lives only as nm2 = {-m_ref, -m_ref}: a separate register
+    //  for it, live across the main loop for the sake of the log-sum-exp output, was the 169th and cost the kernel its only scratch
+    //  spills: 6 scratch instructions, 1.2 % of the launch at 16 x 24 x 1229)
     const f32x2 c2 = {p.scale_log2e, p.scale_log2e};
     f32x2 nm2 = {0.f, 0.f};              // -m_ref twice: addend of the packed multiply-add in front of the exponentials
 
@@ -316,17 +328,22 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
     };
     auto mask_tail = [&](f32x16 (&sc)[2], int kv0) __attribute__((always_inline)) {
         if (kv0 + ATT_KB > p.Skv) {       // keys past the end of the sequence
+            int ml;                           // (fresh lane id: `hi` kept live across the main loop for this one use was spilled)
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ml));
+            const int mhi = ml >> 5;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = kv0 + kb * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+                    const int key = kv0 + kb * 32 + 8 * (r >> 2) + 4 * mhi + (r & 3);
                     if (key >= p.Skv) sc[kb][r] = -INFINITY;
                 }
         }
     };
-    m_ref = row_max(sA) * p.scale_log2e;      // (a row of tile 0 always holds a real key: finite)
-    nm2 = f32x2{-m_ref, -m_ref};
+    {
+        const float m_ref = row_max(sA) * p.scale_log2e;      // (a row of tile 0 always holds a real key: finite)
+        nm2 = f32x2{-m_ref, -m_ref};
+    }
     ATT_STAMP(3)
 
     // One steady-state iteration j (0 <= j <= nt - 2), j = PH (mod 3): probabilities of tile j (raw scores sc -> pn), Q K^T
@@ -495,8 +512,7 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
                 tile_pv(3 * TILE_B, pA);
                 l_run += xor32_add((lsum[0][0] + lsum[0][1]) + (lsum[1][0] + lsum[1][1]));
             }
-            m_ref = m_run;
-            l = l_run;
+            l = l_run;                                       // (nm2 = -m_run already)
             __builtin_amdgcn_s_barrier();                        // the epilogue reuses the K ring
         }
     }
@@ -511,8 +527,14 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
         }
     }
     const float inv = l > 0.f ? 1.0f / l : 0.f;
-    const int qi = q0 + ql;
-    if ((ATT_ABL & (32 | 256)) == 0 && p.lse && hi == 0 && qi < p.Sq) p.lse[((int64_t)b * p.H + h) * p.Sq + qi] = m_ref + __builtin_amdgcn_logf(l);
+    // the lane id re-derived (two VALU instructions) from here on: lane / ql / q0 + ql kept live across the main loop for the sake of these
+    // few address computations were what the 168-register budget spilled (4 scratch instructions and their waits per workgroup)
+    int el;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el));
+    const int eql = el & 31, ehi = el >> 5;
+    const int q0s = __builtin_amdgcn_readfirstlane(q0);
+    const int qi = q0s + eql;
+    if ((ATT_ABL & (32 | 256)) == 0 && p.lse && ehi == 0 && qi < p.Sq) p.lse[((int64_t)b * p.H + h) * p.Sq + qi] = __builtin_amdgcn_logf(l) - nm2[0];
     char* ob = Kr + wave * 4096;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -522,14 +544,14 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
             pk.x = att_cvt_pk(o[db][4 * i] * inv, o[db][4 * i + 1] * inv);
             pk.y = att_cvt_pk(o[db][4 * i + 2] * inv, o[db][4 * i + 3] * inv);
             // d = db*32 + 8 i + 4 hi .. + 3  ->  16-byte chunk db*4 + i, 8-byte half hi
-            *reinterpret_cast<uint2*>(ob + ql * 128 + (((db * 4 + i) ^ (ql & 7)) << 4) + hi * 8) = pk;
+            *reinterpret_cast<uint2*>(ob + eql * 128 + (((db * 4 + i) ^ (eql & 7)) << 4) + ehi * 8) = pk;
         }
     // (each wave reads back only what it wrote itself: no barrier, the LDS accesses of one wave are ordered)
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
-        const int r = ps * 8 + (lane >> 3), c = lane & 7;
+        const int r = ps * 8 + (el >> 3), c = el & 7;
         const uint4 v = *reinterpret_cast<const uint4*>(ob + r * 128 + ((c ^ (r & 7)) << 4));
-        const int qo = q0 + r;
+        const int qo = q0s + r;
         if (qo < p.Sq) *reinterpret_cast<uint4*>(p.o + (int64_t)b * p.bso + (int64_t)qo * p.ldo + h * HD + c * 8) = v;
     }
     if constexpr ((ATT_ABL & 256) != 0) {

@@ -416,7 +416,8 @@ __device__ __forceinline__ void gemm_epilogue_f32io(const GemmParams& p, f32x4 (
                 uint32_t hw[2], lw[2];
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {
-                    const float a = v[e] * p.pair_prescale, b = v[e + 1] * p.pair_prescale;
+                    const float a = fminf(fmaxf(v[e] * p.pair_prescale, -65504.f), 65504.f);        // (saturating, as split8_f16)
+                    const float b = fminf(fmaxf(v[e + 1] * p.pair_prescale, -65504.f), 65504.f);
                     const _Float16 ha = (_Float16)a, hb = (_Float16)b;
                     const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
                     hw[e >> 1] = (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);

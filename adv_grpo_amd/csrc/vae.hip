@@ -66,7 +66,10 @@ __device__ inline void split8_f16(const float v[8], float prescale, uint4& hi, u
     uint32_t h[4], l[4];
 #pragma unroll
     for (int k = 0; k < 8; k += 2) {
-        const float a = v[k] * prescale, b = v[k + 1] * prescale;
+        // (saturated at the fp16 range: beyond it hi would be inf and lo = a - inf NaN -- a silently NaN image; clamped, the pair
+        //  carries +-65504 + its rounding residue, i.e. the value is CLIPPED at |v| = 65504 / prescale (1.05e6 for the un-normalised
+        //  inputs of the upsamplers, 65504 after a GroupNorm: activations of a working decoder are O(10)))
+        const float a = fminf(fmaxf(v[k] * prescale, -65504.f), 65504.f), b = fminf(fmaxf(v[k + 1] * prescale, -65504.f), 65504.f);
         const _Float16 ha = (_Float16)a, hb = (_Float16)b;
         const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
         h[k >> 1] = (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);

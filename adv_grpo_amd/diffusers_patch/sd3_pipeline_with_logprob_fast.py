@@ -104,5 +104,10 @@ def pipeline_with_logprob_random(self, prompt=None, prompt_2=None, prompt_3=None
             all_latents.append(latents)
             all_log_probs.append(log_prob)
             all_timesteps.append(t.repeat(B))
+    if output_type == "latent":
+        # diffusers' StableDiffusion3Pipeline.__call__ option (`if output_type == "latent": image = latents`) that the reference's trimmed copy
+        # of the function dropped: the final latents are returned undecoded so that the caller can run `self.vae.decode_to_image` wherever
+        # it schedules the reward computation (bench.py / Trainer: inside the reward future, beside the next group's rollout)
+        return latents, all_latents, all_log_probs, all_timesteps
     image = self.vae.decode_to_image(latents)                                  # PF:667-670 (rescale, decode, postprocess)
     return image, all_latents, all_log_probs, all_timesteps

@@ -220,6 +220,11 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
 
     # ------------------------------------------------------------------ the adapter-free transformer (KL reference)
     _fp8_base = None           # {(block, Linear): Fp8Rows of the BASE weight}, filled by the first fp8 reference forward
+
+    def _base_forward(self, *a, **kw):
+        """The rollout forward of the model class underneath the adapters (QwenImageTransformerLoRA binds its own)."""
+        return SD3Transformer2DModel.__call__(self, *a, **kw)
+
     @torch.no_grad()
     def forward_reference(self, hidden_states, timestep, encoder_hidden_states, pooled_projections):
         """The forward under PEFT's `disable_adapter()` (TP:1105-1108: the reference policy of the KL term): the rollout
@@ -231,7 +236,7 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                 saved.append((b, {k: b[k] for k in keys}))
                 b[gk + ".w"] = base
                 b.pop(gk + ".A", None)          # side mode: no side columns -> the plain [rows, D] input
-        ext, self.lora_ext = self.lora_ext, (0, 0)
+        ext, self.lora_ext = getattr(self, "lora_ext", (0, 0)), (0, 0)
         # fp8 Linears (enable_fp8): the forward reads self.fp8[(block, Linear)], the quantised MERGED weights -- the reference
         # policy needs the quantised BASE weights of the adapted projections there (quantised once: they never change);
         # without the swap the "reference" equals the policy and the KL term vanishes silently
@@ -246,7 +251,7 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                     f8_saved[(i, gk)] = self.fp8[(i, gk)]
                     self.fp8[(i, gk)] = self._fp8_base[(i, gk)]
         try:
-            (v,) = SD3Transformer2DModel.__call__(self, hidden_states, timestep, encoder_hidden_states, pooled_projections)
+            (v,) = self._base_forward(hidden_states, timestep, encoder_hidden_states, pooled_projections)
         finally:
             self.lora_ext = ext
             for b, kv in saved:

@@ -14,6 +14,8 @@ Differences that come with the platform, none of which change the number compute
     two products in f32; both are bounded against the fp32 oracle in tests/test_gpu_vit.py.  ``compute_dtype`` says
     what runs ("bf16" or "bf16x3").
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -33,6 +35,7 @@ class PickScoreScorer(torch.nn.Module):
         self.tokenizer = tokenizer
         self.model = (vit_x3.CLIPModelX3 if dtype == torch.float32 else vit.CLIPModel)(model_sd, clip_cfg, device)
         self._text_streams = {}         # calling stream -> side stream of the text tower
+        self._text_streams_lock = threading.Lock()
 
     def _images(self, images):
         if isinstance(images, torch.Tensor):
@@ -68,14 +71,27 @@ class PickScoreScorer(torch.nn.Module):
                 return uniq.index_select(0, torch.tensor(inverse, device=uniq.device))
         return self.model.get_text_features(ids)
 
+    def prepare_streams(self, mains):
+        """Choose -- by measurement (ops.concurrent_stream: device-wide synchronisations, micro-bursts) -- the text tower's side stream for
+        every stream the scorer will be called on.  Construction-time work: the Trainer calls it from __init__ for its scoring stream and
+        the launch stream, before a worker thread or a rollout exists (measured lazily from the scoring worker the bursts waited on
+        everyone's kernels and timed other threads' load)."""
+        for main in mains:
+            with self._text_streams_lock:
+                if main.cuda_stream not in self._text_streams:
+                    self._text_streams[main.cuda_stream] = ops.concurrent_stream(self.device, [main], reuse=False)
+
     def _side_stream(self, main):
         """The text tower's stream for calls made on `main`: the towers are independent until the logits, and the text tower of
         one prompt is 77 rows -- 24 layers of GEMMs that give 8 - 32 workgroups to 256 CUs, 3.2 ms of latency that hides
-        completely beside the image tower.  One stream per calling stream (scorer calls may come from worker threads)."""
+        completely beside the image tower.  One stream per calling stream (scorer calls may come from worker threads).  A calling
+        stream that was not announced through prepare_streams gets a plain new stream, unmeasured: no device-wide synchronisation on
+        a hot path (it may share the caller's hardware queue and then simply runs behind it)."""
         key = main.cuda_stream
-        st = self._text_streams.get(key)
-        if st is None:
-            st = self._text_streams[key] = ops.concurrent_stream(self.device, [main])
+        with self._text_streams_lock:
+            st = self._text_streams.get(key)
+            if st is None:
+                st = self._text_streams[key] = torch.cuda.Stream(device=self.device)
         return st
 
     @torch.no_grad()

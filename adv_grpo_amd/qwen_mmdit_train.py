@@ -86,6 +86,14 @@ class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
     _lora_wgrad_now = SD3TransformerLoRA._lora_wgrad_now
     optimizer_step = SD3TransformerLoRA.optimizer_step
     ema_step = SD3TransformerLoRA.ema_step
+    # the KL term's reference policy (train.beta > 0; g_step.micro_step): the same weight swap -- base bf16 weights and, in fp8 mode, base
+    # e4m3 rows of the adapted projections -- around this class's own rollout forward (the method was missing, beta > 0 raised
+    # AttributeError in the middle of an epoch)
+    _fp8_base = None
+    forward_reference = SD3TransformerLoRA.forward_reference
+
+    def _base_forward(self, *a, **kw):
+        return QwenImageTransformer2DModel.__call__(self, *a, **kw)
 
     def _prepare_transposes(self):
         """Transposed copies for the data-gradient GEMMs; base (un-merged) copies of the adapted weights and their transposes

@@ -206,6 +206,10 @@ class Trainer:
             d = torch.device(self.device)
             self._dev_index = d.index if d.index is not None else torch.cuda.current_device()
             self._score_stream = torch.cuda.Stream(device=self._dev_index)
+        # side streams that are chosen by measurement are chosen NOW, before a worker thread or a rollout exists (measured
+        # lazily on the scoring worker, the device-wide synchronisations of the probe waited for every thread's kernels)
+        if hasattr(scorer, "prepare_streams") and torch.cuda.is_available():
+            scorer.prepare_streams(([self._score_stream] if self.async_reward else []) + [torch.cuda.current_stream(torch.device(self.device))])
         self.epoch, self.global_step = 0, 0
         self.logger = JsonlLogger(log_path, enabled=(rank == 0))
         self.timers = {}

@@ -50,6 +50,11 @@ def parse():
                     help="c2 = the headline (BASELINE config 2); c3 = BASELINE config 3's rank-local work (config 2's rollout with the co-trained "
                          "DINOv2-patch discriminator as reward; its epoch leg runs one D epoch and one G epoch); c4 = secondary line, SD3.5-large 1024^2 G=4 (BASELINE config 4 shapes); "
                          "c5 = secondary line, Qwen-Image MMDiT 1024^2 G=8, DINO reward, fp8 Linears (BASELINE config 5 shapes)")
+    ap.add_argument("--decode-in-future", type=int, default=0, help="experiment (measured, no gain: DESIGN 6 round 5): 1 = the VAE decode runs inside "
+                    "the reward future as well (the rollout returns latents, output_type='latent')")
+    ap.add_argument("--rollout-priority", type=int, default=0, help="experiment (measured, no gain): -1 = the timed rollouts on a high-priority HIP stream")
+    ap.add_argument("--sync-scoring", action="store_true",
+                    help="score each group on the launch stream right after its decode instead of on the reward-future stream (SURVEY 8a11)")
     ap.add_argument("--no-pricing", action="store_true",
                     help="skip the untimed legs that price the alternative modes (split-bf16 VAE, LoRA side path): profiling runs, "
                          "so that the rocprof summary holds the timed configuration only")
@@ -554,14 +559,12 @@ def main():
     # one prompt per group (TP:813-817 repeat the group's prompt G times): the scorers see G equal prompts
     ids = synthetic.clip_input_ids(1, 3 + rank).repeat(G, 1).to(device)
 
-    def step(it, exchange=True):
-        sampler.set_epoch(it)
-        prompt_idx = next(iter(sampler))[0]
-        image, lats, lps, tss = pipeline_with_logprob_random(
-            pipe, prompt_embeds=pe, pooled_prompt_embeds=ppe, negative_prompt_embeds=npe,
-            negative_pooled_prompt_embeds=nppe, num_inference_steps=STEPS, guidance_scale=4.5, output_type="pt",
-            height=RES, width=RES, noise_level=0.8, mini_num_image_per_prompt=G, train_num_steps=T,
-            process_index=rank, sample_num_steps=STEPS, random_timestep=0, seed=rollout_seed(42, it, rank))
+    # Reward futures (TP:668 executor, TP:816-817 submit, TP:839-856 resolve): the scorer of group i runs on its own HIP
+    # stream behind an event and is resolved one step later, so it overlaps the rollout of group i + 1 -- the rollouts themselves stay
+    # serial (one prompt group at a time on the launch stream).  --sync-scoring puts it back on the launch stream.
+    score_stream = None if args.sync_scoring else torch.cuda.Stream(device=device)
+
+    def score(image):
         if c5 or c3:    # the co-trained DINOv2 patch scorer (RW:375-434): bicubic -> 518, ViT-B/14, 64 random patches, head
             scores, _ = dino_score(dino, dino_head, image.to(torch.bfloat16), None, None)
         elif c4:    # fp32 scorer (RW:561-574)
@@ -571,6 +574,40 @@ def main():
         else:       # (the text tower on the group's ONE distinct prompt, as PickScoreScorer does from the host strings)
             scores = vit.pickscore_scores(clip.get_image_features(images=image.to(torch.bfloat16)),
                                           clip.get_text_features(ids[:1]).expand(G, -1).contiguous(), clip.logit_scale)
+        return scores
+
+    def rollout_and_submit(it, worker=None):
+        """Rollout (+ decode) of one prompt group on the current stream; its scoring on `worker` (None: the current stream)."""
+        sampler.set_epoch(it)
+        prompt_idx = next(iter(sampler))[0]
+        image, lats, lps, tss = pipeline_with_logprob_random(
+            pipe, prompt_embeds=pe, pooled_prompt_embeds=ppe, negative_prompt_embeds=npe,
+            negative_pooled_prompt_embeds=nppe, num_inference_steps=STEPS, guidance_scale=4.5,
+            height=RES, width=RES, noise_level=0.8, mini_num_image_per_prompt=G, train_num_steps=T,
+            process_index=rank, sample_num_steps=STEPS, random_timestep=0, seed=rollout_seed(42, it, rank),
+            output_type="latent" if (worker is not None and args.decode_in_future) else "pt")
+        if worker is None:
+            return prompt_idx, lps, score(image), None
+        ready = torch.cuda.Event()
+        ready.record()
+        worker.wait_event(ready)
+        with torch.cuda.stream(worker):
+            if args.decode_in_future:
+                latents = image
+                image = pipe.vae.decode_to_image(latents)                   # PF:667-670, moved behind the event
+                latents.record_stream(worker)
+            scores = score(image)
+            done = torch.cuda.Event()
+            done.record(worker)
+        if not args.decode_in_future:
+            image.record_stream(worker)
+        return prompt_idx, lps, scores, done
+
+    def finish(pending, exchange=True):
+        prompt_idx, lps, scores, done = pending
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
+            scores.record_stream(torch.cuda.current_stream())
         rewards = scores.unsqueeze(1).repeat(1, T)                          # TP:926-928
         gids = torch.full((G,), prompt_idx, dtype=torch.int32, device=device)
         if not exchange:                                                    # (the solo leg of the scaling diagnostics below)
@@ -579,19 +616,39 @@ def main():
         adv = stat_tracking.group_advantage(rewards, gids, True)            # TP:970 (global_std)
         return D.ungather(adv, world, rank), torch.stack(lps, 1)            # TP:995-999
 
+    def step(it, exchange=True):
+        """One group start to finish on the current stream (the pricing legs, the two-groups leg, the scaling diagnostics)."""
+        return finish(rollout_and_submit(it), exchange)
+
+    def steps_pipelined(first, n):
+        """n timed steps: rollout of group i, then the (already submitted) scores of group i - 1 are gathered and normalised."""
+        pend, out = None, None
+        for it in range(n):
+            cur = rollout_and_submit(first + it, score_stream)
+            if pend is not None:
+                out = finish(pend)
+            pend = cur
+        return finish(pend)
+
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for it in range(args.warmup):
-        step(it)
+    if args.warmup:
+        steps_pipelined(0, args.warmup)
     ops.PROFILE, ops.PROFILE_STRIDE = [], max(1, args.event_stride)
     sync()
     with PowerSampler(local_rank if rank == 0 and os.environ.get("ADVGRPO_BENCH_NO_SMI", "0") != "1" else -1) as power:
         t0 = time.perf_counter()
-        for it in range(args.steps):
-            out = step(args.warmup + it)
+        if args.rollout_priority:
+            hp = torch.cuda.Stream(device=device, priority=args.rollout_priority)
+            hp.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(hp):
+                out = steps_pipelined(args.warmup, args.steps)
+            torch.cuda.current_stream().wait_stream(hp)
+        else:
+            out = steps_pipelined(args.warmup, args.steps)       # every group's scores are resolved inside the timed region
         sync()
         dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
@@ -697,6 +754,20 @@ def main():
             torch.cuda.synchronize()
             lora_ms["side"] = round((time.perf_counter() - tl) / 2 * 1e3, 2)
             pipe.transformer = merged_tr
+        # the same steps with the scorer on the launch stream (no reward future): what the overlap of scoring with the next rollout buys
+        scoring = {"mode": "sync (--sync-scoring)" if score_stream is None else
+                   "reward future: the group's scorer runs on its own HIP stream behind an event and is resolved one step later (TP:668,816-817,839-856); "
+                   "rollouts serial, one prompt group at a time"}
+        if score_stream is not None and world == 1 and not args.no_pricing:
+            step(0)
+            torch.cuda.synchronize()
+            tl = time.perf_counter()
+            for it in range(3):
+                step(1 + it)
+            torch.cuda.synchronize()
+            sync_ms = (time.perf_counter() - tl) / 3 * 1e3
+            scoring.update(ms_per_step_if_sync=round(sync_ms, 2), value_if_sync=round(G / (sync_ms * 1e-3), 3),
+                           frac_of_bf16_mfma_peak_if_sync=round(per_image_tflop * G / (sync_ms * 1e-3) / BF16_DENSE_PEAK_TFLOPS, 4))
         # the same step with the block Linears of the MMDiT on fp8 e4m3 operands (BASELINE config 5's "fp8 MFMA path";
         # quantize.hip + gemm8p_fp8.hip).  Priced, not the headline: the reference has no fp8 arithmetic to match.
         fp8 = None
@@ -820,6 +891,7 @@ def main():
             "scaling_diagnostics": scaling_diag,
             "clock_and_power": power.summary(),
             "overlap": overlap,
+            "scoring": scoring,
             "fp8_linears": fp8,
             **({"ocr": "stand-in recogniser (constant reward half): PaddleOCR is not in this image, adv_grpo_amd.ocr.OcrScorer runs with a callable that "
                        "returns a fixed string, so half of config 4's reward is a constant and the recognition phase costs nothing in this line"} if c4 else {}),

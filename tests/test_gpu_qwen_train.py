@@ -246,3 +246,28 @@ def test_qwen_lora_backward_fp8_replay_straight_through():
     autograd through the (unquantised) oracle -- a stated property with looser bounds, no reference arithmetic exists."""
     from oracle.qwen_mmdit import QwenMMDiTConfig
     _lora_case(QwenMMDiTConfig(num_layers=3, num_heads=4, joint_attention_dim=256), 47, B=4, hw=16, Nt=20, fp8=True)      # (the fp8 GEMM's row epilogue wants >= 16 text tokens)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_qwen_forward_reference_is_the_adapter_free_model(fp8):
+    """forward_reference (the KL term's reference policy under train.beta > 0, TP:1105-1108 disable_adapter): with non-zero adapters it
+    gives the bits of a model built WITHOUT them and differs from the adapted forward; the adapted forward is untouched afterwards."""
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.model_configs import QwenMMDiTConfig
+    from adv_grpo_amd.qwen_mmdit import QwenImageTransformer2DModel
+    from adv_grpo_amd.qwen_mmdit_train import QwenImageTransformerLoRA
+    cfg = QwenMMDiTConfig(num_layers=2, num_heads=4, joint_attention_dim=256)
+    W = {k: v.to(bf16) for k, v in synthetic.qwen_mmdit_weights(cfg, 5).items()}
+    g = torch.Generator().manual_seed(9)
+    lat = torch.randn(2, 16, 16, 16, generator=g).to(bf16).cuda()
+    ctx = torch.randn(2, 20, cfg.joint_attention_dim, generator=g).to(bf16).cuda()
+    t = torch.full((2,), 700.0).cuda()
+    model = QwenImageTransformerLoRA(dict(W), cfg, "cuda", lora_state=_lora_init(cfg, 6))
+    plain = QwenImageTransformer2DModel(dict(W), cfg, "cuda")
+    if fp8:
+        model.enable_fp8(); plain.enable_fp8()
+    (v_pol,) = model(lat, t, ctx)
+    v_ref = model.forward_reference(lat, t, ctx, None)
+    (v_plain,) = plain(lat, t, ctx)
+    assert torch.equal(v_ref, v_plain) and not torch.equal(v_ref, v_pol)
+    assert torch.equal(model(lat, t, ctx)[0], v_pol)

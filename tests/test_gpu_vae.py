@@ -442,3 +442,18 @@ def test_decoder_reports_the_arithmetic_it_runs():
     assert (b["f16x2"], b["bf16x3"]) == (0, 33) and b["text"] == "bf16x3 (33/33 convs)"
     c = AutoencoderKLDecoder(synthetic.vae_decoder_weights(cfg, 4321), cfg, "cuda", mode="bf16").arithmetic()
     assert c["bf16"] == 33 and c["text"] == "bf16 (33/33 convs)"
+
+
+def test_f16_pair_split_saturates_instead_of_overflowing():
+    """The fp16-pair operand rows (f16x2 convolutions) of activations beyond the fp16 range: hi + lo reproduces the value to 22 bits
+    inside the range, and is CLIPPED at +-65504 / prescale outside it -- finite, never inf / NaN (unsaturated, |s x| > 65504
+    gave hi = inf, lo = NaN and a silently NaN image)."""
+    from adv_grpo_amd import ops
+    x = torch.tensor([[1.0, -3.5e4, 6.5e4, 7.0e4, -1.0e6, 2.0e6, 3.0e38, -3.0e38] * 8], device="cuda")
+    for s in (1.0, 2.0 ** -4):
+        rows = ops.split_f16x2(x.contiguous(), prescale=s).view(torch.float16).float()          # [1, 3 K]: hi | - | lo
+        K = x.shape[1]
+        got = (rows[:, :K] + rows[:, 2 * K:]) / s
+        want = x.clamp(-65504.0 / s, 65504.0 / s)
+        assert torch.isfinite(rows[:, :K]).all() and torch.isfinite(rows[:, 2 * K:]).all()
+        assert ((got - want).abs() <= want.abs() * 2.0 ** -20 + 1e-30).all(), (s, got, want)
