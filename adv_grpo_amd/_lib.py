@@ -41,6 +41,14 @@ class LnDesc(ctypes.Structure):
                 ("q0", _P), ("qs0", _P), ("q1", _P), ("qs1", _P), ("ldq", c_int64)]
 
 
+class TnDesc(ctypes.Structure):
+    """advgrpo_tn_desc (include/advgrpo.h), field for field."""
+    _fields_ = [("P", _P), ("ldp", c_int64), ("p_seg_rows", c_int32), ("p_seg_stride", c_int64), ("p_seg_off", c_int64),
+                ("Q", _P), ("ldq", c_int64), ("q_seg_rows", c_int32), ("q_seg_stride", c_int64), ("q_seg_off", c_int64),
+                ("C", _P * 3), ("ldc", c_int64), ("transpose_out", c_int32),
+                ("M", c_int32), ("N1", c_int32), ("NQ", c_int32), ("alpha", c_float)]
+
+
 class Fp8Scales(ctypes.Structure):
     """advgrpo_fp8_scales (include/advgrpo.h)."""
     _fields_ = [("a_scale", _P), ("w_scale", _P)]
@@ -85,6 +93,8 @@ SIGNATURES = {
     "advgrpo_gemm_tn_f32acc": (c_int, [_P, c_int64, c_int, c_int64, c_int64, _P, c_int64, c_int, c_int64, c_int64, _P, c_int64,
                                        c_int, c_int, c_int, c_int, c_float, _P, _P]),
     "advgrpo_gemm_tn_workspace_bytes": (c_int64, [c_int, c_int]),
+    "advgrpo_gemm_tn_grouped_workspace_bytes": (c_int64, [POINTER(TnDesc), c_int]),
+    "advgrpo_gemm_tn_grouped": (c_int, [POINTER(TnDesc), c_int, _P, c_int64, c_int, _P]),
     "advgrpo_transpose_bf16": (c_int, [_P, _P, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int64, c_int64, _P]),
     "advgrpo_layernorm_mod_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int, _P, _P, c_int64, c_int,
                                           c_int, c_float, _P]),

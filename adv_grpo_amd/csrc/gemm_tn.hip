@@ -198,6 +198,284 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
     *c += s * alpha;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Grouped form (round 5): every token-contracted product of one adapter group -- the dB products of up to six adapters, or the dA
+// products of the adapters that share an input -- in ONE launch, and no reduce kernel.
+//   * a launch carries up to TN_MAX problems (advgrpo_tn_desc); a workgroup finds its (problem, 128-column tile, token slice) from
+//     the problems' workgroup prefix (wave-uniform scan over at most TN_MAX entries);
+//   * Q may be 64 * NQB wide (NQB = 1 or 3): the three adapters of a fused q | k | v projection share their input X, so
+//     dA_j = s (dY_j B_j)^T X for j = 0..2 is ONE pass over X against u = [u_0 | u_1 | u_2] instead of three (X is the 50 MB
+//     operand); the output rows of adapter j go to its own C[j];
+//   * slices of the token range meet in the workspace, and the LAST workgroup to arrive at a tile (agent-scope counter) adds the
+//     slices in slice order into C: a fixed summation order whoever arrives last -- bitwise reproducible, no float atomics -- and the
+//     separate reduce launch is gone.  XCD L2s are not coherent with each other: partial tiles are written and read with agent-scope
+//     (sc1) accesses, the counter is bumped after the stores have completed (vmcnt(0) + workgroup barrier), and the last workgroup
+//     leaves the counter at zero for the next launch.
+constexpr int TN_MAX = 12;
+struct TnProblem {
+    const bf16_t* P; const bf16_t* Q; float* C[3];
+    int64_t ldp, p_seg_stride, p_seg_off, ldq, q_seg_stride, q_seg_off, ldc, ws_off;
+    int p_seg_rows, q_seg_rows, transpose_out, M, N1, tiles, slices, chunks_per_block, wg0, cnt_off;
+    float alpha;
+};
+struct TnGroup { TnProblem pr[TN_MAX]; int n; float* ws; int* counters; };
+
+typedef unsigned long long tn_u64;
+typedef __attribute__((ext_vector_type(2))) float tn_f32x2;
+__device__ __forceinline__ void tn_st16_sc1(float* p, const tn_f32x4& v) {
+    tn_u64* q = reinterpret_cast<tn_u64*>(p);
+    const tn_f32x2 lo{v[0], v[1]}, hi{v[2], v[3]};
+    __hip_atomic_store(q, __builtin_bit_cast(tn_u64, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, __builtin_bit_cast(tn_u64, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ tn_f32x4 tn_ld16_sc1(const float* p) {
+    tn_u64* q = reinterpret_cast<tn_u64*>(const_cast<float*>(p));
+    const tn_f32x2 lo = __builtin_bit_cast(tn_f32x2, __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const tn_f32x2 hi = __builtin_bit_cast(tn_f32x2, __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return tn_f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
+// One DMA instruction of the grouped kernel: 64 lanes x 16 bytes from (uniform base + per-lane 32-bit byte offset) to LDS [lds, lds + 1 KiB).
+// Hand-written (as in attention.hpp / gemm8p_kernel.hpp): issued through the builtin, the compiler treats the DMA as a possible alias of
+// every later LDS read and waits with vmcnt(0) in front of the first fragment read of the SAME iteration -- the ring then hides nothing
+// (the per-adapter kernel above: 1.4 TB/s).
+__device__ __forceinline__ void tn_dma16(const void* base, uint32_t off, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
+}
+// A lane's source cursor: byte offset of its token's row (+ column) from the operand base, and the token's position in its row segment.
+// Advancing by MC tokens is division-free.
+struct TnCur {
+    uint32_t off; int rem;
+};
+__device__ __forceinline__ void tn_cur_init(TnCur& c, int m, int64_t ld, int col, int seg_rows, int64_t seg_stride, int64_t seg_off) {
+    c.off = (uint32_t)((tn_row(m, seg_rows, seg_stride, seg_off) * ld + col) * 2);
+    c.rem = seg_rows > 0 ? m % seg_rows : 0;
+}
+__device__ __forceinline__ void tn_cur_advance(TnCur& c, int step, uint32_t step_bytes, int seg_rows, uint32_t jump_bytes) {
+    c.off += step_bytes;
+    c.rem += step;
+    while (c.rem >= seg_rows) {           // (0 or 1 trips for the hot path's 205- / 1024-token segments; short segments wrap more than once)
+        c.off += jump_bytes;
+        c.rem -= seg_rows;
+    }
+}
+
+template <int NQB>
+__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroup grp) {
+    // tokens per stage: 64 with a 64-wide Q (24 KiB per stage), 32 with a 192-wide one (20 KiB): three stages, two workgroups per CU
+    constexpr int MC = NQB == 1 ? 64 : 32, NS = 3, NQ = 64 * NQB, KC = MC / 32;
+    constexpr int P_BYTES = MC * 256, Q_ROW = 128 * NQB, Q_BYTES = MC * Q_ROW, STAGE = P_BYTES + Q_BYTES;
+    constexpr int PI = P_BYTES / 4096, QI = Q_BYTES / 4096;            // DMA instructions per wave per stage (1 KiB each, 4 waves)
+    constexpr int LOADS = PI + QI;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, t = lane & 15;
+    // ---- which problem, tile, slice
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.n; ++i)
+        if ((int)blockIdx.x >= grp.pr[i].wg0) pi = i;
+    pi = __builtin_amdgcn_readfirstlane(pi);
+    const TnProblem& p = grp.pr[pi];
+    const int local = (int)blockIdx.x - p.wg0;
+    const int tile = local % p.tiles, slice = local / p.tiles;
+    const int n1_0 = tile * 128;
+    const int M = p.M;
+    const int m_begin = slice * p.chunks_per_block * 64;               // (chunks_per_block counts 64-token chunks whatever MC is)
+    const int m_end = min(M, m_begin + p.chunks_per_block * 64);
+    const int nch = (m_end - m_begin + MC - 1) / MC;                   // >= 1 by construction of `slices`
+
+    // ---- DMA sources.  The stage image is token-major: P rows of 256 bytes (this tile's 128 columns), Q rows of Q_ROW bytes.
+    // Instruction j of an operand fills LDS bytes [1024 j, 1024 j + 1024): lane l -> byte 1024 j + 16 l -> token byte / row, column.
+    // This wave issues j = wave + 4 i.  A token past the end of the matrix reads the matrix's last row (its products are zeroed).
+    const int p_sr = p.p_seg_rows > 0 ? p.p_seg_rows : 0x7fffffff, q_sr = p.q_seg_rows > 0 ? p.q_seg_rows : 0x7fffffff;
+    const uint32_t p_step = (uint32_t)(MC * p.ldp * 2), q_step = (uint32_t)(MC * p.ldq * 2);
+    const uint32_t p_jump = p.p_seg_rows > 0 ? (uint32_t)((p.p_seg_stride - p.p_seg_rows) * p.ldp * 2) : 0u;
+    const uint32_t q_jump = p.q_seg_rows > 0 ? (uint32_t)((p.q_seg_stride - p.q_seg_rows) * p.ldq * 2) : 0u;
+    TnCur pc[PI], qc[QI];
+    int p_tok[PI], q_tok[QI];
+    uint32_t p_last[PI], q_last[QI];                                   // the same column of the matrix's last row
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+        const int byte = 1024 * (wave + 4 * i) + 16 * lane;
+        p_tok[i] = byte >> 8;
+        const int col = n1_0 + ((byte & 255) >> 1);
+        tn_cur_init(pc[i], min(m_begin + p_tok[i], M - 1), p.ldp, col, p.p_seg_rows, p.p_seg_stride, p.p_seg_off);
+        p_last[i] = (uint32_t)((tn_row(M - 1, p.p_seg_rows, p.p_seg_stride, p.p_seg_off) * p.ldp + col) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < QI; ++i) {
+        const int byte = 1024 * (wave + 4 * i) + 16 * lane;
+        q_tok[i] = byte / Q_ROW;
+        const int col = (byte - q_tok[i] * Q_ROW) >> 1;
+        tn_cur_init(qc[i], min(m_begin + q_tok[i], M - 1), p.ldq, col, p.q_seg_rows, p.q_seg_stride, p.q_seg_off);
+        q_last[i] = (uint32_t)((tn_row(M - 1, p.q_seg_rows, p.q_seg_stride, p.q_seg_off) * p.ldq + col) * 2);
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)(smem)) + wave * 1024;
+    auto stage = [&](int slot, int m0) __attribute__((always_inline)) {      // stages are requested in increasing token order
+        const uint32_t base = lds0 + slot * STAGE;
+        const bool ragged = m0 + MC > M;                                      // (uniform; only the last stage of the matrix)
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const uint32_t off = ragged && m0 + p_tok[i] >= M ? p_last[i] : pc[i].off;
+            tn_dma16(p.P, off, base + i * 4096);
+            tn_cur_advance(pc[i], MC, p_step, p_sr, p_jump);
+        }
+#pragma unroll
+        for (int i = 0; i < QI; ++i) {
+            const uint32_t off = ragged && m0 + q_tok[i] >= M ? q_last[i] : qc[i].off;
+            tn_dma16(p.Q, off, base + P_BYTES + i * 4096);
+            tn_cur_advance(qc[i], MC, q_step, q_sr, q_jump);
+        }
+    };
+
+    tn_f32x4 acc[2][4 * NQB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4 * NQB; ++j) acc[i][j] = tn_f32x4{0.f, 0.f, 0.f, 0.f};
+    // transposed fragment reads: inside a 16-lane group, lane t supplies the address of 4 contiguous features of token
+    // (g*4 + t/4) and receives feature t of tokens g*4 .. g*4+3; a second read 16 tokens further completes the 8
+    // contraction values of the lane.  P and Q use the same token permutation, so the products pair up correctly.
+    const int tok = g * 4 + (t >> 2);
+    const int p_off = tok * 256 + (wave * 32) * 2 + (t & 3) * 8;
+    const int q_off = tok * Q_ROW + (t & 3) * 8;
+
+    stage(0, m_begin);
+    if (nch > 1) stage(1, m_begin + MC);
+    int slot = 0;
+    for (int c = 0; c < nch; ++c) {
+        if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int fill = slot == 0 ? NS - 1 : slot - 1;      // slot of stage c-1: free once every wave is past the barrier
+        if (c + 2 < nch) stage(fill, m_begin + (c + 2) * MC);
+        const char* pb = smem + slot * STAGE;
+        const char* qb = pb + P_BYTES;
+        slot = slot == NS - 1 ? 0 : slot + 1;
+        const int m0 = m_begin + c * MC;
+        const bool ragged = m0 + MC > m_end;                 // tokens of the next slice / past the matrix: zero their contribution
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            bf16x8_t pf[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const char* a = pb + kc * 32 * 256 + p_off + nb * 32;
+                const tn_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(a));
+                const tn_s16x4 hi =
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(a + 16 * 256));
+                tn_s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                if (ragged) {
+                    asm volatile("; ragged stage" ::: "memory");
+                    const int mb = m0 + kc * 32 + g * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (mb + e >= m_end) both[e] = 0;
+                        if (mb + 16 + e >= m_end) both[4 + e] = 0;
+                    }
+                }
+                pf[nb] = __builtin_bit_cast(bf16x8_t, both);
+            }
+#pragma unroll
+            for (int qn = 0; qn < 4 * NQB; ++qn) {
+                const char* a = qb + kc * 32 * Q_ROW + q_off + qn * 32;
+                const tn_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(a));
+                const tn_s16x4 hi =
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(a + 16 * Q_ROW));
+                const bf16x8_t qf = __builtin_bit_cast(bf16x8_t, (tn_s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc[nb][qn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, pf[nb], acc[nb][qn], 0, 0, 0);
+            }
+        }
+    }
+    int* const s_last_p = reinterpret_cast<int*>(smem);           // (the ring is idle from here on; every wave is past its last read
+    __syncthreads();                                              //  once it has passed this barrier)
+#define s_last (*s_last_p)
+    // ---- partial tile -> workspace (agent scope), then the arrival counter of the tile.  lane holds
+    //      partial C[n1 = n1_0 + wave*32 + nb*16 + t][n2 = qn*16 + g*4 .. +3]
+    float* ws = grp.ws + p.ws_off;
+    float* mine = ws + (int64_t)slice * p.N1 * NQ;
+    if (p.slices > 1) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int n1 = n1_0 + wave * 32 + nb * 16 + t;
+#pragma unroll
+            for (int qn = 0; qn < 4 * NQB; ++qn) tn_st16_sc1(mine + (int64_t)n1 * NQ + qn * 16 + g * 4, acc[nb][qn]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's stores have completed
+        __syncthreads();                                                // ... every wave's
+        if (tid == 0) {
+            int* cnt = grp.counters + p.cnt_off + tile;
+            const int before = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = before == p.slices - 1;
+            if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero again for the next launch
+        }
+        __syncthreads();
+        if (!s_last) return;
+    }
+    // ---- the last workgroup at this tile: C (+)= alpha * (slice 0 + slice 1 + ...), in slice order.  Slice by slice, with the lane's
+    // 8 NQB chunk loads of a slice issued together (a first version walked chunk by chunk, slice by slice inside: 8 NQB x slices
+    // dependent round trips of an agent-scope load each -- 300 - 440 us per launch, most of it this loop in 24 workgroups)
+    if (p.slices > 1) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int qn = 0; qn < 4 * NQB; ++qn)
+                acc[nb][qn] = tn_ld16_sc1(ws + (int64_t)(n1_0 + wave * 32 + nb * 16 + t) * NQ + qn * 16 + g * 4);
+        for (int k = 1; k < p.slices; ++k) {
+            const float* wk = ws + (int64_t)k * p.N1 * NQ;
+            tn_f32x4 v[2][4 * NQB];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int qn = 0; qn < 4 * NQB; ++qn)
+                    v[nb][qn] = tn_ld16_sc1(wk + (int64_t)(n1_0 + wave * 32 + nb * 16 + t) * NQ + qn * 16 + g * 4);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int qn = 0; qn < 4 * NQB; ++qn) acc[nb][qn] += v[nb][qn];
+        }
+    }
+    // C += alpha * sum: every load of C first, then every store (written as `C[..] += ..` per element the compiler has to assume that a
+    // store aliases the next load and serialises 8 - 96 memory round trips per lane: 120 of the 130 us of the 192-wide launch)
+    tn_f32x4 cur[2][4 * NQB];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int n1 = n1_0 + wave * 32 + nb * 16 + t;
+#pragma unroll
+        for (int qn = 0; qn < 4 * NQB; ++qn) {
+            const float* C = p.C[qn >> 2];                              // adapter qn / 4 of the group
+            const int n2 = (qn & 3) * 16 + g * 4;
+            if (p.transpose_out) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cur[nb][qn][e] = C[(int64_t)(n2 + e) * p.ldc + n1];
+            } else {
+                cur[nb][qn] = *reinterpret_cast<const tn_f32x4*>(C + (int64_t)n1 * p.ldc + n2);
+            }
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int n1 = n1_0 + wave * 32 + nb * 16 + t;
+#pragma unroll
+        for (int qn = 0; qn < 4 * NQB; ++qn) {
+            const tn_f32x4 out = cur[nb][qn] + acc[nb][qn] * p.alpha;
+            float* C = p.C[qn >> 2];
+            const int n2 = (qn & 3) * 16 + g * 4;
+            if (p.transpose_out) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) C[(int64_t)(n2 + e) * p.ldc + n1] = out[e];
+            } else {
+                *reinterpret_cast<tn_f32x4*>(C + (int64_t)n1 * p.ldc + n2) = out;
+            }
+        }
+    }
+}
+
+#undef s_last
+
 }  // namespace advgrpo
 
 using namespace advgrpo;
@@ -237,6 +515,105 @@ extern "C" int advgrpo_gemm_tn_f32acc(const void* P, int64_t ldp, int p_seg_rows
     ADVGRPO_LAUNCH_CHECK();
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((N1 * 64 + 255) / 256), dim3(256), 0, s, (const float*)workspace, slices,
                        N1, C, ldc, transpose_out, alpha);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+// one advgrpo_tn_desc (include/advgrpo.h) -> TnProblem; returns the workgroups it takes
+constexpr int TN_MAX_SLICES = 8;               // token slices per problem: what the last workgroup at a tile has to add up
+constexpr int64_t TN_CNT_BYTES = 4096;          // arrival counters at the front of the workspace (1024 tiles per launch)
+
+extern "C" int64_t advgrpo_gemm_tn_grouped_workspace_bytes(const advgrpo_tn_desc* d, int n) {
+    int64_t f = 0;
+    for (int i = 0; i < n; ++i) {
+        const int nchunks = (d[i].M + 63) / 64;
+        const int slices = nchunks < 64 ? (nchunks < 1 ? 1 : nchunks) : 64;     // (64: room for the EXPERIMENTS build's slice knob)        // upper bound of what the launcher picks
+        f += (int64_t)slices * d[i].N1 * d[i].NQ;
+    }
+    return f * 4 + TN_CNT_BYTES;
+}
+
+extern "C" int advgrpo_gemm_tn_grouped(const advgrpo_tn_desc* d, int n, void* workspace, int64_t workspace_bytes,
+                                       int workspace_is_zeroed, void* stream) {
+    ADVGRPO_CHECK(d && n > 0 && n <= TN_MAX && workspace, "gemm_tn_grouped: 1..%d problems and a workspace", TN_MAX);
+    const int NQ = d[0].NQ;
+    ADVGRPO_CHECK(NQ == 64 || NQ == 192, "gemm_tn_grouped: Q is 64 or 192 columns wide (got %d)", NQ);
+    TnGroup g{};
+    g.n = n;
+    int64_t chunks_total = 0;
+    for (int i = 0; i < n; ++i) {
+        const advgrpo_tn_desc& a = d[i];
+        ADVGRPO_CHECK(a.P && a.Q && a.C[0] && a.M > 0, "gemm_tn_grouped: problem %d: bad argument", i);
+        ADVGRPO_CHECK(a.NQ == NQ, "gemm_tn_grouped: every problem of a launch has the same Q width");
+        ADVGRPO_CHECK(NQ == 64 || (a.C[1] && a.C[2]), "gemm_tn_grouped: a 192-wide Q needs three outputs");
+        ADVGRPO_CHECK(a.N1 > 0 && a.N1 % 128 == 0, "gemm_tn_grouped: N1 %% 128 == 0 (N1=%d)", a.N1);
+        ADVGRPO_CHECK(a.ldp % 8 == 0 && a.ldq % 8 == 0 && (reinterpret_cast<uintptr_t>(a.P) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.Q) & 15) == 0,
+                      "gemm_tn_grouped: operands must be 16-byte aligned with pitches that are multiples of 8");
+        ADVGRPO_CHECK((a.p_seg_rows == 0 || a.p_seg_rows >= 8) && (a.q_seg_rows == 0 || a.q_seg_rows >= 8), "gemm_tn_grouped: bad row segments");
+        {   // 32-bit byte offsets from the operand bases
+            auto last_row = [](int M, int sr, int64_t ss, int64_t so) { return sr > 0 ? (int64_t)((M - 1) / sr) * ss + so + (M - 1) % sr : (int64_t)M - 1; };
+            ADVGRPO_CHECK((last_row(a.M, a.p_seg_rows, a.p_seg_stride, a.p_seg_off) + 1) * a.ldp * 2 < (1ll << 32) &&
+                              (last_row(a.M, a.q_seg_rows, a.q_seg_stride, a.q_seg_off) + 1) * a.ldq * 2 < (1ll << 32),
+                          "gemm_tn_grouped: problem %d: an operand spans 4 GiB or more (32-bit byte offsets)", i);
+        }
+        ADVGRPO_CHECK(a.transpose_out || (a.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C[0]) & 15) == 0), "gemm_tn_grouped: C rows must be 16-byte aligned");
+        chunks_total += (int64_t)(a.M + 63) / 64 * (a.N1 / 128);
+    }
+    // ~768 workgroups per launch (NQB = 1: two per CU), at most TN_MAX_SLICES token slices per problem and at least 8 chunks (512 tokens)
+    // per slice
+    // (same-box sweep at the config-2 shapes, scripts/bench_tn.py: 4 / 8 / 16 / 32 slices -> 77 / 70 / 100 / 104 us for the six dB problems of a
+    //  q | k | v group and 136 / 107 / 130 / 181 us for its two 192-wide dA problems; 384 .. 1536 target workgroups within 5 %)
+    int64_t target = NQ == 64 ? 768 : 384;
+    int max_slices = TN_MAX_SLICES;
+#ifdef ADVGRPO_EXPERIMENTS
+    { const char* e = getenv("ADVGRPO_TNG_TARGET"); if (e && atoi(e) > 0) target = atoi(e); }
+    { const char* e = getenv("ADVGRPO_TNG_SLICES"); if (e && atoi(e) > 0) max_slices = atoi(e); }
+#endif
+    int cpb = (int)((chunks_total + target - 1) / target);
+    if (cpb < 8) cpb = 8;
+    int wg = 0, cnt = 0;
+    int64_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        const advgrpo_tn_desc& a = d[i];
+        TnProblem& p = g.pr[i];
+        const int nchunks = (a.M + 63) / 64;
+        int c = cpb;
+        if ((nchunks + c - 1) / c > max_slices) c = (nchunks + max_slices - 1) / max_slices;
+        p.chunks_per_block = c;
+        p.slices = (nchunks + c - 1) / c;
+        p.tiles = a.N1 / 128;
+        p.P = (const bf16_t*)a.P; p.Q = (const bf16_t*)a.Q;
+        for (int j = 0; j < 3; ++j) p.C[j] = a.C[j];
+        p.ldp = a.ldp; p.p_seg_rows = a.p_seg_rows; p.p_seg_stride = a.p_seg_stride; p.p_seg_off = a.p_seg_off;
+        p.ldq = a.ldq; p.q_seg_rows = a.q_seg_rows; p.q_seg_stride = a.q_seg_stride; p.q_seg_off = a.q_seg_off;
+        p.ldc = a.ldc; p.transpose_out = a.transpose_out; p.M = a.M; p.N1 = a.N1; p.alpha = a.alpha;
+        p.wg0 = wg; p.cnt_off = cnt; p.ws_off = off;
+        wg += p.tiles * p.slices;
+        cnt += p.tiles;
+        off += (int64_t)p.slices * a.N1 * NQ;
+    }
+    // layout: [arrival counters of every tile: zero between launches, at a fixed place so that launches with different problem sets
+    // share the zeroed words | partial tiles]
+    ADVGRPO_CHECK((int64_t)cnt * 4 <= TN_CNT_BYTES, "gemm_tn_grouped: too many tiles in one launch (%d)", cnt);
+    ADVGRPO_CHECK(off * 4 + TN_CNT_BYTES <= workspace_bytes, "gemm_tn_grouped: workspace too small (%lld bytes needed)", (long long)(off * 4 + TN_CNT_BYTES));
+    ADVGRPO_CHECK((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "gemm_tn_grouped: workspace must be 256-byte aligned");
+    g.counters = reinterpret_cast<int*>(workspace);
+    g.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + TN_CNT_BYTES);
+    hipStream_t s = as_stream(stream);
+    if (!workspace_is_zeroed) {
+        if (hipMemsetAsync(workspace, 0, TN_CNT_BYTES, s) != hipSuccess) { set_error("gemm_tn_grouped: memset failed"); return -2; }
+    }
+    if (NQ == 64) {
+        constexpr int LDS = 3 * (64 * 256 + 64 * 128);
+        static bool attr1 = false;
+        if (!attr1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_grouped_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr1 = true; }
+        hipLaunchKernelGGL(gemm_tn_grouped_kernel<1>, dim3(wg), dim3(256), LDS, s, g);
+    } else {
+        constexpr int LDS = 3 * (32 * 256 + 32 * 384);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_grouped_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+        hipLaunchKernelGGL(gemm_tn_grouped_kernel<3>, dim3(wg), dim3(256), LDS, s, g);
+    }
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

@@ -174,6 +174,8 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
         self.params_bf16.copy_(self.params)
         D = self.cfg.dim
         self._lora = {}
+        if not hasattr(self, "_Bbd"):
+            self._Bbd = {}
         for i, b in enumerate(self.blocks):
             p = f"transformer_blocks.{i}.attn"
             groups = {"qkv": ["to_q", "to_k", "to_v"], "cqkv": ["add_q_proj", "add_k_proj", "add_v_proj"],
@@ -200,7 +202,16 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                     As.append(A16)
                     Bts.append(ops.transpose(B16))                               # [64, N]
                 A_cat = torch.cat(As, 0).contiguous()
-                self._lora[(i, gk)] = (A_cat, Bts, [self.adapters[f"{p}.{n}"] for n in names])
+                # [B_0^T; B_1^T; ...] as ONE block-diagonal right operand [64 n, n D]: u = [dY_0 B_0 | dY_1 B_1 | ...] is then a single
+                # GEMM over the group's whole output gradient (K = n D; the off-diagonal zeros cost flops on a pass that is bound by
+                # reading dY) instead of n launches (kept across refreshes: only the diagonal blocks are rewritten)
+                n_ad = len(names)
+                Bbd = self._Bbd.get((i, gk))
+                if Bbd is None:
+                    Bbd = self._Bbd[(i, gk)] = torch.zeros(RPAD * n_ad, n_ad * D, dtype=torch.bfloat16, device=self.device)
+                for j in range(n_ad):
+                    Bbd[j * RPAD:(j + 1) * RPAD, j * D:(j + 1) * D] = Bts[j]
+                self._lora[(i, gk)] = (A_cat, Bts, [self.adapters[f"{p}.{n}"] for n in names], Bbd)
                 if self.lora_mode == "side":
                     # forward weight [W | s B]: the base weight is left as loaded, each adapter's s * B (bf16; s = 2 is exact)
                     # sits in its own 64 side columns of its output rows
@@ -417,18 +428,41 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             self._lora_wgrad_now(key, X, x_rows, x_seg, dY, dy_seg)
 
     def _lora_wgrad_now(self, key, X, x_rows, x_seg, dY, dy_seg):
-        A_cat, Bts, ads = self._lora[key]
+        self._lora_wgrad_group_now([(key, X, x_rows, x_seg, dY, dy_seg)])
+
+    def _lora_wgrad_group(self, items):
+        """_lora_wgrad for the image- and text-stream twins of one Linear group at once (items: (key, X, x_rows, x_seg, dY, dy_seg))."""
+        if self._wgrad_stream is None or not self.overlap_wgrad:
+            return self._lora_wgrad_group_now(items)
+        ready = torch.cuda.Event()
+        ready.record()
+        self._wgrad_stream.wait_event(ready)
+        for it in items:
+            for t in (it[1], it[4]):
+                t.record_stream(self._wgrad_stream)
+        with torch.cuda.stream(self._wgrad_stream):
+            self._lora_wgrad_group_now(items)
+
+    def _lora_wgrad_group_now(self, items):
+        """Adapter gradients of one Linear group, both streams: 2 skinny GEMM launches (t = X A^T, u = dY . blockdiag(B)) and 1 - 2 grouped
+        token-contracted launches (csrc/gemm_tn.hip, grouped form) instead of 5 n + 1 launches per stream (round 4: 44 per block):
+          dB_j += s dY_j^T t_j              one problem per adapter, all in one launch
+          dA_j += s u_j^T X                 ONE problem per stream: the n adapters share X, u = [u_0 | .. | u_{n-1}] is 64 n wide
+        (n = 3: the 192-wide problems take their own launch, the kernel is instantiated per Q width)."""
         D = self.cfg.dim
-        M = x_rows
-        t = ops.gemm(X, A_cat, a_seg=x_seg, M=M)                                # [M, n*64] = X A^T
-        for j, ad in enumerate(ads):
-            gA, gB = self.A_view(ad, self.grads), self.B_view(ad, self.grads)
-            dYj = dY[:, j * D:(j + 1) * D]
-            # dB[N,64] += s * dY_j^T t_j      (token-contracted GEMM: no transposed copies)
-            ops.gemm_tn(dYj, t[:, j * RPAD:(j + 1) * RPAD], gB, alpha=self.scale, M=M, p_seg=dy_seg)
-            # u = dY_j B [M,64] ; dA[64,K] += s * u^T X
-            u = ops.gemm(dYj, Bts[j], a_seg=dy_seg, M=M)
-            ops.gemm_tn(X, u, gA, alpha=self.scale, M=M, p_seg=x_seg, transpose_out=True)
+        ts = ops.gemm_grouped([ops.gemm_desc(X, self._lora[key][0], a_seg=x_seg, M=M) for key, X, M, x_seg, dY, dy_seg in items])
+        us = ops.gemm_grouped([ops.gemm_desc(dY, self._lora[key][3], a_seg=dy_seg, M=M) for key, X, M, x_seg, dY, dy_seg in items])
+        narrow, wide = [], []
+        for (key, X, M, x_seg, dY, dy_seg), t, u in zip(items, ts, us):
+            ads = self._lora[key][2]
+            for j, ad in enumerate(ads):
+                narrow.append(ops.tn_desc(dY[:, j * D:(j + 1) * D], t[:, j * RPAD:(j + 1) * RPAD], self.B_view(ad, self.grads), alpha=self.scale,
+                                          M=M, p_seg=dy_seg))
+            gAs = [self.A_view(ad, self.grads) for ad in ads]
+            (narrow if len(ads) == 1 else wide).append(ops.tn_desc(X, u, gAs, alpha=self.scale, M=M, p_seg=x_seg, transpose_out=True))
+        ops.gemm_tn_grouped(narrow)
+        if wide:
+            ops.gemm_tn_grouped(wide)
 
     # ------------------------------------------------------------------ explicit backward
     @torch.no_grad()
@@ -493,9 +527,8 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                 dyc = ops.gate_mul(dc1, mod(kc, 2), Nt)
                 douts.append(ops.gemm_desc(dyc, b["cout.wT"], out=datt, seg=(Nt, S, Ni)))
             ops.gemm_grouped(douts)
-            self._lora_wgrad((i, "out"), att2d, B * Ni, (Ni, S, 0), dyo, None)
-            if not b["last"]:
-                self._lora_wgrad((i, "cout"), att2d, B * Nt, (Nt, S, Ni), dyc, None)
+            self._lora_wgrad_group([((i, "out"), att2d, B * Ni, (Ni, S, 0), dyo, None)] +
+                                   ([] if b["last"] else [((i, "cout"), att2d, B * Nt, (Nt, S, Ni), dyc, None)]))
             q3 = s["qkv"].view(B, S, 3 * D)
             dqkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
             d3 = dqkv.view(B, S, 3 * D)
@@ -505,8 +538,8 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             ops.rmsnorm_heads_bwd(dqkv, s["qkv"], s["rs"], 0, 2 * H, b["rms_c"], H, seg=(Nt, S, Ni), M=B * Nt)
             dnx, dnc = ops.gemm_grouped([ops.gemm_desc(dqkv, b["qkv.wT"], a_seg=(Ni, S, 0), M=B * Ni),
                                          ops.gemm_desc(dqkv, b["cqkv.wT"], a_seg=(Nt, S, Ni), M=B * Nt)])
-            self._lora_wgrad((i, "qkv"), s["nx"], B * Ni, None, dqkv, (Ni, S, 0))
-            self._lora_wgrad((i, "cqkv"), s["nc"], B * Nt, None, dqkv, (Nt, S, Ni))
+            self._lora_wgrad_group([((i, "qkv"), s["nx"], B * Ni, None, dqkv, (Ni, S, 0)),
+                                    ((i, "cqkv"), s["nc"], B * Nt, None, dqkv, (Nt, S, Ni))])
             # ---- first norms
             dx = ops.layernorm_mod_bwd(s["x_in"], dnx, scale0=mod(kx, 1), dy1=dnx2, scale1=mod(kx, 7) if b["dual"] else None,
                                        dres=dx1, rows_per_batch=Ni)

@@ -84,6 +84,8 @@ class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
     refresh = SD3TransformerLoRA.refresh
     _lora_wgrad = SD3TransformerLoRA._lora_wgrad
     _lora_wgrad_now = SD3TransformerLoRA._lora_wgrad_now
+    _lora_wgrad_group = SD3TransformerLoRA._lora_wgrad_group
+    _lora_wgrad_group_now = SD3TransformerLoRA._lora_wgrad_group_now
     optimizer_step = SD3TransformerLoRA.optimizer_step
     ema_step = SD3TransformerLoRA.ema_step
     # the KL term's reference policy (train.beta > 0; g_step.micro_step): the same weight swap -- base bf16 weights and, in fp8 mode, base
@@ -257,8 +259,7 @@ class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
             ops.gemm_grouped([ops.gemm_desc(dyo, b["out.wT"], out=datt, seg=(Ni, S, 0)),
                               ops.gemm_desc(dyc, b["cout.wT"], out=datt, seg=(Nt, S, Ni))])
             att2d = s["att"].view(B * S, D)
-            self._lora_wgrad((i, "out"), att2d, B * Ni, (Ni, S, 0), dyo, None)
-            self._lora_wgrad((i, "cout"), att2d, B * Nt, (Nt, S, Ni), dyc, None)
+            self._lora_wgrad_group([((i, "out"), att2d, B * Ni, (Ni, S, 0), dyo, None), ((i, "cout"), att2d, B * Nt, (Nt, S, Ni), dyc, None)])
             q3 = s["qkv"].view(B, S, 3 * D)
             dqkv = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
             d3 = dqkv.view(B, S, 3 * D)
@@ -267,8 +268,7 @@ class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
             ops.qk_norm_rope_bwd(dqkv, s["qkv"], s["rs"], S, Ni, 2 * H, hd, b["rms_x"], b["rms_c"], H, rope=rope)
             dnx, dnc = ops.gemm_grouped([ops.gemm_desc(dqkv, b["qkv.wT"], a_seg=(Ni, S, 0), M=B * Ni),
                                          ops.gemm_desc(dqkv, b["cqkv.wT"], a_seg=(Nt, S, Ni), M=B * Nt)])
-            self._lora_wgrad((i, "qkv"), s["nx"], B * Ni, None, dqkv, (Ni, S, 0))
-            self._lora_wgrad((i, "cqkv"), s["nc"], B * Nt, None, dqkv, (Nt, S, Ni))
+            self._lora_wgrad_group([((i, "qkv"), s["nx"], B * Ni, None, dqkv, (Ni, S, 0)), ((i, "cqkv"), s["nc"], B * Nt, None, dqkv, (Nt, S, Ni))])
             # ---- first norms
             dx = ops.layernorm_mod_bwd(x_in, dnx, scale0=mod(kx, 1), dres=dx1, rows_per_batch=Ni)
             dc = ops.layernorm_mod_bwd(c_in, dnc, scale0=mod(kc, 1), dres=dc1, rows_per_batch=Nt)

@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--decode-in-future", type=int, default=0, help="experiment (measured, no gain: DESIGN 6 round 5): 1 = the VAE decode runs inside "
                     "the reward future as well (the rollout returns latents, output_type='latent')")
     ap.add_argument("--rollout-priority", type=int, default=0, help="experiment (measured, no gain): -1 = the timed rollouts on a high-priority HIP stream")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="N > 1 (or --spawn): bring the process group up, check that every rank is there (all-reduce of ones, device "
+                         "names), time the path's two collectives alone, print that as the JSON line and stop -- no model is built")
     ap.add_argument("--sync-scoring", action="store_true",
                     help="score each group on the launch stream right after its decode instead of on the reward-future stream (SURVEY 8a11)")
     ap.add_argument("--no-pricing", action="store_true",
@@ -442,6 +445,43 @@ def scaling_diagnostics(dist, device, world, rank, G, T, dt_local, dt_max, steps
                     "HIP events around back-to-back calls"}
 
 
+def host_rss_mb():
+    import resource
+    return round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0, 1)        # (Linux: kilobytes)
+
+
+def print_dry_run(dist, device, ranks_seen, world, rank):
+    """--dry-run: what the first multi-GPU line must show before anything expensive runs -- every rank present, one GPU each, the two
+    collectives of the path alive and timed (reward all-gather TP:926-966, the 75 MB LoRA-gradient all-reduce TP:1165)."""
+    from adv_grpo_amd import distributed as D
+    res = {"dry_run": True, "n_gpus": world, "ranks_seen": ranks_seen, "host_rss_mb_rank0": host_rss_mb()}
+    if dist is not None:
+        names = [None] * world
+        dist.all_gather_object(names, f"rank {rank}: {torch.cuda.get_device_name(device)} (cuda:{device.index}, pid {os.getpid()})")
+        G, T = 8, 2
+        rw, gi = torch.rand(G, T, device=device), torch.full((G,), rank, dtype=torch.int32, device=device)
+        flat = torch.ones(18_776_064, dtype=torch.float32, device=device)
+
+        def timed_ms(fn, reps):
+            fn()
+            dist.barrier()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(reps):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            return s.elapsed_time(e) / reps
+        res.update(ranks=names, reward_all_gather_ms=round(timed_ms(lambda: D.gather_rewards(rw, gi), 20), 4),
+                   lora_gradient_all_reduce_ms=round(timed_ms(lambda: D.average_gradients(flat), 5), 3), lora_gradient_bytes=18_776_064 * 4,
+                   all_reduce_of_ones_after_averaging=float(flat[0].item()))
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -486,12 +526,15 @@ def main():
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or args.spawn:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")                # RCCL's own warnings on stderr (the driver keeps the tail)
         if shared_gpu:
             shared_gpu_collectives(dist)
         else:
-            dist.init_process_group("nccl", device_id=device)      # RCCL over xGMI
+            # (a finite timeout: a rank that died before the rendezvous ends the others with an error instead of a hang)
+            dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=600))      # RCCL over xGMI
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     ranks_seen = 1
@@ -500,6 +543,9 @@ def main():
         dist.all_reduce(ones)
         ranks_seen = int(ones.item())
         assert ranks_seen == world, f"all-reduce of ones saw {ranks_seen} ranks, expected {world}"
+    if args.dry_run:
+        print_dry_run(dist, device, ranks_seen, world, rank)
+        return
 
     from adv_grpo_amd import distributed as D
     from adv_grpo_amd import ops, stat_tracking, synthetic, vit
@@ -889,6 +935,7 @@ def main():
                     "value_if_bf16": round(images / (dt + args.steps * (vae_ms["bf16"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)
                     if "bf16" in vae_ms else None},
             "scaling_diagnostics": scaling_diag,
+            "host_rss_mb_rank0": host_rss_mb(),
             "clock_and_power": power.summary(),
             "overlap": overlap,
             "scoring": scoring,
@@ -923,5 +970,27 @@ def main():
         dist.destroy_process_group()
 
 
+def main_with_error_forwarding():
+    """A rank that raises says so where the driver looks: rank 0 prints a JSON line with `error` (the contract's one line), every rank
+    leaves bench_error_rank<r>.json beside the script's working directory's gpurun_out/ (kept by gpurun), then the exception goes on."""
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:          # noqa: BLE001 (re-raised)
+        import traceback
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        info = {"error": f"{type(e).__name__}: {e}", "rank": rank, "n_gpus": world, "traceback_tail": traceback.format_exc()[-2000:]}
+        try:
+            os.makedirs("gpurun_out", exist_ok=True)
+            with open(os.path.join("gpurun_out", f"bench_error_rank{rank}.json"), "w") as f:
+                json.dump(info, f)
+        except OSError:
+            pass
+        if rank == 0:
+            print(json.dumps({"metric": "sampled+scored images/sec (whole node), SD3-med 512^2 10-step G=8 GRPO", "value": None, **info}))
+        raise
+
+
 if __name__ == "__main__":
-    main()
+    main_with_error_forwarding()

@@ -12,7 +12,7 @@ with synthetic.on_device("cuda"):
 # "serial" runs them in the chain
 mode = sys.argv[1] if len(sys.argv) > 1 else ""
 if mode == "nowgrad":
-    model._lora_wgrad = lambda *a, **k: None
+    model._lora_wgrad_group = lambda *a, **k: None
 if mode == "serial":
     model.overlap_wgrad = False
 if mode == "fp8":                     # block Linears of the forward on e4m3 operands (enable_fp8); backward unchanged (bf16)

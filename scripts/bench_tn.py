@@ -1,17 +1,40 @@
-"""Token-contracted GEMM (LoRA weight gradient) timing: ADVGRPO_TN_BLOCKS=<target workgroups> python scripts/bench_tn.py"""
+"""Token-contracted GEMMs of the LoRA weight gradients at the config-2 shapes (CFG batch 16: 16384 image rows, 3280 text rows, D = 1536):
+the grouped launches of round 5 (one per adapter group) beside the per-adapter launches they replace.  Bytes = one pass over P and Q."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adv_grpo_amd import ops
-def bench(M, N1, iters=20):
-    P = torch.randn(M, N1, device="cuda").to(torch.bfloat16); Q = torch.randn(M, 64, device="cuda").to(torch.bfloat16)
-    out = torch.zeros(N1, 64, dtype=torch.float32, device="cuda")
-    for _ in range(3): ops.gemm_tn(P, Q, out)
-    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(); s.record()
-    for _ in range(iters): ops.gemm_tn(P, Q, out)
-    e.record(); torch.cuda.synchronize()
-    us = s.elapsed_time(e) / iters * 1e3
-    return us, (M * N1 * 2 + M * 128) / us / 1e6
-for M in (16384, 3280):
-    us, tbs = bench(M, 1536)
-    print(f"blocks {os.environ.get('ADVGRPO_TN_BLOCKS', '1024')} M={M}: {us:.1f} us  {tbs:.2f} TB/s")
+D, Mi, Mt, S, Ni, Nt = 1536, 16384, 3280, 1229, 1024, 205
+rnd = lambda *s: torch.randn(*s, device="cuda").to(torch.bfloat16)
+def timed(fn, iters=50):
+    for _ in range(5): fn()
+    ts = []
+    for _ in range(5):
+        s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); s.record()
+        for _ in range(iters): fn()
+        e.record(); torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) / iters * 1e3)
+    return min(ts)
+dqkv = rnd(16 * S, 3 * D); nx = rnd(Mi, D); nc = rnd(Mt, D)
+t_i, t_t, u_i, u_t = rnd(Mi, 192), rnd(Mt, 192), rnd(Mi, 192), rnd(Mt, 192)
+gB = [torch.zeros(D, 64, dtype=torch.float32, device="cuda") for _ in range(6)]
+gA = [torch.zeros(64, D, dtype=torch.float32, device="cuda") for _ in range(6)]
+seg_i, seg_t = (Ni, S, 0), (Nt, S, Ni)
+def dB_grouped():
+    ops.gemm_tn_grouped([ops.tn_desc(dqkv[:, j * D:(j + 1) * D], t_i[:, 64 * j:64 * j + 64], gB[j], alpha=2.0, M=Mi, p_seg=seg_i) for j in range(3)] +
+                        [ops.tn_desc(dqkv[:, j * D:(j + 1) * D], t_t[:, 64 * j:64 * j + 64], gB[3 + j], alpha=2.0, M=Mt, p_seg=seg_t) for j in range(3)])
+def dB_single():
+    for j in range(3):
+        ops.gemm_tn(dqkv[:, j * D:(j + 1) * D], t_i[:, 64 * j:64 * j + 64], gB[j], alpha=2.0, M=Mi, p_seg=seg_i)
+        ops.gemm_tn(dqkv[:, j * D:(j + 1) * D], t_t[:, 64 * j:64 * j + 64], gB[3 + j], alpha=2.0, M=Mt, p_seg=seg_t)
+def dA_grouped():
+    ops.gemm_tn_grouped([ops.tn_desc(nx, u_i, gA[:3], alpha=2.0, M=Mi, transpose_out=True), ops.tn_desc(nc, u_t, gA[3:], alpha=2.0, M=Mt, transpose_out=True)])
+def dA_single():
+    for j in range(3):
+        ops.gemm_tn(nx, u_i[:, 64 * j:64 * j + 64], gA[j], alpha=2.0, M=Mi, transpose_out=True)
+        ops.gemm_tn(nc, u_t[:, 64 * j:64 * j + 64], gA[3 + j], alpha=2.0, M=Mt, transpose_out=True)
+bytes_dB = 3 * (Mi + Mt) * (D + 64) * 2
+for name, fn, b in (("dB q|k|v, both streams: 6 problems, one grouped launch", dB_grouped, bytes_dB), ("dB: 6 launches + 6 reduces (round 4)", dB_single, bytes_dB),
+                    ("dA q|k|v, both streams: 2 problems 192 wide, one launch", dA_grouped, (Mi + Mt) * (D + 192) * 2), ("dA: 6 launches + 6 reduces (round 4)", dA_single, 3 * (Mi + Mt) * (D + 64) * 2)):
+    us = timed(fn)
+    print(f"{name:62s} {us:8.1f} us   {b / us / 1e6:5.2f} TB/s of its own operand bytes")

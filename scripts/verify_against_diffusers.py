@@ -16,7 +16,13 @@ Checks (fp32, same inputs):
   * SD3Transformer2DModel forward (CFG pair, 64x64 latents, 205 text tokens)                           -> rel L2 < 1e-4
   * AutoencoderKL.decode (1 x 16 x 32 x 32 latents) + VaeImageProcessor.postprocess("pt")              -> max abs < 1e-4
 The oracle takes diffusers' own state_dict (weights are keyed by diffusers names on purpose), so nothing is converted.
-Exit status 0 = the restatements are pinned on this machine; the printed lines are what to paste into DESIGN.md section 4.
+  * QwenImageTransformer2DModel forward (diffusers >= 0.35; reduced depth with --random; non-square latents, two prompts of      -> rel L2 < 1e-4
+    different lengths through the pipeline's padding mask) vs oracle/qwen_mmdit.py
+  * AutoencoderKLQwenImage.decode on one frame vs oracle/qwen_vae.py                                    -> max abs < 1e-4
+  * peft: an adapter written by `get_peft_model(...).save_pretrained` read by checkpoint.load_lora, and one written by
+    checkpoint.save_lora read by `PeftModel.from_pretrained`                                            -> bit-identical tensors
+Exit status 0 = the restatements are pinned on this machine (non-zero on any mismatch; sections whose package is missing are reported
+and skipped); the printed lines are what to paste into DESIGN.md section 4.
 """
 import argparse
 import os
@@ -136,7 +142,100 @@ def main():
         dq = (img_q - ref_q).abs().max().item()
         print(f"AutoencoderKLQwenImage.decode (one frame) + postprocess('pt'): max abs {dq:.2e}")
         ok &= dq < 1e-4
-    print("PINNED: oracle/{scheduler,mmdit,vae}.py reproduce diffusers on this machine" if ok else "MISMATCH: see the lines above")
+    # ---------------------------------------------------------------- Qwen-Image transformer (BASELINE config 5; diffusers >= 0.35)
+    try:
+        from diffusers import QwenImageTransformer2DModel
+    except ImportError:
+        QwenImageTransformer2DModel = None
+        print("QwenImageTransformer2DModel: not in this diffusers (needs >= 0.35) -- oracle/qwen_mmdit.py stays unpinned here")
+    if QwenImageTransformer2DModel is not None:
+        from oracle import qwen_mmdit as o_qm
+        torch.manual_seed(7)
+        if a.random:
+            # the released config with a reduced depth (the blocks are identical; 60 of them in fp32 are 82 GB): pins the chunk orders of
+            # img_mod / txt_mod, the rotary layout (scale_rope index ranges, text offset), txt_norm, norm_out's (scale, shift) order, the
+            # proj_out / unpack permutation
+            qcfg = o_qm.QwenMMDiTConfig(num_layers=4)
+            qt = QwenImageTransformer2DModel(patch_size=2, in_channels=64, out_channels=16, num_layers=qcfg.num_layers, attention_head_dim=128,
+                                             num_attention_heads=24, joint_attention_dim=3584, guidance_embeds=False, axes_dims_rope=(16, 56, 56))
+            with torch.no_grad():
+                for n_, p_ in qt.named_parameters():
+                    if p_.dim() > 1:
+                        torch.nn.init.normal_(p_, std=0.02)
+                    elif "norm" in n_ and n_.endswith("weight"):
+                        p_.copy_(1 + 0.1 * torch.randn_like(p_))
+                    else:
+                        torch.nn.init.normal_(p_, std=0.1)
+        else:
+            qt = QwenImageTransformer2DModel.from_pretrained("Qwen/Qwen-Image", subfolder="transformer", torch_dtype=torch.float32)
+            c = qt.config
+            qcfg = o_qm.QwenMMDiTConfig(num_layers=c.num_layers, num_heads=c.num_attention_heads, head_dim=c.attention_head_dim,
+                                        joint_attention_dim=c.joint_attention_dim, axes_dims_rope=tuple(c.axes_dims_rope))
+        qt = qt.to(dev).float().eval()
+        Wq = {k: v.detach() for k, v in qt.state_dict().items()}
+        hq, wq = 48, 32                                             # latent height / width: 24 x 16 packed positions (not square on purpose)
+        lat = torch.randn(2, 16, hq, wq, device=dev)
+        # ragged text lengths as the pipeline produces them: padded to the longest, masked (the restatement has no mask: the shorter
+        # prompt is compared on its own, unpadded, which is what the mask makes of it)
+        lens = [37, 23]
+        ctx = torch.randn(2, max(lens), 3584, device=dev)
+        mask = torch.zeros(2, max(lens), dtype=torch.long, device=dev)
+        for i, L in enumerate(lens):
+            mask[i, :L] = 1
+        sigma = torch.tensor([0.9133, 0.9133], device=dev)
+        tok = o_qm.pack_latents(lat)
+        with torch.no_grad():
+            ref = qt(hidden_states=tok, timestep=sigma, encoder_hidden_states=ctx, encoder_hidden_states_mask=mask,
+                     img_shapes=[[(1, hq // 2, wq // 2)]] * 2, txt_seq_lens=lens, return_dict=False)[0]
+            ref = o_qm.unpack_latents(ref, hq, wq)
+            out_full = o_qm.qwen_forward(Wq, qcfg, lat[:1], sigma[:1], ctx[:1, :lens[0]])
+            out_short = o_qm.qwen_forward(Wq, qcfg, lat[1:], sigma[1:], ctx[1:, :lens[1]])
+        r0 = ((out_full - ref[:1]).norm() / ref[:1].norm()).item()
+        r1 = ((out_short - ref[1:]).norm() / ref[1:].norm()).item()
+        print(f"QwenImageTransformer2DModel ({qcfg.num_layers} blocks, D={qcfg.dim}, {hq // 2}x{wq // 2} positions, text {lens}): rel L2 {r0:.2e} "
+              f"(longest prompt), {r1:.2e} (shorter prompt: padded + masked there, unpadded here)")
+        ok &= r0 < 1e-4 and r1 < 1e-4
+        del qt, Wq
+
+    # ---------------------------------------------------------------- PEFT's adapter files (TP:389-398 save_ckpt, TP:506-509 load)
+    try:
+        import peft
+    except ImportError:
+        peft = None
+        print("peft is not installed: adv_grpo_amd/checkpoint.py's adapter_model.safetensors / adapter_config.json layout stays unpinned here")
+    if peft is not None:
+        import json
+        import tempfile
+        from adv_grpo_amd import checkpoint
+        torch.manual_seed(11)
+        tiny = SD3Transformer2DModel(sample_size=32, patch_size=2, in_channels=16, num_layers=2, attention_head_dim=64, num_attention_heads=2,
+                                     joint_attention_dim=64, caption_projection_dim=128, pooled_projection_dim=32, out_channels=16,
+                                     pos_embed_max_size=16, dual_attention_layers=(0,), qk_norm="rms_norm")
+        targets = ["attn.add_k_proj", "attn.add_q_proj", "attn.add_v_proj", "attn.to_add_out", "attn.to_k", "attn.to_out.0", "attn.to_q", "attn.to_v"]
+        pm = peft.get_peft_model(tiny, peft.LoraConfig(r=32, lora_alpha=64, init_lora_weights="gaussian", target_modules=targets))     # TP:490-505
+        with torch.no_grad():
+            for n_, p_ in pm.named_parameters():
+                if "lora_B" in n_:
+                    p_.copy_(torch.randn_like(p_) * 0.02)
+        with tempfile.TemporaryDirectory() as d:
+            pm.save_pretrained(d)                                                                                             # TP:389-398
+            state, cfg_json = checkpoint.load_lora(d)
+            want = {k.replace("base_model.model.", "").replace(".default", ""): v for k, v in pm.state_dict().items() if "lora_" in k}
+            same_keys = set(state) == set(want)
+            same_vals = same_keys and all(torch.equal(state[k].float().cpu(), want[k].float().cpu()) for k in want)
+            print(f"peft {peft.__version__}: adapter written by save_pretrained -> checkpoint.load_lora: {len(state)} tensors, keys {'match' if same_keys else 'DIFFER'}, "
+                  f"values {'bit-identical' if same_vals else 'DIFFER'}; r / alpha {cfg_json.get('r')} / {cfg_json.get('lora_alpha')}")
+            ok &= same_vals and cfg_json.get("r") == 32 and cfg_json.get("lora_alpha") == 64
+            # and the other direction: a directory written by checkpoint.save_lora loads into PEFT
+            d2 = os.path.join(d, "ours")
+            checkpoint.save_lora(d2, {k: v.clone() for k, v in want.items()}, r=32, lora_alpha=64)
+            tiny2 = SD3Transformer2DModel(**{k: v for k, v in tiny.config.items() if not k.startswith("_")})
+            pm2 = peft.PeftModel.from_pretrained(tiny2, d2)
+            got = {k.replace("base_model.model.", "").replace(".default", ""): v for k, v in pm2.state_dict().items() if "lora_" in k}
+            back = set(got) == set(want) and all(torch.equal(got[k].float().cpu(), want[k].float().cpu()) for k in want)
+            print(f"checkpoint.save_lora -> peft.PeftModel.from_pretrained: {'bit-identical' if back else 'DIFFERS'}")
+            ok &= back
+    print("PINNED: every oracle restatement checked above reproduces the installed third-party code on this machine" if ok else "MISMATCH: see the lines above")
     return 0 if ok else 1
 
 
