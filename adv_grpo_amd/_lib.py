@@ -41,6 +41,14 @@ class LnDesc(ctypes.Structure):
                 ("q0", _P), ("qs0", _P), ("q1", _P), ("qs1", _P), ("ldq", c_int64)]
 
 
+class MMDiTBlockDesc(ctypes.Structure):
+    """advgrpo_mmdit_block_desc (include/advgrpo.h), field for field."""
+    _fields_ = ([(n, c_int32) for n in ("B", "Ni", "Nt", "D", "H", "dual", "last")] + [("x", _P), ("c", _P), ("mods", _P)] +
+                [(n, c_int64) for n in ("mod_stride", "mod_x", "mod_c")] +
+                [(n, _P) for n in ("qkv_w", "qkv_b", "cqkv_w", "cqkv_b", "out_w", "out_b", "cout_w", "cout_b", "qkv2_w", "qkv2_b", "out2_w", "out2_b",
+                                   "ff1_w", "ff1_b", "ff2_w", "ff2_b", "cff1_w", "cff1_b", "cff2_w", "cff2_b", "rms_x", "rms_c", "rms_2")])
+
+
 class TnDesc(ctypes.Structure):
     """advgrpo_tn_desc (include/advgrpo.h), field for field."""
     _fields_ = [("P", _P), ("ldp", c_int64), ("p_seg_rows", c_int32), ("p_seg_stride", c_int64), ("p_seg_off", c_int64),
@@ -93,6 +101,8 @@ SIGNATURES = {
     "advgrpo_gemm_tn_f32acc": (c_int, [_P, c_int64, c_int, c_int64, c_int64, _P, c_int64, c_int, c_int64, c_int64, _P, c_int64,
                                        c_int, c_int, c_int, c_int, c_float, _P, _P]),
     "advgrpo_gemm_tn_workspace_bytes": (c_int64, [c_int, c_int]),
+    "advgrpo_mmdit_block_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "advgrpo_mmdit_block_forward": (c_int, [POINTER(MMDiTBlockDesc), _P, c_int64, _P]),
     "advgrpo_gemm_tn_grouped_workspace_bytes": (c_int64, [POINTER(TnDesc), c_int]),
     "advgrpo_gemm_tn_grouped": (c_int, [POINTER(TnDesc), c_int, _P, c_int64, c_int, _P]),
     "advgrpo_transpose_bf16": (c_int, [_P, _P, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int64, c_int64, _P]),

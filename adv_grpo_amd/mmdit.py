@@ -18,9 +18,12 @@ Data layout in HBM (bf16 unless noted), B = batch incl. the CFG halves, S = N_im
 LoRA (peft r=32, alpha=64 on the attention projections, train_sd3_fast_pickscore.py:490-505) is merged
 into the bf16 weights for the no-grad rollout: W_eff = W + (alpha/r) B A.
 """
+import ctypes
+import os
+
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 def _ln_two_launches(a, b):
@@ -42,6 +45,7 @@ class SD3Transformer2DModel:
         self.config = type("Cfg", (), {"in_channels": cfg.in_channels})()
         self._prepare({k: v for k, v in state_dict.items()})
         self._pos_cache = {}
+        self._block_descs = {}   # block index -> _lib.MMDiTBlockDesc with the block's weight pointers (c_block)
         self.fp8 = None          # {(block, Linear): ops.Fp8Rows} once enable_fp8() has been called
 
     # ------------------------------------------------------------------ weight preparation
@@ -151,6 +155,33 @@ class SD3Transformer2DModel:
             return pe.to(torch.bfloat16).repeat(B, 1).contiguous()
         return ops.cached(self._pos_cache, (B, hh, ww), make)
 
+    c_block = True             # forward through advgrpo_mmdit_block_forward (one C-ABI call per block) where it applies
+
+    def _blocks_c(self, x, c, mods, B, Ni, Nt):
+        """All blocks through the C-level block entry, in place on x [B * Ni, D] and c [B * Nt, D]."""
+        lib, cfg = _lib.load(), self.cfg
+        D, H = cfg.dim, cfg.num_heads
+        need = max(int(lib.advgrpo_mmdit_block_workspace_bytes(B, Ni, Nt, D, int(d))) for d in {bool(b["dual"]) for b in self.blocks})
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        assert mods.stride(1) == 1 and x.is_contiguous() and c.is_contiguous()
+        p = lambda t: t.data_ptr() if t is not None else None
+        for i, b in enumerate(self.blocks):
+            d = self._block_descs.get(i)
+            if d is None or d._weights is not b.get("qkv.w"):          # (rebuilt when the merged LoRA weights were replaced)
+                d = _lib.MMDiTBlockDesc()
+                d.D, d.H, d.dual, d.last = D, H, int(b["dual"]), int(b["last"])
+                for k in ("qkv", "cqkv", "out", "cout", "qkv2", "out2", "ff1", "ff2", "cff1", "cff2"):
+                    setattr(d, k + "_w", p(b.get(k + ".w")))
+                    setattr(d, k + "_b", p(b.get(k + ".b")))
+                if cfg.qk_norm:
+                    d.rms_x, d.rms_c, d.rms_2 = p(b["rms_x"]), p(b["rms_c"]), p(b.get("rms_2"))
+                d.mod_x, d.mod_c = self.mod_off[("x", i)], self.mod_off[("c", i)]
+                d._weights = b.get("qkv.w")
+                self._block_descs[i] = d
+            d.B, d.Ni, d.Nt = B, Ni, Nt
+            d.x, d.c, d.mods, d.mod_stride = x.data_ptr(), c.data_ptr(), mods.data_ptr(), mods.stride(0)
+            _lib.check(lib.advgrpo_mmdit_block_forward(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+
     # ------------------------------------------------------------------ forward
     def _temb(self, timestep, pooled_projections):
         """time_text_embed: timestep_embedder(t) + text_embedder(pooled) -> [B, D] bf16."""
@@ -240,7 +271,17 @@ class SD3Transformer2DModel:
                 return ops.gemm_grouped_fp8([ops.gemm_desc_fp8(a, f8[(i, key)], bias=b[key + ".b"], **kw) for a, key, kw in items])
             return ops.gemm_grouped([ops.gemm_desc(a, b[key + ".w"], bias=b[key + ".b"], **kw) for a, key, kw in items])
 
-        for i, b in enumerate(self.blocks):
+        # One C-ABI call per block (csrc/mmdit_block.cpp: the launches below, in C++, for callers that are not Python) when nothing this
+        # entry does not cover is on -- fp8 Linears, LoRA side columns, saved intermediates; bit-identical either way
+        # (tests/test_gpu_mmdit.py), `c_block = False` keeps the Python sequencing for A/Bs.
+        # (not while bench.py's per-launch HIP events are being recorded: ops._Prof brackets the launches it issues itself)
+        if (self.c_block and f8 is None and (Eq, Eo) == (0, 0) and not return_intermediates and self.pair_norms and D == H * 64 and
+                (ops.PROFILE is None or os.environ.get("ADVGRPO_CBLOCK_WHILE_PROFILING") == "1")):
+            self._blocks_c(x, c, mods, B, Ni, Nt)
+            blocks = ()
+        else:
+            blocks = self.blocks
+        for i, b in enumerate(blocks):
             kx, kc = ("x", i), ("c", i)
             # --- norms + modulation (chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
             #     [, shift_msa2, scale_msa2, gate_msa2]); AdaLayerNormContinuous (last context): scale, shift

@@ -418,6 +418,28 @@ typedef struct advgrpo_gemm_desc {
 } advgrpo_gemm_desc;
 int advgrpo_gemm_grouped(const advgrpo_gemm_desc* descs, int count /* 1 or 2 */, void* stream);
 
+/* ------------------------------------------------------------------ one MMDiT block behind one entry (csrc/mmdit_block.cpp)
+ * diffusers JointTransformerBlock of SD3 / SD3.5 ("MMDiT-X": dual = the block has the second, image-only attention; last = the
+ * context_pre_only block) as called by the transformer forward at sd3_pipeline_with_logprob_fast.py:630-637 and
+ * train_sd3_fast_pickscore.py:235-255: norms + adaLN modulation, fused q|k|v projections with QK RMSNorm, joint attention, gated
+ * output projections, [second attention,] gated GELU-tanh feed-forwards -- both streams, ~10 launches on `stream`, x / c updated in
+ * place.  bf16 everywhere, head dim 64; weights in nn.Linear layout [N, K] (the q | k | v weights of a projection stacked along N);
+ * mods [B, >= ..] bf16 holds the block's modulation rows, chunk j of the image stream at column mod_x + j D (j: shift_msa, scale_msa,
+ * gate_msa, shift_mlp, scale_mlp, gate_mlp [, shift_msa2, scale_msa2, gate_msa2]), of the text stream at mod_c + j D (last block:
+ * scale, shift).  rms_*: [2, 64] q / k RMSNorm weights, or NULL for no QK norm.  Bit-identical to the same launches issued one by
+ * one (adv_grpo_amd/mmdit.py does exactly that when a feature this entry does not cover is on: fp8 Linears, LoRA side columns). */
+typedef struct advgrpo_mmdit_block_desc {
+    int32_t B, Ni, Nt, D, H, dual, last;
+    void* x; void* c;                                            /* [B Ni, D], [B Nt, D] residual streams, updated in place */
+    const void* mods; int64_t mod_stride, mod_x, mod_c;          /* elements */
+    const void *qkv_w, *qkv_b, *cqkv_w, *cqkv_b, *out_w, *out_b, *cout_w, *cout_b, *qkv2_w, *qkv2_b, *out2_w, *out2_b;
+    const void *ff1_w, *ff1_b, *ff2_w, *ff2_b, *cff1_w, *cff1_b, *cff2_w, *cff2_b;
+    const void *rms_x, *rms_c, *rms_2;
+} advgrpo_mmdit_block_desc;
+int64_t advgrpo_mmdit_block_workspace_bytes(int B, int Ni, int Nt, int D, int dual);
+int advgrpo_mmdit_block_forward(const advgrpo_mmdit_block_desc* block, void* workspace /* 256-byte aligned */, int64_t workspace_bytes,
+                                void* stream);
+
 /* ------------------------------------------------------------------ fp8 Linears (BASELINE config 5: "fp8 MFMA path")
  * The reference has no fp8 code (config 5 changes pretrained.model / resolution only); the scheme is this
  * library's: OCP e4m3 codes, one f32 scale per token row of the activation and per output channel of the weight,

@@ -187,3 +187,36 @@ def test_precomputed_modulation_rows_are_bit_identical():
     t = ts[1].expand(B)
     assert torch.equal(model(lat, t, ctx, pooled, mods=mods_all[1], context=rows)[0], model(lat, t, ctx, pooled)[0])
     assert torch.equal(rows, keep)                      # the forward works on a copy: the rows serve the next step unchanged
+
+
+@pytest.mark.parametrize("size", ["small", "config2"])
+def test_c_level_block_entry_is_bit_identical_to_the_python_sequencing(size):
+    """advgrpo_mmdit_block_forward (csrc/mmdit_block.cpp: one C-ABI call per MMDiT block -- norms, fused q|k|v + QK-norm, joint attention,
+    gated output projections, second attention of the dual blocks, gated feed-forwards) against the same launches issued one by one from
+    Python: the velocity has the same bits; "config2" is the rollout's own shape (24 blocks of which 13 dual and the last text-free,
+    CFG batch 16 at 512^2: the 256 x 256 eight-phase GEMM with its paired launches)."""
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.mmdit import SD3Transformer2DModel
+    from oracle.mmdit import MMDiTConfig
+    if size == "small":
+        cfg = MMDiTConfig(num_layers=4, num_heads=4, joint_attention_dim=128, pooled_projection_dim=64, pos_embed_max_size=96, dual_attention_layers=(0, 2))
+        B, hw, Nt = 3, 16, 13
+        W = synthetic.mmdit_weights(cfg, 3)
+    else:
+        cfg, B, hw, Nt = MMDiTConfig(), 16, 64, 205
+        with synthetic.on_device("cuda"):
+            W = synthetic.mmdit_weights(cfg, 3)
+    model = SD3Transformer2DModel(W, cfg, "cuda")
+    g = torch.Generator(device="cuda").manual_seed(4)
+    lat = torch.randn(B, 16, hw, hw, device="cuda", generator=g).to(torch.bfloat16)
+    ctx = torch.randn(B, Nt, cfg.joint_attention_dim, device="cuda", generator=g).to(torch.bfloat16)
+    pooled = torch.randn(B, cfg.pooled_projection_dim, device="cuda", generator=g).to(torch.bfloat16)
+    t = torch.full((B,), 700.0, device="cuda")
+    assert model.c_block
+    (a,) = model(lat, t, ctx, pooled)
+    model.c_block = False
+    (b,) = model(lat, t, ctx, pooled)
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    model.c_block = True
+    (c,) = model(lat, t, ctx, pooled)              # cached descriptors, second call
+    assert torch.equal(a, c)

@@ -19,7 +19,7 @@ from adv_grpo_amd import hub, synthetic  # noqa: E402
 from adv_grpo_amd.model_configs import (ClipConfig, ClipTextConfig, DinoConfig, MMDiTConfig, QwenMMDiTConfig, QwenTextConfig,  # noqa: E402
                                         QwenVaeConfig, T5Config, VaeConfig)
 
-MM = MMDiTConfig(num_layers=3, num_heads=2, joint_attention_dim=64, pooled_projection_dim=32, pos_embed_max_size=16, dual_attention_layers=(0, 1))
+MM = MMDiTConfig(num_layers=3, num_heads=2, joint_attention_dim=64, pooled_projection_dim=64, pos_embed_max_size=16, dual_attention_layers=(0, 1))
 VAE = VaeConfig(block_out_channels=(32, 32, 64, 64), norm_num_groups=8)
 CL = ClipTextConfig(hidden=128, layers=2, heads=2, mlp=256, proj=64, vocab=300)
 CG = ClipTextConfig(hidden=192, layers=2, heads=3, mlp=384, proj=96, vocab=300, act="gelu")
@@ -62,6 +62,7 @@ def mmdit_json(c, **over):
 
 def write_sd3_snapshot(root, legacy_vae=False, MM=MM, VAE=VAE):
     """-> the dicts that were written (checkpoint dtypes: fp16 transformer / VAE, as released)."""
+    os.makedirs(root, exist_ok=True)
     json.dump({"_class_name": "StableDiffusion3Pipeline"}, open(os.path.join(root, "model_index.json"), "w"))
     W = {"transformer": synthetic.mmdit_weights(MM, 1), "vae": synthetic.vae_decoder_weights(VAE, 2), "text_encoder": synthetic.clip_text_weights(CL, 3),
          "text_encoder_2": synthetic.clip_text_weights(CG, 4), "text_encoder_3": synthetic.t5_encoder_weights(T5, 5)}
@@ -235,15 +236,15 @@ def test_loaded_models_match_dict_built_models(tmp_path):
     g = torch.Generator().manual_seed(0)
     lat = torch.randn(2, 16, 16, 16, generator=g).cuda().to(torch.bfloat16)
     ctx = torch.randn(2, 20, 64, generator=g).cuda().to(torch.bfloat16)
-    pooled = torch.randn(2, 32, generator=g).cuda().to(torch.bfloat16)
+    pooled = torch.randn(2, 64, generator=g).cuda().to(torch.bfloat16)
     t = torch.tensor([500.0, 500.0]).cuda()
     a = SD3Transformer2DModel({k: v.half() for k, v in W["transformer"].items()}, MM, "cuda")
     b = SD3Transformer2DModel(*out["transformer"], "cuda")
-    assert torch.equal(a(lat, ctx, pooled, t), b(lat, ctx, pooled, t))
+    assert torch.equal(a(lat, t, ctx, pooled)[0], b(lat, t, ctx, pooled)[0])
     va = AutoencoderKLDecoder({k: v.half().float() for k, v in W["vae"].items()}, FULL_VAE, "cuda", mode="bf16x3")
     vb = AutoencoderKLDecoder(*out["vae"], "cuda", mode="bf16x3")
     z = torch.randn(1, 16, 8, 8, generator=g).cuda()
-    assert torch.equal(va.decode(z), vb.decode(z))
+    assert torch.equal(va.decode_to_image(z), vb.decode_to_image(z))
     ids = torch.randint(3, 290, (2, 77), generator=g); ids[:, 30:] = 299
     for name, c in (("text_encoder", CL), ("text_encoder_2", CG)):
         ea = CLIPTextEncoder(W[name], c.layers, c.heads, c.act, c.eos_token_id)
