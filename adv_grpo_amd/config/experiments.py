@@ -18,6 +18,8 @@ DEFAULTS = {
                "num_image_per_prompt": 1, "test_batch_size": 1, "num_batches_per_epoch": 2, "global_std": True,
                # (build extension, not a reference field) prompt groups rolled out at the same time, each on its own HIP stream
                "groups_in_flight": 2,
+               # (build extension) the unconditional / conditional halves of every rollout forward as two forwards on two HIP streams (same bits)
+               "cfg_two_streams": False,
                "noise_level": 0.7, "same_latent": False},
     "train": {"batch_size": 1, "use_8bit_adam": False, "learning_rate": 3e-4, "adam_beta1": 0.9, "adam_beta2": 0.999,
               "adam_weight_decay": 1e-4, "adam_epsilon": 1e-8, "gradient_accumulation_steps": 1, "max_grad_norm": 1.0,

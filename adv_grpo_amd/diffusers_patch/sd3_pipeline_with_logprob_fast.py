@@ -88,12 +88,34 @@ def pipeline_with_logprob_random(self, prompt=None, prompt_2=None, prompt_3=None
             cur = noise_level
         else:
             cur = 0
-        inp = torch.cat([latents] * 2) if do_cfg else latents                  # PF:625
-        v = self.transformer(hidden_states=inp, timestep=t.expand(inp.shape[0]), encoder_hidden_states=tem_pe,
-                             pooled_projections=tem_ppe, joint_attention_kwargs=joint_attention_kwargs,
-                             return_dict=False, **({} if mods_all is None else {"mods": mods_all[i]}),
-                             **({} if ctx_rows is None else {"context": ctx_rows}))[0]                             # PF:630-637
-        vu, vt = (v[:B], v[B:]) if do_cfg else (v, None)
+        if do_cfg and getattr(self, "cfg_two_streams", False) and mods_all is not None and ctx_rows is not None:
+            # optional schedule (config `sample.cfg_two_streams`, bench.py's `cfg_two_streams` leg): the unconditional and the conditional half of the CFG batch are
+            # independent until the combine -- two forwards of batch B on two HIP streams instead of one of batch 2 B (every row of
+            # every kernel is independent of the others: the same bits)
+            main = torch.cuda.current_stream(device)
+            sides = self.__dict__.setdefault("_cfg_sides", {})                  # one side stream per calling stream (rollout threads)
+            side = sides.get(main.cuda_stream)
+            if side is None:
+                side = sides[main.cuda_stream] = torch.cuda.Stream(device=device)
+            Nt = tem_pe.shape[1]
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                vt = self.transformer(hidden_states=latents, timestep=t.expand(B), encoder_hidden_states=tem_pe[B:], pooled_projections=tem_ppe[B:],
+                                      return_dict=False, mods=mods_all[i][B:], context=ctx_rows[B * Nt:])[0]
+            latents.record_stream(side)
+            vu = self.transformer(hidden_states=latents, timestep=t.expand(B), encoder_hidden_states=tem_pe[:B], pooled_projections=tem_ppe[:B],
+                                  return_dict=False, mods=mods_all[i][:B], context=ctx_rows[:B * Nt])[0]
+            main.wait_stream(side)
+            vt.record_stream(main)
+        else:
+            inp = torch.cat([latents] * 2) if do_cfg else latents                  # PF:625
+            v = self.transformer(hidden_states=inp, timestep=t.expand(inp.shape[0]), encoder_hidden_states=tem_pe,
+                                 pooled_projections=tem_ppe, joint_attention_kwargs=joint_attention_kwargs,
+                                 return_dict=False, **({} if mods_all is None else {"mods": mods_all[i]}),
+                                 **({} if ctx_rows is None else {"context": ctx_rows}))[0]                             # PF:630-637
+            vu, vt = (v[:B], v[B:]) if do_cfg else (v, None)
         want_f32 = dtype == torch.float32
         nxt, cast, log_prob, _, _ = sde_step_cfg(                              # PF:640-655 fused
             self.scheduler, vu, vt, guidance_scale, None, latents, cur,

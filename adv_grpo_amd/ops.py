@@ -488,27 +488,25 @@ def _overlaps(a, b, dev):
 
 
 _CONCURRENT_LOCK = threading.Lock()
-_CONCURRENT_CACHE = {}          # (device, partner stream handles) -> stream measured to overlap them
 
 
-def concurrent_stream(device, partners=(), reuse=True):
+def concurrent_stream(device, partners=()):
     """A torch stream on `device` that is MEASURED to run concurrently with every stream in `partners` (default: the current
     stream): candidates from torch's pool are tried until one does (at most 8).  With more live streams than hardware queues
     not every pair can be concurrent -- name the partners that matter.
 
     The measurement drains the DEVICE (torch.cuda.synchronize) around micro-bursts of single-workgroup kernels, so it is only
     meaningful -- and only cheap -- while nothing else is enqueuing work: call it at construction time (Trainer / scorer / model
-    __init__), never from a worker thread beside running rollouts.  Calls are serialised by a module lock; the result
-    for a (device, partners) set is cached (reuse=True), so a second model built on the same stream pays nothing; if no candidate
-    overlaps, a warning says so and the last candidate is returned (work on it is then serialised behind a partner: slower, not wrong)."""
+    __init__), never from a worker thread beside running rollouts.  Calls are serialised by a module lock; if no
+    candidate overlaps, a warning says so and the last candidate is returned (work on it is then serialised behind a partner: slower,
+    not wrong).  The result is NOT cached across calls: a stream measured early in a process did not stay concurrent with the
+    launch stream once other streams had come and gone (bench.py's epoch leg behind its pricing legs: G-step micro-steps of 109 ms
+    with the reused stream against 88 ms with one measured when the model was built; round 5, same box)."""
     dev = torch.device(device)
     if dev.type != "cuda" or not torch.cuda.is_available():
         return None
     partners = list(partners or ()) or [torch.cuda.current_stream(dev)]
-    key = (str(dev), tuple(p.cuda_stream for p in partners))
     with _CONCURRENT_LOCK:
-        if reuse and key in _CONCURRENT_CACHE:
-            return _CONCURRENT_CACHE[key]
         cand, ok = None, False
         for _ in range(8):
             cand = torch.cuda.Stream(device=dev)
@@ -519,8 +517,6 @@ def concurrent_stream(device, partners=(), reuse=True):
             import warnings
             warnings.warn(f"adv_grpo_amd.ops.concurrent_stream: none of 8 candidate streams ran beside {len(partners)} partner stream(s) on {dev} "
                           "(all hardware queues shared? GPU_MAX_HW_QUEUES is read when the HIP runtime starts); side work will be serialised")
-        if reuse:
-            _CONCURRENT_CACHE[key] = cand
         return cand
 
 

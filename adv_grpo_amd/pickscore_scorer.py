@@ -79,7 +79,7 @@ class PickScoreScorer(torch.nn.Module):
         for main in mains:
             with self._text_streams_lock:
                 if main.cuda_stream not in self._text_streams:
-                    self._text_streams[main.cuda_stream] = ops.concurrent_stream(self.device, [main], reuse=False)
+                    self._text_streams[main.cuda_stream] = ops.concurrent_stream(self.device, [main])
 
     def _side_stream(self, main):
         """The text tower's stream for calls made on `main`: the towers are independent until the logits, and the text tower of

@@ -323,6 +323,7 @@ class Trainer:
                 s["ref_images"] = ref
             return s, first
 
+        self.pipe.cfg_two_streams = bool(c.sample.get("cfg_two_streams", False))     # the CFG halves of a forward on two HIP streams (same bits)
         in_flight = int(c.sample.get("groups_in_flight", 2))   # (the random SDE-window draw is per calling thread: pipeline.py)
         in_flight = max(1, min(in_flight, nb))
         t0 = time.perf_counter()

@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="N > 1 (or --spawn): bring the process group up, check that every rank is there (all-reduce of ones, device "
                          "names), time the path's two collectives alone, print that as the JSON line and stop -- no model is built")
+    ap.add_argument("--cfg-streams", action="store_true", help="experiment: the two halves of the CFG batch as two forwards on two HIP streams")
     ap.add_argument("--sync-scoring", action="store_true",
                     help="score each group on the launch stream right after its decode instead of on the reward-future stream (SURVEY 8a11)")
     ap.add_argument("--no-pricing", action="store_true",
@@ -572,6 +573,8 @@ def main():
     else:
         pipe, clip = build(device, large=c4, vae_mode=args.vae_mode)
     G, STEPS, T, RES = (4, 10, 2, 1024) if c4 else ((8, 10, 2, 1024) if c5 else (8, 10, 2, 512))
+    if args.cfg_streams:
+        pipe.cfg_two_streams = True
     sampler = DistributedKRepeatSampler(range(25432), 1, 1, world, rank, seed=42)   # k = 1: one group per rank
     # synthetic prompts: one embedding set per dataset index is not needed for timing; a fixed set per rank
     text_tower = None
@@ -814,6 +817,25 @@ def main():
             sync_ms = (time.perf_counter() - tl) / 3 * 1e3
             scoring.update(ms_per_step_if_sync=round(sync_ms, 2), value_if_sync=round(G / (sync_ms * 1e-3), 3),
                            frac_of_bf16_mfma_peak_if_sync=round(per_image_tflop * G / (sync_ms * 1e-3) / BF16_DENSE_PEAK_TFLOPS, 4))
+        # the same steps with the two halves of the CFG batch as two forwards on two HIP streams (one prompt group at a time still; the
+        # kernels of one half run in the ragged last rounds / epilogue bursts of the other's).  Priced, not the headline: with two streams a
+        # launch's HIP-event duration includes the other stream's kernels, so the per-kernel roofline is only defined for the schedule above.
+        cfg_streams = None
+        if not c5 and world == 1 and not args.no_pricing and not args.cfg_streams:
+            pipe.cfg_two_streams = True
+            keep_prof, ops.PROFILE = ops.PROFILE, None
+            steps_pipelined(0, 1)
+            torch.cuda.synchronize()
+            tl = time.perf_counter()
+            steps_pipelined(1, 3)
+            torch.cuda.synchronize()
+            c_ms = (time.perf_counter() - tl) / 3 * 1e3
+            pipe.cfg_two_streams = False
+            ops.PROFILE = keep_prof
+            cfg_streams = {"ms_per_step": round(c_ms, 2), "value": round(G / (c_ms * 1e-3), 3),
+                           "frac_of_bf16_mfma_peak": round(per_image_tflop * G / (c_ms * 1e-3) / BF16_DENSE_PEAK_TFLOPS, 4),
+                           "note": "unconditional and conditional half of the CFG batch as two batch-8 forwards on two HIP streams, combined in the SDE step as before: "
+                                   "bit-identical samples (tests/test_gpu_rollout.py); pipeline attribute cfg_two_streams"}
         # the same step with the block Linears of the MMDiT on fp8 e4m3 operands (BASELINE config 5's "fp8 MFMA path";
         # quantize.hip + gemm8p_fp8.hip).  Priced, not the headline: the reference has no fp8 arithmetic to match.
         fp8 = None
@@ -939,6 +961,7 @@ def main():
             "clock_and_power": power.summary(),
             "overlap": overlap,
             "scoring": scoring,
+            "cfg_two_streams": cfg_streams,
             "fp8_linears": fp8,
             **({"ocr": "stand-in recogniser (constant reward half): PaddleOCR is not in this image, adv_grpo_amd.ocr.OcrScorer runs with a callable that "
                        "returns a fixed string, so half of config 4's reward is a constant and the recognition phase costs nothing in this line"} if c4 else {}),

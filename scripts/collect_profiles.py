@@ -14,7 +14,8 @@ names = {"bench_c2.json": f"{pre}_bench_c2_full.json", "bench_c4.json": f"{pre}_
          "kernel_stats_c5.md": f"{pre}_kernel_stats_c5.md", "kernel_stats_c3_with_epoch_legs.md": f"{pre}_kernel_stats_c3_with_epoch_legs.md",
          "attention_d128.txt": f"{pre}_attention_d128.txt", "attention_bwd.txt": f"{pre}_attention_bwd.txt", "gstep_under_rocprof.txt": f"{pre}_gstep_under_rocprof.txt",
          "qwen_vae.txt": f"{pre}_qwen_vae.txt", "attention_bwd_d128.txt": f"{pre}_attention_bwd_d128.txt", "gstep_qwen.txt": f"{pre}_gstep_qwen.txt",
-         "kernel_stats_gstep_qwen_6_blocks.md": f"{pre}_kernel_stats_gstep_qwen_6_blocks.md"}
+         "kernel_stats_gstep_qwen_6_blocks.md": f"{pre}_kernel_stats_gstep_qwen_6_blocks.md",
+         "attention_fwd_d64.txt": f"{pre}_attention_fwd_d64.txt", "tn_grouped.txt": f"{pre}_tn_grouped.txt"}
 for a, b in names.items():
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b))

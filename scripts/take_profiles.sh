@@ -2,7 +2,7 @@
 # Re-takes every profiles/ artefact of a round on the GPU box (run through gpurun from the repo root):
 #   scripts/take_profiles.sh r3        -> gpurun_out/prof_r3/*  (copy the summaries into profiles/ afterwards: scripts/collect_profiles.py)
 set -x
-TAG=${1:-r4}
+TAG=${1:-r5}
 R=$PWD
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -18,6 +18,8 @@ python $R/scripts/rocpd_stats.py $O/kt_c5/x_results.db $O/kernel_stats_c5.md > /
 rocprofv3 --kernel-trace --stats -d $O/kt_c3 -o x -- python $R/bench.py --config c3 --steps 1 --warmup 1 --no-pricing > $O/bench_c3_prof.json 2>/dev/null
 python $R/scripts/rocpd_stats.py $O/kt_c3/x_results.db $O/kernel_stats_c3_with_epoch_legs.md > /dev/null
 python $R/scripts/bench_attention_d128.py 10 > $O/attention_d128.txt 2>/dev/null
+python $R/scripts/bench_attention.py 2>/dev/null | grep -v amdgpu > $O/attention_fwd_d64.txt
+python $R/scripts/bench_tn.py 2>/dev/null | grep -v amdgpu > $O/tn_grouped.txt
 python $R/scripts/bench_attention_bwd.py > $O/attention_bwd.txt 2>/dev/null
 # config 5's pieces: its VAE decoder, the head-dim-128 attention backward, one full-size G-step micro-batch, the kernel table of a 6-block one
 export PYTHONPATH=$R

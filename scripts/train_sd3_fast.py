@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--log", default="logs/train.jsonl")
     ap.add_argument("--groups-in-flight", type=int, default=None,
                     help="override sample.groups_in_flight (prompt groups rolled out concurrently on separate HIP streams)")
+    ap.add_argument("--cfg-streams", action="store_true",
+                    help="sample.cfg_two_streams: the unconditional and conditional halves of every rollout forward on two HIP streams (same samples)")
     ap.add_argument("--lora-mode", default="merged", choices=["merged", "side"],
                     help="merged: LoRA folded into the bf16 weights (default); side: PEFT's side-path arithmetic (TP:490-511)")
     ap.add_argument("--no-train-d", action="store_true", help="keep the discriminator frozen: every epoch is a G-step epoch")
@@ -79,6 +81,8 @@ def main():
         cfg.sample.mini_num_image_per_prompt = min(cfg.sample.mini_num_image_per_prompt, args.images_per_prompt)     # G = 4 (config 4)
     if args.groups_in_flight:
         cfg.sample.groups_in_flight = args.groups_in_flight
+    if args.cfg_streams:
+        cfg.sample.cfg_two_streams = True
     if args.no_train_d:
         cfg.train_d = False
     if args.batches:

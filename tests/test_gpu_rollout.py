@@ -134,3 +134,32 @@ def test_end_to_end_sample_decode_score_small_stack(qk_scale):
                                               C32["logit_scale"])
     print(f"C1 end-to-end PickScore: product {scores.tolist()} oracle {o_scores.tolist()} max |diff| {(scores - o_scores).abs().max().item():.3e}")
     assert (scores - o_scores).abs().max().item() < E2E_SCORE_TOL * max(1.0, o_scores.abs().max().item()), (scores, o_scores)
+
+
+def test_cfg_halves_on_two_streams_give_the_same_rollout():
+    """pipeline.cfg_two_streams: the unconditional and conditional halves of the CFG batch as two forwards on two HIP streams instead of one
+    forward of twice the batch (bench.py's `cfg_two_streams` leg).  Every row of every kernel of the transformer is independent of the other
+    rows, so the latents, log-probs and the decoded image of a rollout are bit-identical -- at a reduced depth and at config 2's full size
+    (where the halves take differently tiled launches: 8192 + 1640 rows instead of 16384 + 3280)."""
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.diffusers_patch.sd3_pipeline_with_logprob_fast import pipeline_with_logprob_random
+    from adv_grpo_amd.mmdit import SD3Transformer2DModel
+    from adv_grpo_amd.model_configs import MMDiTConfig, VaeConfig
+    from adv_grpo_amd.pipeline import SD3Pipeline
+    from adv_grpo_amd.vae import AutoencoderKLDecoder
+    with synthetic.on_device("cuda"):
+        vae = AutoencoderKLDecoder(synthetic.vae_decoder_weights(VaeConfig(), 22, fp16_checkpoint=True), VaeConfig(), "cuda")
+    for mcfg, G, hw, steps in ((MMDiTConfig(num_layers=3, num_heads=6, pos_embed_max_size=96, dual_attention_layers=(0, 1)), 3, 256, 4), (MMDiTConfig(), 8, 512, 3)):
+        with synthetic.on_device("cuda"):
+            pipe = SD3Pipeline(SD3Transformer2DModel(synthetic.mmdit_weights(mcfg, 21), mcfg, "cuda"), vae, "cuda")
+        pe, ppe, npe, nppe = (t.cuda().to(torch.bfloat16) for t in synthetic.prompt_embeddings(5))
+        kw = dict(prompt_embeds=pe, pooled_prompt_embeds=ppe, negative_prompt_embeds=npe, negative_pooled_prompt_embeds=nppe, num_inference_steps=steps,
+                  guidance_scale=4.5, height=hw, width=hw, noise_level=0.8, mini_num_image_per_prompt=G, train_num_steps=2, process_index=0,
+                  sample_num_steps=steps, random_timestep=0, seed=77, output_type="pt")
+        img_a, lats_a, lps_a, _ = pipeline_with_logprob_random(pipe, **kw)
+        pipe.cfg_two_streams = True
+        img_b, lats_b, lps_b, _ = pipeline_with_logprob_random(pipe, **kw)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(lats_a, lats_b)) and all(torch.equal(a, b) for a, b in zip(lps_a, lps_b))
+        assert torch.equal(img_a, img_b) and torch.isfinite(img_a).all()
+        del pipe
