@@ -53,8 +53,8 @@ class TnDesc(ctypes.Structure):
     """advgrpo_tn_desc (include/advgrpo.h), field for field."""
     _fields_ = [("P", _P), ("ldp", c_int64), ("p_seg_rows", c_int32), ("p_seg_stride", c_int64), ("p_seg_off", c_int64),
                 ("Q", _P), ("ldq", c_int64), ("q_seg_rows", c_int32), ("q_seg_stride", c_int64), ("q_seg_off", c_int64),
-                ("C", _P * 3), ("ldc", c_int64), ("transpose_out", c_int32),
-                ("M", c_int32), ("N1", c_int32), ("NQ", c_int32), ("alpha", c_float)]
+                ("C", _P), ("ldc", c_int64), ("transpose_out", c_int32),
+                ("M", c_int32), ("N1", c_int32), ("alpha", c_float)]
 
 
 class Fp8Scales(ctypes.Structure):

@@ -204,9 +204,11 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
 // products of the adapters that share an input -- in ONE launch, and no reduce kernel.
 //   * a launch carries up to TN_MAX problems (advgrpo_tn_desc); a workgroup finds its (problem, 128-column tile, token slice) from
 //     the problems' workgroup prefix (wave-uniform scan over at most TN_MAX entries);
-//   * Q may be 64 * NQB wide (NQB = 1 or 3): the three adapters of a fused q | k | v projection share their input X, so
-//     dA_j = s (dY_j B_j)^T X for j = 0..2 is ONE pass over X against u = [u_0 | u_1 | u_2] instead of three (X is the 50 MB
-//     operand); the output rows of adapter j go to its own C[j];
+//   * the dA products of the adapters that share an input X (the three of a fused q | k | v projection) are three problems of the SAME
+//     launch: their workgroups run side by side and X comes from HBM once, from L2 / the Infinity Cache twice.  (A 192-wide Q -- one
+//     pass over X against [u_q | u_k | u_v], three outputs -- was built and measured: 110 us for the two dA problems of a group at
+//     config 2 beside 68 us for its six dB problems, against 118 us for all TWELVE as 64-wide problems of one launch; scripts/bench_tn.py.
+//     Its 40 KiB stages allow fewer workgroups per CU and its 96 KiB partial tiles make the last workgroup's sum the long pole.)
 //   * slices of the token range meet in the workspace, and the LAST workgroup to arrive at a tile (agent-scope counter) adds the
 //     slices in slice order into C: a fixed summation order whoever arrives last -- bitwise reproducible, no float atomics -- and the
 //     separate reduce launch is gone.  XCD L2s are not coherent with each other: partial tiles are written and read with agent-scope
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
 //     leaves the counter at zero for the next launch.
 constexpr int TN_MAX = 12;
 struct TnProblem {
-    const bf16_t* P; const bf16_t* Q; float* C[3];
+    const bf16_t* P; const bf16_t* Q; float* C;
     int64_t ldp, p_seg_stride, p_seg_off, ldq, q_seg_stride, q_seg_off, ldc, ws_off;
     int p_seg_rows, q_seg_rows, transpose_out, M, N1, tiles, slices, chunks_per_block, wg0, cnt_off;
     float alpha;
@@ -261,10 +263,9 @@ __device__ __forceinline__ void tn_cur_advance(TnCur& c, int step, uint32_t step
     }
 }
 
-template <int NQB>
 __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroup grp) {
-    // tokens per stage: 64 with a 64-wide Q (24 KiB per stage), 32 with a 192-wide one (20 KiB): three stages, two workgroups per CU
-    constexpr int MC = NQB == 1 ? 64 : 32, NS = 3, NQ = 64 * NQB, KC = MC / 32;
+    constexpr int NQB = 1;                       // Q is 64 columns wide
+    constexpr int MC = 64, NS = 3, NQ = 64 * NQB, KC = MC / 32;      // 64 tokens (24 KiB) per stage, three stages, two workgroups per CU
     constexpr int P_BYTES = MC * 256, Q_ROW = 128 * NQB, Q_BYTES = MC * Q_ROW, STAGE = P_BYTES + Q_BYTES;
     constexpr int PI = P_BYTES / 4096, QI = Q_BYTES / 4096;            // DMA instructions per wave per stage (1 KiB each, 4 waves)
     constexpr int LOADS = PI + QI;
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroup g
         const int n1 = n1_0 + wave * 32 + nb * 16 + t;
 #pragma unroll
         for (int qn = 0; qn < 4 * NQB; ++qn) {
-            const float* C = p.C[qn >> 2];                              // adapter qn / 4 of the group
+            const float* C = p.C;
             const int n2 = (qn & 3) * 16 + g * 4;
             if (p.transpose_out) {
 #pragma unroll
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroup g
 #pragma unroll
         for (int qn = 0; qn < 4 * NQB; ++qn) {
             const tn_f32x4 out = cur[nb][qn] + acc[nb][qn] * p.alpha;
-            float* C = p.C[qn >> 2];
+            float* C = p.C;
             const int n2 = (qn & 3) * 16 + g * 4;
             if (p.transpose_out) {
 #pragma unroll
@@ -528,7 +529,7 @@ extern "C" int64_t advgrpo_gemm_tn_grouped_workspace_bytes(const advgrpo_tn_desc
     for (int i = 0; i < n; ++i) {
         const int nchunks = (d[i].M + 63) / 64;
         const int slices = nchunks < 64 ? (nchunks < 1 ? 1 : nchunks) : 64;     // (64: room for the EXPERIMENTS build's slice knob)        // upper bound of what the launcher picks
-        f += (int64_t)slices * d[i].N1 * d[i].NQ;
+        f += (int64_t)slices * d[i].N1 * 64;
     }
     return f * 4 + TN_CNT_BYTES;
 }
@@ -536,16 +537,13 @@ extern "C" int64_t advgrpo_gemm_tn_grouped_workspace_bytes(const advgrpo_tn_desc
 extern "C" int advgrpo_gemm_tn_grouped(const advgrpo_tn_desc* d, int n, void* workspace, int64_t workspace_bytes,
                                        int workspace_is_zeroed, void* stream) {
     ADVGRPO_CHECK(d && n > 0 && n <= TN_MAX && workspace, "gemm_tn_grouped: 1..%d problems and a workspace", TN_MAX);
-    const int NQ = d[0].NQ;
-    ADVGRPO_CHECK(NQ == 64 || NQ == 192, "gemm_tn_grouped: Q is 64 or 192 columns wide (got %d)", NQ);
+    constexpr int NQ = 64;
     TnGroup g{};
     g.n = n;
     int64_t chunks_total = 0;
     for (int i = 0; i < n; ++i) {
         const advgrpo_tn_desc& a = d[i];
-        ADVGRPO_CHECK(a.P && a.Q && a.C[0] && a.M > 0, "gemm_tn_grouped: problem %d: bad argument", i);
-        ADVGRPO_CHECK(a.NQ == NQ, "gemm_tn_grouped: every problem of a launch has the same Q width");
-        ADVGRPO_CHECK(NQ == 64 || (a.C[1] && a.C[2]), "gemm_tn_grouped: a 192-wide Q needs three outputs");
+        ADVGRPO_CHECK(a.P && a.Q && a.C && a.M > 0, "gemm_tn_grouped: problem %d: bad argument", i);
         ADVGRPO_CHECK(a.N1 > 0 && a.N1 % 128 == 0, "gemm_tn_grouped: N1 %% 128 == 0 (N1=%d)", a.N1);
         ADVGRPO_CHECK(a.ldp % 8 == 0 && a.ldq % 8 == 0 && (reinterpret_cast<uintptr_t>(a.P) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.Q) & 15) == 0,
                       "gemm_tn_grouped: operands must be 16-byte aligned with pitches that are multiples of 8");
@@ -556,14 +554,14 @@ extern "C" int advgrpo_gemm_tn_grouped(const advgrpo_tn_desc* d, int n, void* wo
                               (last_row(a.M, a.q_seg_rows, a.q_seg_stride, a.q_seg_off) + 1) * a.ldq * 2 < (1ll << 32),
                           "gemm_tn_grouped: problem %d: an operand spans 4 GiB or more (32-bit byte offsets)", i);
         }
-        ADVGRPO_CHECK(a.transpose_out || (a.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C[0]) & 15) == 0), "gemm_tn_grouped: C rows must be 16-byte aligned");
+        ADVGRPO_CHECK(a.transpose_out || (a.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0), "gemm_tn_grouped: C rows must be 16-byte aligned");
         chunks_total += (int64_t)(a.M + 63) / 64 * (a.N1 / 128);
     }
     // ~768 workgroups per launch (NQB = 1: two per CU), at most TN_MAX_SLICES token slices per problem and at least 8 chunks (512 tokens)
     // per slice
     // (same-box sweep at the config-2 shapes, scripts/bench_tn.py: 4 / 8 / 16 / 32 slices -> 77 / 70 / 100 / 104 us for the six dB problems of a
-    //  q | k | v group and 136 / 107 / 130 / 181 us for its two 192-wide dA problems; 384 .. 1536 target workgroups within 5 %)
-    int64_t target = NQ == 64 ? 768 : 384;
+    //  q | k | v group; 384 .. 1536 target workgroups within 5 %)
+    int64_t target = 768;
     int max_slices = TN_MAX_SLICES;
 #ifdef ADVGRPO_EXPERIMENTS
     { const char* e = getenv("ADVGRPO_TNG_TARGET"); if (e && atoi(e) > 0) target = atoi(e); }
@@ -583,7 +581,7 @@ extern "C" int advgrpo_gemm_tn_grouped(const advgrpo_tn_desc* d, int n, void* wo
         p.slices = (nchunks + c - 1) / c;
         p.tiles = a.N1 / 128;
         p.P = (const bf16_t*)a.P; p.Q = (const bf16_t*)a.Q;
-        for (int j = 0; j < 3; ++j) p.C[j] = a.C[j];
+        p.C = a.C;
         p.ldp = a.ldp; p.p_seg_rows = a.p_seg_rows; p.p_seg_stride = a.p_seg_stride; p.p_seg_off = a.p_seg_off;
         p.ldq = a.ldq; p.q_seg_rows = a.q_seg_rows; p.q_seg_stride = a.q_seg_stride; p.q_seg_off = a.q_seg_off;
         p.ldc = a.ldc; p.transpose_out = a.transpose_out; p.M = a.M; p.N1 = a.N1; p.alpha = a.alpha;
@@ -603,17 +601,10 @@ extern "C" int advgrpo_gemm_tn_grouped(const advgrpo_tn_desc* d, int n, void* wo
     if (!workspace_is_zeroed) {
         if (hipMemsetAsync(workspace, 0, TN_CNT_BYTES, s) != hipSuccess) { set_error("gemm_tn_grouped: memset failed"); return -2; }
     }
-    if (NQ == 64) {
-        constexpr int LDS = 3 * (64 * 256 + 64 * 128);
-        static bool attr1 = false;
-        if (!attr1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_grouped_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr1 = true; }
-        hipLaunchKernelGGL(gemm_tn_grouped_kernel<1>, dim3(wg), dim3(256), LDS, s, g);
-    } else {
-        constexpr int LDS = 3 * (32 * 256 + 32 * 384);
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_grouped_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
-        hipLaunchKernelGGL(gemm_tn_grouped_kernel<3>, dim3(wg), dim3(256), LDS, s, g);
-    }
+    constexpr int LDS = 3 * (64 * 256 + 64 * 128);
+    static bool attr1 = false;
+    if (!attr1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr1 = true; }
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(wg), dim3(256), LDS, s, g);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

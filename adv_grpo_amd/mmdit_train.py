@@ -444,25 +444,20 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             self._lora_wgrad_group_now(items)
 
     def _lora_wgrad_group_now(self, items):
-        """Adapter gradients of one Linear group, both streams: 2 skinny GEMM launches (t = X A^T, u = dY . blockdiag(B)) and 1 - 2 grouped
-        token-contracted launches (csrc/gemm_tn.hip, grouped form) instead of 5 n + 1 launches per stream (round 4: 44 per block):
-          dB_j += s dY_j^T t_j              one problem per adapter, all in one launch
-          dA_j += s u_j^T X                 ONE problem per stream: the n adapters share X, u = [u_0 | .. | u_{n-1}] is 64 n wide
-        (n = 3: the 192-wide problems take their own launch, the kernel is instantiated per Q width)."""
+        """Adapter gradients of one Linear group, both streams: 2 skinny GEMM launches (t = X A^T, u = dY . blockdiag(B)) and ONE grouped
+        token-contracted launch (csrc/gemm_tn.hip, grouped form) instead of 5 n + 1 launches per stream (round 4: 44 per block, now 6):
+          dB_j += s dY_j^T t_j      and      dA_j += s u_j^T X            two problems per adapter, all in the one launch
+        (the adapters of a fused q | k | v projection share X: their dA workgroups run side by side and X comes from HBM once)."""
         D = self.cfg.dim
         ts = ops.gemm_grouped([ops.gemm_desc(X, self._lora[key][0], a_seg=x_seg, M=M) for key, X, M, x_seg, dY, dy_seg in items])
         us = ops.gemm_grouped([ops.gemm_desc(dY, self._lora[key][3], a_seg=dy_seg, M=M) for key, X, M, x_seg, dY, dy_seg in items])
-        narrow, wide = [], []
+        descs = []
         for (key, X, M, x_seg, dY, dy_seg), t, u in zip(items, ts, us):
-            ads = self._lora[key][2]
-            for j, ad in enumerate(ads):
-                narrow.append(ops.tn_desc(dY[:, j * D:(j + 1) * D], t[:, j * RPAD:(j + 1) * RPAD], self.B_view(ad, self.grads), alpha=self.scale,
-                                          M=M, p_seg=dy_seg))
-            gAs = [self.A_view(ad, self.grads) for ad in ads]
-            (narrow if len(ads) == 1 else wide).append(ops.tn_desc(X, u, gAs, alpha=self.scale, M=M, p_seg=x_seg, transpose_out=True))
-        ops.gemm_tn_grouped(narrow)
-        if wide:
-            ops.gemm_tn_grouped(wide)
+            for j, ad in enumerate(self._lora[key][2]):
+                cols = slice(j * RPAD, (j + 1) * RPAD)
+                descs.append(ops.tn_desc(dY[:, j * D:(j + 1) * D], t[:, cols], self.B_view(ad, self.grads), alpha=self.scale, M=M, p_seg=dy_seg))
+                descs.append(ops.tn_desc(X, u[:, cols], self.A_view(ad, self.grads), alpha=self.scale, M=M, p_seg=x_seg, transpose_out=True))
+        ops.gemm_tn_grouped(descs)                       # (2 problems per adapter: 12 for the q | k | v groups of both streams, 4 for the output projections)
 
     # ------------------------------------------------------------------ explicit backward
     @torch.no_grad()

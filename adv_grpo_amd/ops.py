@@ -843,28 +843,24 @@ _TN_WS = {}
 _TNG_WS = {}
 
 
-def tn_desc(P, Q, outs, alpha=1.0, M=None, p_seg=None, q_seg=None, transpose_out=False):
-    """One problem of gemm_tn_grouped: outs[j][n1, n2] (or [n2, n1] with transpose_out) += alpha * sum_m P[row_p(m), n1] * Q[row_q(m), 64 j + n2];
-    P [.., N1] and Q [.., 64 * len(outs)] bf16 token-major views, outs: 1 or 3 f32 matrices of one row pitch."""
-    outs = list(outs) if isinstance(outs, (list, tuple)) else [outs]
-    assert P.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16 and all(o.dtype == torch.float32 and o.stride(1) == 1 for o in outs)
-    assert P.stride(1) == 1 and Q.stride(1) == 1 and len(outs) in (1, 3) and Q.shape[1] == 64 * len(outs)
-    assert all(o.stride(0) == outs[0].stride(0) for o in outs)
+def tn_desc(P, Q, out, alpha=1.0, M=None, p_seg=None, q_seg=None, transpose_out=False):
+    """One problem of gemm_tn_grouped: out[n1, n2] (or out[n2, n1] with transpose_out) += alpha * sum_m P[row_p(m), n1] * Q[row_q(m), n2];
+    P [.., N1] and Q [.., 64] bf16 token-major views, out f32 holding the running sum."""
+    assert P.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16 and out.dtype == torch.float32
+    assert P.stride(1) == 1 and Q.stride(1) == 1 and out.stride(1) == 1 and Q.shape[1] == 64
     d = _lib.TnDesc()
     ps, qs = p_seg or (0, 0, 0), q_seg or (0, 0, 0)
     d.P, d.ldp, d.p_seg_rows, d.p_seg_stride, d.p_seg_off = P.data_ptr(), P.stride(0), int(ps[0]), int(ps[1]), int(ps[2])
     d.Q, d.ldq, d.q_seg_rows, d.q_seg_stride, d.q_seg_off = Q.data_ptr(), Q.stride(0), int(qs[0]), int(qs[1]), int(qs[2])
-    for j, o in enumerate(outs):
-        d.C[j] = o.data_ptr()
-    d.ldc, d.transpose_out = outs[0].stride(0), int(transpose_out)
-    d.M, d.N1, d.NQ, d.alpha = (P.shape[0] if M is None else M), P.shape[1], Q.shape[1], float(alpha)
-    d._keep = (P, Q, outs)
+    d.C, d.ldc, d.transpose_out = out.data_ptr(), out.stride(0), int(transpose_out)
+    d.M, d.N1, d.alpha = (P.shape[0] if M is None else M), P.shape[1], float(alpha)
+    d._keep = (P, Q, out)
     return d
 
 
 def gemm_tn_grouped(descs):
-    """All token-contracted products of an adapter group in one launch (csrc/gemm_tn.hip, grouped form): descs from tn_desc, all with
-    the same Q width.  One workspace per launch stream, used by nothing else (its arrival counters stay zero between launches)."""
+    """All token-contracted products of an adapter group in one launch (csrc/gemm_tn.hip, grouped form): up to 12 descs from tn_desc.
+    One workspace per launch stream, used by nothing else (its arrival counters stay zero between launches)."""
     lib = _lib.load()
     arr = (_lib.TnDesc * len(descs))(*descs)
     need = int(lib.advgrpo_gemm_tn_grouped_workspace_bytes(arr, len(descs)))

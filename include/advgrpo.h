@@ -478,18 +478,17 @@ int advgrpo_gemm_tn_f32acc(const void* P, int64_t ldp, int p_seg_rows, int64_t p
                            void* workspace /* advgrpo_gemm_tn_workspace_bytes(M, N1), 16-byte aligned */, void* stream);
 int64_t advgrpo_gemm_tn_workspace_bytes(int M, int N1);
 /* The same products for a whole adapter group in ONE launch (round 5): up to 12 problems, each
- *   C_j[n1, n2] += alpha * sum_m P[row_p(m), n1] * Q[row_q(m), 64 j + n2]     (j < NQ / 64; transpose_out: C_j[n2 * ldc + n1])
- * with Q 64 or 192 columns wide (every problem of a launch the same).  NQ = 192 is the dA of the three adapters of a fused q | k | v
- * projection in one pass over their shared input X (P = X, Q = [dY_q B_q | dY_k B_k | dY_v B_v], three outputs).  Token slices meet
- * in `workspace` and the last workgroup to reach a tile adds them in slice order (reproducible; no float atomics, no reduce launch).
- * workspace: 256-byte aligned, advgrpo_gemm_tn_grouped_workspace_bytes(descs, n) bytes, its first 4096 bytes (arrival counters) zero
- * at every launch -- a workspace only ever used by this function stays that way (workspace_is_zeroed = 1); 0 = memset first.
- * Reference site: the LoRA layers' weight gradients inside loss.backward() (TP:490-511, TP:1165). */
+ *   C[n1, n2] += alpha * sum_m P[row_p(m), n1] * Q[row_q(m), n2]     (Q 64 wide; transpose_out: C[n2 * ldc + n1])
+ * -- the dB of every adapter of a group (P = dY_j, Q = X A_j^T) and the dA of every adapter (P = X, Q = dY_j B_j, transposed) together.
+ * Token slices meet in `workspace` and the last workgroup to reach a tile adds them in slice order (reproducible; no float atomics,
+ * no reduce launch).  workspace: 256-byte aligned, advgrpo_gemm_tn_grouped_workspace_bytes(descs, n) bytes, its first 4096 bytes
+ * (arrival counters) zero at every launch -- a workspace only ever used by this function stays that way (workspace_is_zeroed = 1);
+ * 0 = memset first.  Reference site: the LoRA layers' weight gradients inside loss.backward() (TP:490-511, TP:1165). */
 typedef struct advgrpo_tn_desc {
     const void* P; int64_t ldp; int32_t p_seg_rows; int64_t p_seg_stride, p_seg_off;      /* wide operand [M, N1] bf16, token-major */
-    const void* Q; int64_t ldq; int32_t q_seg_rows; int64_t q_seg_stride, q_seg_off;      /* [M, NQ] bf16 */
-    float* C[3]; int64_t ldc; int32_t transpose_out;
-    int32_t M, N1, NQ;
+    const void* Q; int64_t ldq; int32_t q_seg_rows; int64_t q_seg_stride, q_seg_off;      /* [M, 64] bf16 */
+    float* C; int64_t ldc; int32_t transpose_out;
+    int32_t M, N1;
     float alpha;
 } advgrpo_tn_desc;
 int64_t advgrpo_gemm_tn_grouped_workspace_bytes(const advgrpo_tn_desc* descs, int n);

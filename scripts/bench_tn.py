@@ -28,13 +28,20 @@ def dB_single():
         ops.gemm_tn(dqkv[:, j * D:(j + 1) * D], t_i[:, 64 * j:64 * j + 64], gB[j], alpha=2.0, M=Mi, p_seg=seg_i)
         ops.gemm_tn(dqkv[:, j * D:(j + 1) * D], t_t[:, 64 * j:64 * j + 64], gB[3 + j], alpha=2.0, M=Mt, p_seg=seg_t)
 def dA_grouped():
-    ops.gemm_tn_grouped([ops.tn_desc(nx, u_i, gA[:3], alpha=2.0, M=Mi, transpose_out=True), ops.tn_desc(nc, u_t, gA[3:], alpha=2.0, M=Mt, transpose_out=True)])
+    ops.gemm_tn_grouped([ops.tn_desc(nx, u_i[:, 64 * j:64 * j + 64], gA[j], alpha=2.0, M=Mi, transpose_out=True) for j in range(3)] +
+                        [ops.tn_desc(nc, u_t[:, 64 * j:64 * j + 64], gA[3 + j], alpha=2.0, M=Mt, transpose_out=True) for j in range(3)])
 def dA_single():
     for j in range(3):
         ops.gemm_tn(nx, u_i[:, 64 * j:64 * j + 64], gA[j], alpha=2.0, M=Mi, transpose_out=True)
         ops.gemm_tn(nc, u_t[:, 64 * j:64 * j + 64], gA[3 + j], alpha=2.0, M=Mt, transpose_out=True)
+def all_narrow():          # dB and dA of the group as twelve problems in ONE launch (X is read three times, twice of them from L2 / the Infinity Cache)
+    ops.gemm_tn_grouped([ops.tn_desc(dqkv[:, j * D:(j + 1) * D], t_i[:, 64 * j:64 * j + 64], gB[j], alpha=2.0, M=Mi, p_seg=seg_i) for j in range(3)] +
+                        [ops.tn_desc(dqkv[:, j * D:(j + 1) * D], t_t[:, 64 * j:64 * j + 64], gB[3 + j], alpha=2.0, M=Mt, p_seg=seg_t) for j in range(3)] +
+                        [ops.tn_desc(nx, u_i[:, 64 * j:64 * j + 64], gA[j], alpha=2.0, M=Mi, transpose_out=True) for j in range(3)] +
+                        [ops.tn_desc(nc, u_t[:, 64 * j:64 * j + 64], gA[3 + j], alpha=2.0, M=Mt, transpose_out=True) for j in range(3)])
 bytes_dB = 3 * (Mi + Mt) * (D + 64) * 2
 for name, fn, b in (("dB q|k|v, both streams: 6 problems, one grouped launch", dB_grouped, bytes_dB), ("dB: 6 launches + 6 reduces (round 4)", dB_single, bytes_dB),
-                    ("dA q|k|v, both streams: 2 problems 192 wide, one launch", dA_grouped, (Mi + Mt) * (D + 192) * 2), ("dA: 6 launches + 6 reduces (round 4)", dA_single, 3 * (Mi + Mt) * (D + 64) * 2)):
+                    ("dA q|k|v, both streams: 6 problems (X shared by three), one launch", dA_grouped, 3 * (Mi + Mt) * (D + 64) * 2), ("dA: 6 launches + 6 reduces (round 4)", dA_single, 3 * (Mi + Mt) * (D + 64) * 2),
+                    ("dB + dA of the group: twelve problems, ONE launch (the product's)", all_narrow, 2 * bytes_dB)):
     us = timed(fn)
     print(f"{name:62s} {us:8.1f} us   {b / us / 1e6:5.2f} TB/s of its own operand bytes")

@@ -466,56 +466,52 @@ def test_gemm_tn_token_contraction(M, seg):
 
 def test_gemm_tn_grouped_matches_torch_and_is_reproducible():
     """The grouped token-contracted launch (csrc/gemm_tn.hip, round 5): several problems of different token counts in one launch -- plain
-    and transposed outputs, a row map on P, a ragged last stage, token ranges long enough to be split into slices that meet in the
-    workspace (the last workgroup at a tile adds them in slice order) -- and the 192-wide form with three outputs; against fp32 torch,
-    accumulating into non-zero outputs; two launches on the same data give the same bits (no float atomics), and a launch leaves the
-    workspace's arrival counters at zero."""
+    and transposed outputs, row maps on P (long and shorter-than-a-stage segments), a ragged last stage, token ranges long enough to be
+    split into slices that meet in the workspace (the last workgroup at a tile adds them in slice order), three problems that share
+    their P (the dA of a fused q | k | v projection) -- against fp32 torch, accumulating into non-zero outputs; two launches on the same
+    data give the same bits (no float atomics), a launch leaves the workspace's arrival counters at zero, twelve problems fit one launch."""
     from adv_grpo_amd import ops
     g = torch.Generator(device="cuda").manual_seed(21)
     rnd = lambda *s: torch.randn(*s, device="cuda", generator=g).to(torch.bfloat16)
     N1 = 384
 
-    def problem(M, seg, nq, transpose_out, alpha):
+    def problem(M, seg, transpose_out, alpha, P=None):
         rows = M if seg is None else (M // seg[0]) * seg[1] + 8
-        P = rnd(rows, N1 + 64)[:, 64:]
-        Q = rnd(M, 64 * nq)
+        P = rnd(rows, N1 + 64)[:, 64:] if P is None else P
+        Q = rnd(M, 64)
         idx = torch.arange(M, device="cuda")
         Pm = (P[:M] if seg is None else P[(idx // seg[0]) * seg[1] + seg[2] + idx % seg[0]]).float()
-        ref = alpha * Pm.t() @ Q.float()                                             # [N1, 64 nq]
-        outs = [torch.full((64, N1) if transpose_out else (N1, 64), 0.25, dtype=torch.float32, device="cuda") for _ in range(nq)]
-        return (P, Q, outs, alpha, M, seg, transpose_out), ref
+        ref = alpha * Pm.t() @ Q.float()                                             # [N1, 64]
+        out = torch.full((64, N1) if transpose_out else (N1, 64), 0.25, dtype=torch.float32, device="cuda")
+        return (P, Q, out, alpha, M, seg, transpose_out), ref
 
     def run(specs):
-        descs = [ops.tn_desc(P, Q, outs, alpha=a, M=M, p_seg=seg, transpose_out=tr) for (P, Q, outs, a, M, seg, tr) in specs]
-        ops.gemm_tn_grouped(descs)
+        ops.gemm_tn_grouped([ops.tn_desc(P, Q, out, alpha=a, M=M, p_seg=seg, transpose_out=tr) for (P, Q, out, a, M, seg, tr) in specs])
 
     def check(specs, refs):
-        for (P, Q, outs, a, M, seg, tr), ref in zip(specs, refs):
-            for j, o in enumerate(outs):
-                got = (o.t() if tr else o) - 0.25
-                want = ref[:, 64 * j:64 * (j + 1)]
-                assert torch.allclose(got, want, rtol=2e-3, atol=2e-3 * want.abs().max().item()), (M, seg, tr, j, (got - want).abs().max().item())
+        for (P, Q, o, a, M, seg, tr), want in zip(specs, refs):
+            got = (o.t() if tr else o) - 0.25
+            assert torch.allclose(got, want, rtol=2e-3, atol=2e-3 * want.abs().max().item()), (M, seg, tr, (got - want).abs().max().item())
 
-    cases = [problem(16384, None, 1, False, 2.0), problem(16 * 205, (205, 1229, 1024), 1, False, 2.0), problem(100, None, 1, True, 0.5),
-             problem(4096 + 37, None, 1, True, 1.0), problem(8 * 1024, (1024, 1229, 0), 1, False, 1.0),
-             problem(40 * 20, (20, 36, 16), 1, False, 1.0)]            # segments shorter than a 64-token stage: several wraps per step
+    shared = rnd(16384, N1)
+    cases = [problem(16384, None, False, 2.0), problem(16 * 205, (205, 1229, 1024), False, 2.0), problem(100, None, True, 0.5),
+             problem(4096 + 37, None, True, 1.0), problem(8 * 1024, (1024, 1229, 0), False, 1.0),
+             problem(40 * 20, (20, 36, 16), False, 1.0),              # segments shorter than a 64-token stage: several wraps per step
+             problem(16384, None, True, 2.0, P=shared), problem(16384, None, True, 2.0, P=shared), problem(16384, None, True, 2.0, P=shared),
+             problem(777, None, False, 1.0), problem(64, None, False, 1.0), problem(1, None, True, 1.0)]
+    assert len(cases) == 12
     specs, refs = [c[0] for c in cases], [c[1] for c in cases]
     run(specs)
     check(specs, refs)
-    first = [[o.clone() for o in sp[2]] for sp in specs]
+    first = [sp[2].clone() for sp in specs]
     for sp in specs:
-        for o in sp[2]:
-            o.fill_(0.25)
+        sp[2].fill_(0.25)
     run(specs)
-    assert all(torch.equal(a, b) for sp, f in zip(specs, first) for a, b in zip(sp[2], f))
-    # three adapters that share P: Q 192 wide, three transposed outputs
-    wide = [problem(16384, None, 3, True, 2.0), problem(3 * 205, (205, 333, 128), 3, True, 2.0)]
-    run([c[0] for c in wide])
-    check([c[0] for c in wide], [c[1] for c in wide])
+    assert all(torch.equal(sp[2], f) for sp, f in zip(specs, first))
     ws = next(iter(ops._TNG_WS.values()))
     assert (ws[:4096] == 0).all()
-    with pytest.raises(Exception, match="same Q width"):
-        run([cases[0][0], wide[0][0]])
+    with pytest.raises(Exception, match="1..12 problems"):
+        run(specs + specs[:1])
 
 
 def test_mmdit_lora_backward_full_size_vs_autograd():
