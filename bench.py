@@ -710,6 +710,14 @@ def main():
         dt = tmax.item()
         scaling_diag = scaling_diagnostics(dist, device, world, rank, G, T, dt_local, dt, args.steps, step, D)
 
+    # The epoch leg runs HERE, right behind the timed steps, for every configuration whose two model sets fit one GPU side by side (all but
+    # config 5): behind the pricing legs below -- which create and drop a dozen HIP streams -- its rollout and adapter-gradient streams landed
+    # on shared hardware queues (round 5, same box: sampling phase 0.89 s against 0.74 s, and 109 ms micro-steps with a re-used side stream).
+    run_epoch = not args.no_epoch                  # at every N: for N > 1 this is the leg with the LoRA-gradient all-reduce (TP:1165)
+    ep_early = None
+    if run_epoch and not c5:                        # every rank takes part (LoRA-gradient all-reduce, reward gather)
+        ep_early = full_epoch(device, world, rank, adversarial=c3, qwen=False, large=c4)
+
     if rank == 0:
         # ---- roofline of the dominant kernel from the HIP events recorded around every GEMM launch
         per = {}
@@ -974,15 +982,15 @@ def main():
                      "ms_per_step": lora_ms,
                      "value_if_side": round(world * G / (lora_ms["side"] * 1e-3), 3) if "side" in lora_ms else None},
         }
-    run_epoch = not args.no_epoch                  # at every N: for N > 1 this is the leg with the LoRA-gradient all-reduce (TP:1165)
-    if run_epoch:                                   # every rank takes part (LoRA-gradient all-reduce, reward gather)
-        if c3 or c5:
-            del dino, dino_head
+    if ep_early is not None and rank == 0:
+        res["epoch"] = ep_early
+    if run_epoch and c5:                            # config 5: the rollout's model set has to go first (155 GiB for the epoch's own)
+        del dino, dino_head
         del pipe, clip
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        ep = full_epoch(device, world, rank, adversarial=c3 or c5, qwen=c5, large=c4)
+        ep = full_epoch(device, world, rank, adversarial=True, qwen=True, large=False)
         if rank == 0:
             res["epoch"] = ep
     if rank == 0:
