@@ -178,9 +178,13 @@ class SD3Transformer2DModel:
                 d.mod_x, d.mod_c = self.mod_off[("x", i)], self.mod_off[("c", i)]
                 d._weights = b.get("qkv.w")
                 self._block_descs[i] = d
-            d.B, d.Ni, d.Nt = B, Ni, Nt
-            d.x, d.c, d.mods, d.mod_stride = x.data_ptr(), c.data_ptr(), mods.data_ptr(), mods.stride(0)
-            _lib.check(lib.advgrpo_mmdit_block_forward(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+            # the cached descriptor holds the block's weights only; the call's own copy gets the activations: rollouts of several prompt
+            # groups run this function at the same time from their own host threads (trainer.sample_epoch), and a ctypes call releases the GIL
+            # -- filling the shared struct in place let one thread's block run on the other thread's rows
+            call = _lib.MMDiTBlockDesc.from_buffer_copy(d)
+            call.B, call.Ni, call.Nt = B, Ni, Nt
+            call.x, call.c, call.mods, call.mod_stride = x.data_ptr(), c.data_ptr(), mods.data_ptr(), mods.stride(0)
+            _lib.check(lib.advgrpo_mmdit_block_forward(ctypes.byref(call), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
 
     # ------------------------------------------------------------------ forward
     def _temb(self, timestep, pooled_projections):

@@ -158,7 +158,7 @@ def pmc_traffic(kernel, config="c2"):
     WRITE_SIZE in separate runs of this same command, scripts/pmc_traffic.py: (2*FETCH_SIZE + WRITE_SIZE)*1024, the factor 2
     being the gfx950 correction of MI355X_MICROARCH.md); None when no pass of that config is committed."""
     root = os.path.dirname(os.path.abspath(__file__))
-    files = (f"profiles/r4_pmc_traffic_{config}.json", f"profiles/r3_pmc_traffic_{config}.json") + \
+    files = (f"profiles/r5_pmc_traffic_{config}.json", f"profiles/r4_pmc_traffic_{config}.json", f"profiles/r3_pmc_traffic_{config}.json") + \
         (("profiles/r2_pmc_traffic.json", "profiles/r1_pmc_traffic.json") if config == "c2" else ())
     for rel in files:
         path = os.path.join(root, rel)

@@ -220,3 +220,48 @@ def test_c_level_block_entry_is_bit_identical_to_the_python_sequencing(size):
     model.c_block = True
     (c,) = model(lat, t, ctx, pooled)              # cached descriptors, second call
     assert torch.equal(a, c)
+
+
+@pytest.mark.gpu
+def test_forwards_from_two_host_threads_do_not_share_call_state():
+    """The Trainer runs the rollouts of two prompt groups at the same time: two host threads, one HIP stream each, ONE model (TP:668 has one
+    pipeline per rank as well).  Whatever a forward keeps per model (descriptor caches of the C-level block entry, modulation offsets, position
+    tables) must be weights-only: every thread's velocities have the bits of the same forwards issued serially.  (Round 5: the cached block
+    descriptor was filled in place with the call's activation pointers -- a ctypes call releases the GIL between the two.)"""
+    import threading
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.mmdit import SD3Transformer2DModel
+    from oracle.mmdit import MMDiTConfig
+    cfg = MMDiTConfig(num_layers=6, num_heads=4, joint_attention_dim=128, pooled_projection_dim=64, pos_embed_max_size=96, dual_attention_layers=(0, 2, 3))
+    model = SD3Transformer2DModel(synthetic.mmdit_weights(cfg, 5), cfg, "cuda")
+    assert model.c_block
+    g = torch.Generator(device="cuda").manual_seed(6)
+    shapes = [(3, 16, 13), (5, 24, 29)]                                    # (B, latent side, text tokens): different workspaces per thread
+    ins = []
+    for B, hw, Nt in shapes:
+        ins.append((torch.randn(B, 16, hw, hw, device="cuda", generator=g).to(torch.bfloat16), torch.full((B,), 400.0, device="cuda"),
+                    torch.randn(B, Nt, cfg.joint_attention_dim, device="cuda", generator=g).to(torch.bfloat16),
+                    torch.randn(B, cfg.pooled_projection_dim, device="cuda", generator=g).to(torch.bfloat16)))
+    serial = [model(*i)[0].clone() for i in ins]
+    torch.cuda.synchronize()
+    bad, errs = [0, 0], []
+    start = threading.Barrier(2)
+
+    def work(k):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                start.wait()
+                for _ in range(40):
+                    bad[k] += int(not torch.equal(model(*ins[k])[0], serial[k]))
+            st.synchronize()
+        except Exception as e:       # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    assert bad == [0, 0], bad
