@@ -108,6 +108,8 @@ SIGNATURES = {
     "advgrpo_transpose_bf16": (c_int, [_P, _P, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int64, c_int64, _P]),
     "advgrpo_layernorm_mod_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int, _P, _P, c_int64, c_int,
                                           c_int, c_float, _P]),
+    "advgrpo_layernorm_mod_bwd_gated": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int, _P, _P, c_int64, c_int,
+                                                c_int, c_float, _P, _P, _P, _P, c_int64, _P]),
     "advgrpo_rmsnorm_heads_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int64,
                                           c_int64, _P]),
     "advgrpo_qk_norm_rope_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),

@@ -62,6 +62,10 @@ struct LnBwdParams {
     const bf16_t* scale0; const bf16_t* scale1; int64_t mod_stride; int rows_per_batch;
     const bf16_t* dres; bf16_t* dx; int64_t lddx;
     int M, D; float eps;
+    // optional: up to two gated copies of the result, gout_k[m, :] = gate_k[m / rows_per_batch, :] * bf16(dx[m, :]) (dense rows of D) -- the
+    // left operands of the data-gradient GEMMs of the gated projections that consume dx next (what gate_mul_kernel computes from the stored dx,
+    // same bits, without reading it back)
+    const bf16_t* gate_a; bf16_t* gout_a; const bf16_t* gate_b; bf16_t* gout_b; int64_t gate_stride;
 };
 template <int MAXC>     // 512-column chunks per row: 4 up to D = 2048 (SD3.5-medium), 8 up to 4096 (SD3.5-large: D = 2432)
 __global__ __launch_bounds__(256) void layernorm_mod_bwd_kernel(const LnBwdParams p) {
@@ -126,7 +130,23 @@ __global__ __launch_bounds__(256) void layernorm_mod_bwd_kernel(const LnBwdParam
             if (p.dres) unpack8t(*reinterpret_cast<const uint4*>(p.dres + (int64_t)row * p.lddx + c * 8), r);
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = rstd * (gv[i][k] - mg - xv[i][k] * mgx) + (p.dres ? r[k] : 0.f);
-            *reinterpret_cast<uint4*>(p.dx + (int64_t)row * p.lddx + c * 8) = pack8t(o);
+            const uint4 packed = pack8t(o);
+            *reinterpret_cast<uint4*>(p.dx + (int64_t)row * p.lddx + c * 8) = packed;
+            if (p.gate_a) {
+                const int64_t grow = (int64_t)(row / p.rows_per_batch) * p.gate_stride;
+                float a[8], g[8];
+                unpack8t(packed, o);                         // the ROUNDED gradient is what the gated branch multiplies
+                unpack8t(*reinterpret_cast<const uint4*>(p.gate_a + grow + c * 8), g);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] = o[k] * g[k];
+                *reinterpret_cast<uint4*>(p.gout_a + (int64_t)row * p.D + c * 8) = pack8t(a);
+                if (p.gate_b) {
+                    unpack8t(*reinterpret_cast<const uint4*>(p.gate_b + grow + c * 8), g);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a[k] = o[k] * g[k];
+                    *reinterpret_cast<uint4*>(p.gout_b + (int64_t)row * p.D + c * 8) = pack8t(a);
+                }
+            }
         }
     }
 }
@@ -312,6 +332,13 @@ extern "C" int advgrpo_transpose_bf16(const void* in, void* out, int R, int C, i
     return 0;
 }
 
+static int ln_mod_bwd_launch(const LnBwdParams& p, void* stream) {
+    if (p.D <= 2048) hipLaunchKernelGGL(layernorm_mod_bwd_kernel<4>, dim3((p.M + 3) / 4), dim3(256), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(layernorm_mod_bwd_kernel<8>, dim3((p.M + 3) / 4), dim3(256), 0, as_stream(stream), p);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int advgrpo_layernorm_mod_bwd(const void* x, int64_t ldx, const void* dy0, const void* dy1, int64_t lddy,
                                          const void* scale0, const void* scale1, int64_t mod_stride, int rows_per_batch,
                                          const void* dres, void* dx, int64_t lddx, int M, int D, float eps, void* stream) {
@@ -319,11 +346,25 @@ extern "C" int advgrpo_layernorm_mod_bwd(const void* x, int64_t ldx, const void*
     ADVGRPO_CHECK(M > 0 && D % 8 == 0 && D <= 4096, "layernorm_mod_bwd: need D %% 8 == 0, D <= 4096 (D=%d)", D);
     ADVGRPO_CHECK(!dy1 || scale1, "layernorm_mod_bwd: dy1 needs scale1");
     LnBwdParams p{(const bf16_t*)x, ldx, (const bf16_t*)dy0, (const bf16_t*)dy1, lddy, (const bf16_t*)scale0,
-                  (const bf16_t*)scale1, mod_stride, rows_per_batch, (const bf16_t*)dres, (bf16_t*)dx, lddx, M, D, eps};
-    if (D <= 2048) hipLaunchKernelGGL(layernorm_mod_bwd_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
-    else hipLaunchKernelGGL(layernorm_mod_bwd_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), p);
-    ADVGRPO_LAUNCH_CHECK();
-    return 0;
+                  (const bf16_t*)scale1, mod_stride, rows_per_batch, (const bf16_t*)dres, (bf16_t*)dx, lddx, M, D, eps,
+                  nullptr, nullptr, nullptr, nullptr, 0};
+    return ln_mod_bwd_launch(p, stream);
+}
+
+extern "C" int advgrpo_layernorm_mod_bwd_gated(const void* x, int64_t ldx, const void* dy0, const void* dy1, int64_t lddy,
+                                               const void* scale0, const void* scale1, int64_t mod_stride, int rows_per_batch,
+                                               const void* dres, void* dx, int64_t lddx, int M, int D, float eps,
+                                               const void* gate_a, void* gout_a, const void* gate_b, void* gout_b,
+                                               int64_t gate_stride, void* stream) {
+    ADVGRPO_CHECK(x && dy0 && dx, "layernorm_mod_bwd_gated: null pointer");
+    ADVGRPO_CHECK(M > 0 && D % 8 == 0 && D <= 4096, "layernorm_mod_bwd_gated: need D %% 8 == 0, D <= 4096 (D=%d)", D);
+    ADVGRPO_CHECK(!dy1 || scale1, "layernorm_mod_bwd_gated: dy1 needs scale1");
+    ADVGRPO_CHECK(gate_a && gout_a && rows_per_batch > 0, "layernorm_mod_bwd_gated: the first gate, its output and rows_per_batch are required");
+    ADVGRPO_CHECK(!gate_b == !gout_b, "layernorm_mod_bwd_gated: the second gate and its output come together");
+    LnBwdParams p{(const bf16_t*)x, ldx, (const bf16_t*)dy0, (const bf16_t*)dy1, lddy, (const bf16_t*)scale0,
+                  (const bf16_t*)scale1, mod_stride, rows_per_batch, (const bf16_t*)dres, (bf16_t*)dx, lddx, M, D, eps,
+                  (const bf16_t*)gate_a, (bf16_t*)gout_a, (const bf16_t*)gate_b, (bf16_t*)gout_b, gate_stride};
+    return ln_mod_bwd_launch(p, stream);
 }
 
 extern "C" int advgrpo_rmsnorm_heads_bwd(void* dy, int64_t lddy, const void* y, int64_t ldy, const float* rs, int M,

@@ -467,6 +467,8 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                 descs.append(ops.tn_desc(X, u[:, cols], self.A_view(ad, self.grads), alpha=self.scale, M=M, p_seg=x_seg, transpose_out=True))
         ops.gemm_tn_grouped(descs)                       # (2 problems per adapter: 12 for the q | k | v groups of both streams, 4 for the output projections)
 
+    fuse_gates = True          # the norms' backward writes the gated copies of its result as well (backward; False: ops.gate_mul, for A/Bs)
+
     # ------------------------------------------------------------------ explicit backward
     @torch.no_grad()
     def backward(self, ctx, dv):
@@ -488,31 +490,42 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
         # final layer: v = unpatchify(LNmod(x) Wp^T + b)
         dtok = self._patch_rows_of_output_grad(dv)                              # [B*Ni, 64]
         dnx = ops.gemm(dtok, w["proj_out.wT"])                                  # [B*Ni, D]
-        dx = ops.layernorm_mod_bwd(ctx["x_final"], dnx, scale0=mod(("out",), 0), rows_per_batch=Ni)
-        dc = None
-        for i in reversed(range(cfg.num_layers)):
+        # Every gradient of a residual stream is consumed next by the gated projections hanging off that stream (dy = gate * dx): the
+        # norm backward that produces dx writes those gated copies in the same pass (fuse_gates; the same bits as ops.gate_mul on the
+        # stored dx, 5 launches and one read of dx per block less)
+        fuse = self.fuse_gates
+        L = cfg.num_layers
+
+        def ln_bwd(x_saved, dy0, gates, rows, **kw):
+            """-> (dx, gated copies in the order of `gates`)"""
+            if fuse and gates:
+                return ops.layernorm_mod_bwd(x_saved, dy0, rows_per_batch=rows, gates=gates, **kw)
+            dxx = ops.layernorm_mod_bwd(x_saved, dy0, rows_per_batch=rows, **kw)
+            return dxx, [ops.gate_mul(dxx, g, rows) for g in gates]
+        dx, (dyg,) = ln_bwd(ctx["x_final"], dnx, [mod(("x", L - 1), 5)], Ni, scale0=mod(("out",), 0))
+        dc = dcyg = None
+        for i in reversed(range(L)):
             b, s = self.blocks[i], ctx["blocks"][i]
             kx, kc = ("x", i), ("c", i)
             # ---- image MLP
             # (the text-stream data-gradient GEMMs ride in the launches of their image-stream twins, as in the forward)
-            dyg = ops.gate_mul(dx, mod(kx, 5), Ni)
             d2 = [ops.gemm_desc(dyg, b["ff2.wT"], act="dgelu_tanh", aux_in=s["pre"])]
             if not b["last"]:
-                dcyg = ops.gate_mul(dc, mod(kc, 5), Nt)
                 d2.append(ops.gemm_desc(dcyg, b["cff2.wT"], act="dgelu_tanh", aux_in=s["cpre"]))
             dpres = ops.gemm_grouped(d2)
             d1 = [ops.gemm_desc(dpres[0], b["ff1.wT"])]
             if not b["last"]:
                 d1.append(ops.gemm_desc(dpres[1], b["cff1.wT"]))
             dmid = ops.gemm_grouped(d1)
-            dx1 = ops.layernorm_mod_bwd(s["x_mid"], dmid[0], scale0=mod(kx, 4), dres=dx, rows_per_batch=Ni)
+            dx1, gx = ln_bwd(s["x_mid"], dmid[0], [mod(kx, 2)] + ([mod(kx, 8)] if b["dual"] else []), Ni, scale0=mod(kx, 4), dres=dx)
+            dyo = gx[0]                                                         # grad of to_out.0 output
             # ---- text MLP
             if not b["last"]:
-                dc1 = ops.layernorm_mod_bwd(s["c_mid"], dmid[1], scale0=mod(kc, 4), dres=dc, rows_per_batch=Nt)
+                dc1, (dyc,) = ln_bwd(s["c_mid"], dmid[1], [mod(kc, 2)], Nt, scale0=mod(kc, 4), dres=dc)
             # ---- second (image-only) attention of the dual blocks
             dnx2 = None
             if b["dual"]:
-                dy2 = ops.gate_mul(dx1, mod(kx, 8), Ni)
+                dy2 = gx[1]
                 datt2 = ops.gemm(dy2, b["out2.wT"]).view(B, Ni, D)
                 q3 = s["qkv2"].view(B, Ni, 3 * D)
                 dqkv2 = torch.empty(B * Ni, 3 * D, dtype=bf16, device=dev)
@@ -523,11 +536,9 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                 dnx2 = ops.gemm(dqkv2, b["qkv2.wT"])
             # ---- joint attention
             datt = torch.zeros(B * S, D, dtype=bf16, device=dev) if b["last"] else torch.empty(B * S, D, dtype=bf16, device=dev)
-            dyo = ops.gate_mul(dx1, mod(kx, 2), Ni)                             # grad of to_out.0 output
             douts = [ops.gemm_desc(dyo, b["out.wT"], out=datt, seg=(Ni, S, 0))]
             att2d = s["att"].view(B * S, D)
             if not b["last"]:
-                dyc = ops.gate_mul(dc1, mod(kc, 2), Nt)
                 douts.append(ops.gemm_desc(dyc, b["cout.wT"], out=datt, seg=(Nt, S, Ni)))
             ops.gemm_grouped(douts)
             self._lora_wgrad_group([((i, "out"), att2d, B * Ni, (Ni, S, 0), dyo, None)] +
@@ -544,12 +555,15 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             self._lora_wgrad_group([((i, "qkv"), s["nx"], B * Ni, None, dqkv, (Ni, S, 0)),
                                     ((i, "cqkv"), s["nc"], B * Nt, None, dqkv, (Nt, S, Ni))])
             # ---- first norms
-            dx = ops.layernorm_mod_bwd(s["x_in"], dnx, scale0=mod(kx, 1), dy1=dnx2, scale1=mod(kx, 7) if b["dual"] else None,
-                                       dres=dx1, rows_per_batch=Ni)
+            # (the gated copies are for block i - 1's feed-forward output projections)
+            gxn = [mod(("x", i - 1), 5)] if i else []
+            gcn = [mod(("c", i - 1), 5)] if i else []
+            dx, gx = ln_bwd(s["x_in"], dnx, gxn, Ni, scale0=mod(kx, 1), dy1=dnx2, scale1=mod(kx, 7) if b["dual"] else None, dres=dx1)
             if b["last"]:
-                dc = ops.layernorm_mod_bwd(s["c_in"], dnc, scale0=mod(kc, 0), rows_per_batch=Nt)
+                dc, gc = ln_bwd(s["c_in"], dnc, gcn, Nt, scale0=mod(kc, 0))
             else:
-                dc = ops.layernorm_mod_bwd(s["c_in"], dnc, scale0=mod(kc, 1), dres=dc1, rows_per_batch=Nt)
+                dc, gc = ln_bwd(s["c_in"], dnc, gcn, Nt, scale0=mod(kc, 1), dres=dc1)
+            dyg, dcyg = (gx[0], gc[0]) if i else (None, None)
         if side is not None:                             # the gradient vector is complete for whoever reads it next
             torch.cuda.current_stream().wait_stream(side)
         return dx, dc

@@ -886,12 +886,23 @@ def transpose(x, R=None, seg=None, pad_to=64, out=None):
     return out
 
 
-def layernorm_mod_bwd(x, dy0, scale0=None, dy1=None, scale1=None, dres=None, rows_per_batch=0, eps=1e-6, out=None):
+def layernorm_mod_bwd(x, dy0, scale0=None, dy1=None, scale1=None, dres=None, rows_per_batch=0, eps=1e-6, out=None, gates=None):
+    """gates: up to two [G, D] bf16 gate views (rows pitch stride(0), the same for both) -> returns (dx, [gate_k * dx ...]): the gated copies
+    the data-gradient GEMMs of the next gated projections read, written by the same pass (bit for bit gate_mul(dx, gate_k))."""
     lib = _lib.load()
     M, D = x.shape
     out = torch.empty(M, D, dtype=torch.bfloat16, device=x.device) if out is None else out
     ms = scale0.stride(0) if scale0 is not None else 0
     dp = lambda t: t.data_ptr() if t is not None else None
+    if gates:
+        assert 1 <= len(gates) <= 2 and all(g.stride(0) == gates[0].stride(0) and g.stride(1) == 1 for g in gates)
+        gouts = [torch.empty(M, D, dtype=torch.bfloat16, device=x.device) for _ in gates]
+        _lib.check(lib.advgrpo_layernorm_mod_bwd_gated(
+            x.data_ptr(), x.stride(0), dy0.data_ptr(), dp(dy1), dy0.stride(0), dp(scale0), dp(scale1), ms, int(rows_per_batch), dp(dres),
+            out.data_ptr(), out.stride(0), M, D, float(eps), gates[0].data_ptr(), gouts[0].data_ptr(),
+            gates[1].data_ptr() if len(gates) > 1 else None, gouts[1].data_ptr() if len(gates) > 1 else None, gates[0].stride(0),
+            _lib.stream_ptr()))
+        return out, gouts
     _lib.check(lib.advgrpo_layernorm_mod_bwd(x.data_ptr(), x.stride(0), dy0.data_ptr(), dp(dy1), dy0.stride(0), dp(scale0),
                                              dp(scale1), ms, int(rows_per_batch), dp(dres), out.data_ptr(), out.stride(0),
                                              M, D, float(eps), _lib.stream_ptr()))

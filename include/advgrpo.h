@@ -501,6 +501,15 @@ int advgrpo_transpose_bf16(const void* in, void* out, int R, int C, int64_t ldi,
 int advgrpo_layernorm_mod_bwd(const void* x, int64_t ldx, const void* dy0, const void* dy1, int64_t lddy,
                               const void* scale0, const void* scale1, int64_t mod_stride, int rows_per_batch,
                               const void* dres, void* dx, int64_t lddx, int M, int D, float eps, void* stream);
+/* The same, plus up to two gated copies of the result for the data-gradient GEMMs of the gated projections that read dx next
+   (autograd of `hidden_states + gate.unsqueeze(1) * branch`, diffusers' JointTransformerBlock behind TP:235-255 / loss.backward() TP:1165):
+   gout_k[m, :] = gate_k[m / rows_per_batch, :] * dx[m, :] with dx as stored (bf16), dense rows of D; gate rows gate_stride elements apart.
+   gate_b / gout_b may both be NULL.  Same bits as advgrpo_layernorm_mod_bwd followed by advgrpo_gate_mul. */
+int advgrpo_layernorm_mod_bwd_gated(const void* x, int64_t ldx, const void* dy0, const void* dy1, int64_t lddy,
+                                    const void* scale0, const void* scale1, int64_t mod_stride, int rows_per_batch,
+                                    const void* dres, void* dx, int64_t lddx, int M, int D, float eps,
+                                    const void* gate_a, void* gout_a, const void* gate_b, void* gout_b,
+                                    int64_t gate_stride, void* stream);
 /* in place: dy (grad of the normalised+weighted q|k heads) -> grad of the un-normalised heads. */
 int advgrpo_rmsnorm_heads_bwd(void* dy, int64_t lddy, const void* y, int64_t ldy, const float* rs, int M,
                               int col0, int nheads, const void* weight, int heads_per_weight, int seg_rows,

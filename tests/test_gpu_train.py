@@ -89,6 +89,41 @@ def test_split_k_atomic_gemm_and_dgelu_epilogue():
     assert ((dpre.float() - p32.grad).norm() / p32.grad.norm()).item() < 1e-2
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("layers,dual,heads", [(4, (0, 2), 4), (2, (), 38)])
+def test_gated_copies_from_the_norm_backward_have_the_bits_of_gate_mul(layers, dual, heads):
+    """advgrpo_layernorm_mod_bwd_gated: the gradient of a residual stream and its gated copies (the left operands of the data-gradient
+    GEMMs of the gated projections, autograd of `hidden_states + gate.unsqueeze(1) * branch`) from ONE pass, against the separate
+    advgrpo_gate_mul launches on the stored gradient: every LoRA gradient and both input gradients have the same bits."""
+    from adv_grpo_amd import ops
+    from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
+    from oracle import mmdit as o
+    cfg = o.MMDiTConfig(num_layers=layers, num_heads=heads, joint_attention_dim=128, pooled_projection_dim=64,
+                        pos_embed_max_size=96, dual_attention_layers=dual)
+    W, lora, lat, t, ctx, pooled, g = _setup(cfg, 37, B=4, hw=16, Nt=13)
+    model = SD3TransformerLoRA(W, cfg, "cuda", lora_state=lora)
+    model.overlap_wgrad = False
+    dv = torch.randn(lat.shape, generator=g).to(torch.bfloat16).cuda()
+    res = []
+    for fuse in (True, False):
+        model.fuse_gates = fuse
+        model.grads.zero_()
+        v, saved = model.forward_train(lat.cuda(), t.cuda(), ctx.cuda(), pooled.cuda())
+        dx, dc = model.backward(saved, dv)
+        res.append((model.grads.clone(), dx.clone(), dc.clone()))
+    assert res[0][0].abs().max().item() > 0
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # the entry on its own: two gates, a residual gradient, rows per batch that do not divide the row tile
+    M, D, rows = 3 * 50, 1536, 50
+    x, dy, dres = (torch.randn(M, D, generator=g).to(torch.bfloat16).cuda() for _ in range(3))
+    mods = torch.randn(3, 5 * D, generator=g).to(torch.bfloat16).cuda()
+    sc, ga, gb = mods[:, :D], mods[:, 2 * D:3 * D], mods[:, 4 * D:]
+    dx0 = ops.layernorm_mod_bwd(x, dy, scale0=sc, dres=dres, rows_per_batch=rows)
+    dx1, (ya, yb) = ops.layernorm_mod_bwd(x, dy, scale0=sc, dres=dres, rows_per_batch=rows, gates=[ga, gb])
+    assert torch.equal(dx0, dx1) and torch.equal(ya, ops.gate_mul(dx0, ga, rows)) and torch.equal(yb, ops.gate_mul(dx0, gb, rows))
+
+
 @pytest.mark.parametrize("layers,dual,heads", [(3, (0,), 4), (4, (0, 1), 4), (2, (), 38)])
 def test_mmdit_lora_backward_vs_autograd(layers, dual, heads):
     """(heads = 38: the SD3.5-large width D = 2432 of BASELINE config 4 -- more than 2048 columns per LayerNorm row, a width
