@@ -49,6 +49,12 @@ class MMDiTBlockDesc(ctypes.Structure):
                                    "ff1_w", "ff1_b", "ff2_w", "ff2_b", "cff1_w", "cff1_b", "cff2_w", "cff2_b", "rms_x", "rms_c", "rms_2")])
 
 
+class LoraMergeItem(ctypes.Structure):
+    """advgrpo_lora_merge_item (include/advgrpo.h), field for field."""
+    _fields_ = ([(n, _P) for n in ("A", "B", "base", "w", "wT", "a_cat", "b_bd")] + [(n, c_int64) for n in ("ld_base", "ld_w", "ld_wT", "ld_bd")] +
+                [("N", c_int32), ("K", c_int32)])
+
+
 class TnDesc(ctypes.Structure):
     """advgrpo_tn_desc (include/advgrpo.h), field for field."""
     _fields_ = [("P", _P), ("ldp", c_int64), ("p_seg_rows", c_int32), ("p_seg_stride", c_int64), ("p_seg_off", c_int64),
@@ -105,6 +111,7 @@ SIGNATURES = {
     "advgrpo_mmdit_block_forward": (c_int, [POINTER(MMDiTBlockDesc), _P, c_int64, _P]),
     "advgrpo_gemm_tn_grouped_workspace_bytes": (c_int64, [POINTER(TnDesc), c_int]),
     "advgrpo_gemm_tn_grouped": (c_int, [POINTER(TnDesc), c_int, _P, c_int64, c_int, _P]),
+    "advgrpo_lora_merge": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P]),
     "advgrpo_transpose_bf16": (c_int, [_P, _P, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int64, c_int64, _P]),
     "advgrpo_layernorm_mod_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int, _P, _P, c_int64, c_int,
                                           c_int, c_float, _P]),

@@ -168,53 +168,33 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
         del self._base_sd
 
     # ------------------------------------------------------------------ merge LoRA into the working weights
+    merge_one_launch = True    # refresh() through advgrpo_lora_merge (one launch for the model); False: the per-adapter GEMMs of rounds 3 - 4
+
+    def _groups(self, b):
+        groups = {"qkv": ["to_q", "to_k", "to_v"], "cqkv": ["add_q_proj", "add_k_proj", "add_v_proj"], "out": ["to_out.0"]}
+        if not b["last"]:
+            groups["cout"] = ["to_add_out"]
+        return groups
+
     @torch.no_grad()
     def refresh(self):
-        """bf16 copies of A/B, their transposes, and W_eff / W_eff^T of every adapted projection."""
+        """bf16 copies of A/B and W_eff / W_eff^T of every adapted projection (after construction, a state load, every optimizer step):
+        W_eff[n,k] = W + s * B A, plus the stacked A and the block-diagonal B^T of every Linear group (the adapter-gradient GEMMs' operands)."""
         self.params_bf16.copy_(self.params)
-        D = self.cfg.dim
-        self._lora = {}
         if not hasattr(self, "_Bbd"):
-            self._Bbd = {}
-        for i, b in enumerate(self.blocks):
-            p = f"transformer_blocks.{i}.attn"
-            groups = {"qkv": ["to_q", "to_k", "to_v"], "cqkv": ["add_q_proj", "add_k_proj", "add_v_proj"],
-                      "out": ["to_out.0"]}
-            if not b["last"]:
-                groups["cout"] = ["to_add_out"]
-            for gk, names in groups.items():
-                base, baseT = self._base_T[i][gk]
-                w = b[gk + ".w"] if self.lora_mode == "merged" else None
-                wT = b.get(gk + ".wT")
-                if wT is None:
-                    wT = b[gk + ".wT"] = torch.empty(base.shape[1], base.shape[0], dtype=torch.bfloat16, device=self.device)
-                As, Bts = [], []
-                for j, n in enumerate(names):
-                    ad = self.adapters[f"{p}.{n}"]
-                    A16 = self.A_view(ad, self.params_bf16)                      # [64, K]
-                    B16 = self.B_view(ad, self.params_bf16)                      # [N, 64]
-                    AT = ops.transpose(A16)                                      # [K, 64]
-                    sl = slice(j * D, (j + 1) * D)
-                    # W_eff[n,k] = W + s * B A ;  W_eff^T[k,n] = W^T + s * A^T B^T
-                    if w is not None:
-                        ops.gemm(B16, AT, alpha=self.scale, residual=base[sl], out=w[sl])
-                    ops.gemm(AT, B16, alpha=self.scale, residual=baseT[:, sl], out=wT[:, sl])
-                    As.append(A16)
-                    Bts.append(ops.transpose(B16))                               # [64, N]
-                A_cat = torch.cat(As, 0).contiguous()
-                # [B_0^T; B_1^T; ...] as ONE block-diagonal right operand [64 n, n D]: u = [dY_0 B_0 | dY_1 B_1 | ...] is then a single
-                # GEMM over the group's whole output gradient (K = n D; the off-diagonal zeros cost flops on a pass that is bound by
-                # reading dY) instead of n launches (kept across refreshes: only the diagonal blocks are rewritten)
-                n_ad = len(names)
-                Bbd = self._Bbd.get((i, gk))
-                if Bbd is None:
-                    Bbd = self._Bbd[(i, gk)] = torch.zeros(RPAD * n_ad, n_ad * D, dtype=torch.bfloat16, device=self.device)
-                for j in range(n_ad):
-                    Bbd[j * RPAD:(j + 1) * RPAD, j * D:(j + 1) * D] = Bts[j]
-                self._lora[(i, gk)] = (A_cat, Bts, [self.adapters[f"{p}.{n}"] for n in names], Bbd)
-                if self.lora_mode == "side":
-                    # forward weight [W | s B]: the base weight is left as loaded, each adapter's s * B (bf16; s = 2 is exact)
-                    # sits in its own 64 side columns of its output rows
+            self._Bbd, self._Acat = {}, {}
+        if self.merge_one_launch:
+            self._refresh_one_launch()
+        else:
+            self._refresh_per_adapter()
+        if self.lora_mode == "side":
+            # forward weight [W | s B]: the base weight is left as loaded, each adapter's s * B (bf16; s = 2 is exact)
+            # sits in its own 64 side columns of its output rows
+            D = self.cfg.dim
+            for i, b in enumerate(self.blocks):
+                p = f"transformer_blocks.{i}.attn"
+                for gk, names in self._groups(b).items():
+                    base = self._base_T[i][gk][0]
                     K = base.shape[1]
                     E = RPAD * len(names)
                     wx = b.get(gk + ".wx")
@@ -225,9 +205,85 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                         B16 = self.B_view(self.adapters[f"{p}.{n}"], self.params_bf16)
                         wx[j * D:(j + 1) * D, K + j * RPAD:K + (j + 1) * RPAD] = (self.scale * B16.float()).to(torch.bfloat16)
                     b[gk + ".w"] = wx
-                    b[gk + ".A"] = A_cat
+                    b[gk + ".A"] = self._lora[(i, gk)][0]
         if self.fp8 is not None:                 # fp8 Linears (enable_fp8): the merged weights have just changed
             self.requantize()
+
+    def _group_buffers(self, i, b, gk, names):
+        """The persistent outputs of one Linear group: W_eff^T, the stacked A [64 n, K], the block-diagonal B^T [64 n, n D]."""
+        base = self._base_T[i][gk][0]
+        wT = b.get(gk + ".wT")
+        if wT is None:
+            wT = b[gk + ".wT"] = torch.empty(base.shape[1], base.shape[0], dtype=torch.bfloat16, device=self.device)
+        n_ad, D = len(names), self.cfg.dim
+        A_cat = self._Acat.get((i, gk))
+        if A_cat is None:
+            A_cat = self._Acat[(i, gk)] = torch.empty(RPAD * n_ad, base.shape[1], dtype=torch.bfloat16, device=self.device)
+        # [B_0^T; B_1^T; ...] as ONE block-diagonal right operand [64 n, n D]: u = [dY_0 B_0 | dY_1 B_1 | ...] is then a single
+        # GEMM over the group's whole output gradient (K = n D; the off-diagonal zeros cost flops on a pass that is bound by
+        # reading dY) instead of n launches (kept across refreshes: only the diagonal blocks are rewritten)
+        Bbd = self._Bbd.get((i, gk))
+        if Bbd is None:
+            Bbd = self._Bbd[(i, gk)] = torch.zeros(RPAD * n_ad, n_ad * D, dtype=torch.bfloat16, device=self.device)
+        return base, wT, A_cat, Bbd
+
+    def _refresh_one_launch(self):
+        """advgrpo_lora_merge over a device table of every adapter (csrc/lora_merge.hip): ~950 launches of ~8 us per optimizer step became one."""
+        D = self.cfg.dim
+        items, self._lora = [], {}
+        pb = self.params_bf16.data_ptr()
+        for i, b in enumerate(self.blocks):
+            p = f"transformer_blocks.{i}.attn"
+            for gk, names in self._groups(b).items():
+                base, wT, A_cat, Bbd = self._group_buffers(i, b, gk, names)
+                w = b[gk + ".w"] if self.lora_mode == "merged" else None
+                K = base.shape[1]
+                ads = [self.adapters[f"{p}.{n}"] for n in names]
+                for j, ad in enumerate(ads):
+                    assert ad.N == D and ad.K == K and ad.N % 64 == 0 and K % 64 == 0
+                    it = _lib.LoraMergeItem()
+                    it.A, it.B = pb + 2 * ad.offA, pb + 2 * ad.offB
+                    it.base, it.ld_base = base.data_ptr() + 2 * j * D * base.stride(0), base.stride(0)
+                    if w is not None:
+                        it.w, it.ld_w = w.data_ptr() + 2 * j * D * w.stride(0), w.stride(0)
+                    it.wT, it.ld_wT = wT.data_ptr() + 2 * j * D, wT.stride(0)
+                    it.a_cat = A_cat.data_ptr() + 2 * j * RPAD * K
+                    it.b_bd, it.ld_bd = Bbd.data_ptr() + 2 * (j * RPAD * Bbd.stride(0) + j * D), Bbd.stride(0)
+                    it.N, it.K = ad.N, ad.K
+                    items.append(it)
+                self._lora[(i, gk)] = (A_cat, None, ads, Bbd)
+        raw = b"".join(bytes(it) for it in items)
+        cached = getattr(self, "_merge_table", None)
+        if cached is None or cached[0] != raw:      # (the pointers move when a state load replaces a tensor)
+            table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            self._merge_table = cached = (raw, table)
+        _lib.check(_lib.load().advgrpo_lora_merge(cached[1].data_ptr(), len(items), max(it.N for it in items), max(it.K for it in items),
+                                                  RPAD, float(self.scale), _lib.stream_ptr()))
+
+    def _refresh_per_adapter(self):
+        """Rounds 3 - 4: per adapter two 64-deep GEMMs (W_eff and, separately, W_eff^T) and two transposes; kept for A/Bs and as the
+        comparison of tests/test_gpu_train.py (the one-launch kernel sums in f32 FMA order, these in the MFMA's: they agree to a bf16 ulp)."""
+        D = self.cfg.dim
+        self._lora = {}
+        for i, b in enumerate(self.blocks):
+            p = f"transformer_blocks.{i}.attn"
+            for gk, names in self._groups(b).items():
+                base, wT, A_cat, Bbd = self._group_buffers(i, b, gk, names)
+                baseT = self._base_T[i][gk][1]
+                w = b[gk + ".w"] if self.lora_mode == "merged" else None
+                for j, n in enumerate(names):
+                    ad = self.adapters[f"{p}.{n}"]
+                    A16 = self.A_view(ad, self.params_bf16)                      # [64, K]
+                    B16 = self.B_view(ad, self.params_bf16)                      # [N, 64]
+                    AT = ops.transpose(A16)                                      # [K, 64]
+                    sl = slice(j * D, (j + 1) * D)
+                    # W_eff[n,k] = W + s * B A ;  W_eff^T[k,n] = W^T + s * A^T B^T
+                    if w is not None:
+                        ops.gemm(B16, AT, alpha=self.scale, residual=base[sl], out=w[sl])
+                    ops.gemm(AT, B16, alpha=self.scale, residual=baseT[:, sl], out=wT[:, sl])
+                    A_cat[j * RPAD:(j + 1) * RPAD] = A16
+                    Bbd[j * RPAD:(j + 1) * RPAD, j * D:(j + 1) * D] = ops.transpose(B16)
+                self._lora[(i, gk)] = (A_cat, None, [self.adapters[f"{p}.{n}"] for n in names], Bbd)
 
     # ------------------------------------------------------------------ the adapter-free transformer (KL reference)
     _fp8_base = None           # {(block, Linear): Fp8Rows of the BASE weight}, filled by the first fp8 reference forward

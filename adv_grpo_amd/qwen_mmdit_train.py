@@ -82,6 +82,11 @@ class QwenImageTransformerLoRA(QwenImageTransformer2DModel):
     save_pretrained = SD3TransformerLoRA.save_pretrained
     lora_grads = SD3TransformerLoRA.lora_grads
     refresh = SD3TransformerLoRA.refresh
+    merge_one_launch = SD3TransformerLoRA.merge_one_launch
+    _groups = SD3TransformerLoRA._groups
+    _group_buffers = SD3TransformerLoRA._group_buffers
+    _refresh_one_launch = SD3TransformerLoRA._refresh_one_launch
+    _refresh_per_adapter = SD3TransformerLoRA._refresh_per_adapter
     _lora_wgrad = SD3TransformerLoRA._lora_wgrad
     _lora_wgrad_now = SD3TransformerLoRA._lora_wgrad_now
     _lora_wgrad_group = SD3TransformerLoRA._lora_wgrad_group

@@ -494,6 +494,25 @@ typedef struct advgrpo_tn_desc {
 int64_t advgrpo_gemm_tn_grouped_workspace_bytes(const advgrpo_tn_desc* descs, int n);
 int advgrpo_gemm_tn_grouped(const advgrpo_tn_desc* descs, int n, void* workspace, int64_t workspace_bytes, int workspace_is_zeroed,
                             void* stream);
+/* ---- LoRA re-merge after an optimizer step (TP:1166-1171; the adapters are PEFT's on the attention projections, TP:490-511) ----
+   One adapter of one projection: W_eff = base + alpha * B A and its transpose, plus the adapter's slices of the two operands the
+   adapter-gradient GEMMs read (the group's stacked A and block-diagonal B^T).  All bf16, N and K multiples of 64, the rank padded to 64
+   with zero rows / columns. */
+typedef struct advgrpo_lora_merge_item {
+    const void* A;        /* [64, K], row pitch K */
+    const void* B;        /* [N, 64], row pitch 64 */
+    const void* base;     /* [N, K] rows of the frozen weight, pitch ld_base */
+    void* w;              /* out [N, K], pitch ld_w; NULL: not written (lora_mode = "side" keeps the base weight in the forward) */
+    void* wT;             /* out [K, N] (this adapter's N columns of its group's transposed weight), pitch ld_wT */
+    void* a_cat;          /* out [64, K], pitch K: copy of A (this adapter's rows of the group's stacked A); NULL: skipped */
+    void* b_bd;           /* out [64, N], pitch ld_bd: B^T (this adapter's diagonal block of the group's block-diagonal B^T); NULL: skipped */
+    int64_t ld_base, ld_w, ld_wT, ld_bd;
+    int32_t N, K;
+} advgrpo_lora_merge_item;
+/* items_device: n_items descriptors in DEVICE memory; max_N / max_K: the largest N / K among them; rank_padded must be 64.
+   acc = sum_r B[n, r] A[r, k] in f32 (fused multiply-adds, r ascending), out = bf16(acc * alpha + base): w and wT hold the same bits. */
+int advgrpo_lora_merge(const advgrpo_lora_merge_item* items_device, int n_items, int max_N, int max_K, int rank_padded, float alpha,
+                       void* stream);
 /* out[c, r] = in[row(r), c] for r < R, zero for R <= r < Rpad (row(r) = the GEMM row-segment map when seg_rows > 0). */
 int advgrpo_transpose_bf16(const void* in, void* out, int R, int C, int64_t ldi, int64_t ldo, int Rpad,
                            int seg_rows, int64_t seg_stride, int64_t seg_off, void* stream);

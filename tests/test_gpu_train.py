@@ -90,6 +90,60 @@ def test_split_k_atomic_gemm_and_dgelu_epilogue():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("heads,mode", [(4, "merged"), (38, "merged"), (4, "side")])
+def test_lora_merge_in_one_launch(heads, mode):
+    """advgrpo_lora_merge (csrc/lora_merge.hip): W_eff = W + (alpha / r) B A of every adapted projection, its transpose, the stacked A and the
+    block-diagonal B^T of every Linear group from ONE launch, against (a) fp32 torch on the same bf16 operands -- at most one bf16 ulp off (the
+    kernel's two f32 roundings before the bf16 one), (b) the per-adapter GEMM launches of rounds 3 - 4 (MFMA summation order: same bound);
+    W_eff^T is the transpose of W_eff bit for bit, the operand copies are exact; a second refresh after a parameter change follows it."""
+    from adv_grpo_amd.mmdit_train import SD3TransformerLoRA, RPAD
+    from oracle import mmdit as o
+    cfg = o.MMDiTConfig(num_layers=2, num_heads=heads, joint_attention_dim=128, pooled_projection_dim=64, pos_embed_max_size=96, dual_attention_layers=(0,))
+    W, lora, *_ = _setup(cfg, 41, B=2, hw=16, Nt=13)
+    model = SD3TransformerLoRA(W, cfg, "cuda", lora_state=lora, lora_mode=mode)
+    assert model.merge_one_launch
+    D = cfg.dim
+
+    def snapshot():
+        out = {}
+        for i, b in enumerate(model.blocks):
+            for gk in model._groups(b):
+                A_cat, _, ads, Bbd = model._lora[(i, gk)]
+                out[(i, gk)] = (b[gk + ".w"].clone(), b[gk + ".wT"].clone(), A_cat.clone(), Bbd.clone())
+        return out
+
+    def ulp(ref):                                    # one bf16 ulp at |ref| (+ the f32 roundings of the terms where they cancel: |W| ~ 0.02)
+        return ref.abs() * 2.0 ** -7 + 1e-7
+
+    for step in range(2):
+        if step:                                     # the optimizer moved the parameters: the next refresh must follow
+            model.params.add_(torch.randn(model.params.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) * 1e-2 * (model.params != 0))
+        model.merge_one_launch = True
+        model.refresh()
+        new = snapshot()
+        model.merge_one_launch = False
+        model.refresh()
+        old = snapshot()
+        for (i, gk), (w, wT, A_cat, Bbd) in new.items():
+            w_o, wT_o, A_o, B_o = old[(i, gk)]
+            assert torch.equal(A_cat, A_o) and torch.equal(Bbd, B_o), (i, gk)
+            base = model._base_T[i][gk][0].float()
+            ads = model._lora[(i, gk)][2]
+            ref = torch.cat([base[j * D:(j + 1) * D] + model.scale * (model.B_view(ad, model.params_bf16).float() @ model.A_view(ad, model.params_bf16).float())
+                             for j, ad in enumerate(ads)])
+            assert (ref - base).abs().max().item() > 0
+            if mode == "merged":
+                assert torch.equal(wT, w.t()), (i, gk)
+                assert ((w.float() - ref).abs() <= ulp(ref)).all(), (i, gk)
+                assert ((w.float() - w_o.float()).abs() <= ulp(ref)).all() and (w != w_o).float().mean().item() < 0.02, (i, gk)
+            else:                                    # side mode: the forward weight keeps the base rows, its side columns hold s * B
+                assert torch.equal(w, w_o) and torch.equal(w[:, :base.shape[1]].float(), base), (i, gk)
+            assert ((wT.float() - ref.t()).abs() <= ulp(ref.t())).all(), (i, gk)
+            assert ((wT.float() - wT_o.float()).abs() <= ulp(ref.t())).all(), (i, gk)
+    model.merge_one_launch = True
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("layers,dual,heads", [(4, (0, 2), 4), (2, (), 38)])
 def test_gated_copies_from_the_norm_backward_have_the_bits_of_gate_mul(layers, dual, heads):
     """advgrpo_layernorm_mod_bwd_gated: the gradient of a residual stream and its gated copies (the left operands of the data-gradient
