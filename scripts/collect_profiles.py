@@ -15,7 +15,9 @@ names = {"bench_c2.json": f"{pre}_bench_c2_full.json", "bench_c4.json": f"{pre}_
          "attention_d128.txt": f"{pre}_attention_d128.txt", "attention_bwd.txt": f"{pre}_attention_bwd.txt", "gstep_under_rocprof.txt": f"{pre}_gstep_under_rocprof.txt",
          "qwen_vae.txt": f"{pre}_qwen_vae.txt", "attention_bwd_d128.txt": f"{pre}_attention_bwd_d128.txt", "gstep_qwen.txt": f"{pre}_gstep_qwen.txt",
          "kernel_stats_gstep_qwen_6_blocks.md": f"{pre}_kernel_stats_gstep_qwen_6_blocks.md",
-         "attention_fwd_d64.txt": f"{pre}_attention_fwd_d64.txt", "tn_grouped.txt": f"{pre}_tn_grouped.txt"}
+         "attention_fwd_d64.txt": f"{pre}_attention_fwd_d64.txt", "tn_grouped.txt": f"{pre}_tn_grouped.txt",
+         "kernel_stats_gstep_serial.md": f"{pre}_gstep_serial_kernel_stats.md", "gpu_idle_c2.txt": f"{pre}_gpu_idle_c2.txt",
+         "gstep_ab_inprocess.txt": f"{pre}_gstep_ab_inprocess.txt"}
 for a, b in names.items():
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b))

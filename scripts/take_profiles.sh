@@ -34,10 +34,20 @@ cd /tmp
 # 2. kernel tables: rollout (timed configuration only) and one G-step micro-batch
 rocprofv3 --kernel-trace --stats -d $O/kt_c2 -o x -- python $R/bench.py $FAST > $O/bench_c2_prof.json 2>/dev/null
 python $R/scripts/rocpd_stats.py $O/kt_c2/x_results.db $O/kernel_stats_c2.md > /dev/null
-python $R/scripts/bench_gstep.py > $O/gstep.txt 2>/dev/null              # the number: without the profiler attached
-python $R/scripts/bench_gstep.py fp8 >> $O/gstep.txt 2>/dev/null
+python $R/scripts/gpu_idle.py $O/kt_c2/x_results.db > $O/gpu_idle_c2.txt
+python $R/scripts/bench_gstep.py 2>/dev/null | grep -v amdgpu > $O/gstep.txt              # the number: without the profiler attached
+python $R/scripts/bench_gstep.py nowgrad 2>/dev/null | grep -v amdgpu | head -1 >> $O/gstep.txt
+python $R/scripts/bench_gstep.py serial 2>/dev/null | grep -v amdgpu | head -1 >> $O/gstep.txt
+python $R/scripts/bench_gstep.py fp8 2>/dev/null | grep -v amdgpu >> $O/gstep.txt
+# class switches of the update half, both variants in ONE process (alternating processes carry a position effect of 1 - 3 %)
+python $R/scripts/probes/gstep_ab_inprocess.py fuse_gates 2>/dev/null | tail -2 > $O/gstep_ab_inprocess.txt
+python $R/scripts/probes/gstep_ab_inprocess.py overlap_wgrad 2>/dev/null | tail -2 >> $O/gstep_ab_inprocess.txt
+python $R/scripts/probes/gstep_ab_inprocess.py merge_one_launch 2>/dev/null | tail -2 >> $O/gstep_ab_inprocess.txt
+[ -f $R/adv_grpo_amd/libadvgrpo_base.so ] && python $R/scripts/probes/attention_ab_inprocess.py 2>/dev/null | grep -v amdgpu > $O/attention_fwd_d64_ab.txt
 rocprofv3 --kernel-trace --stats -d $O/kt_gstep -o x -- python $R/scripts/bench_gstep.py > $O/gstep_under_rocprof.txt 2>/dev/null
 python $R/scripts/rocpd_stats.py $O/kt_gstep/x_results.db $O/kernel_stats_gstep.md > /dev/null
+rocprofv3 --kernel-trace --stats -d $O/kt_gstep_s -o x -- python $R/scripts/bench_gstep.py serial > $O/gstep_serial_under_rocprof.txt 2>/dev/null
+python $R/scripts/rocpd_stats.py $O/kt_gstep_s/x_results.db $O/kernel_stats_gstep_serial.md > /dev/null
 # 3. HBM-side traffic (separate passes, MI355X_MICROARCH "HBM"), per config
 for cfg in c2 c4 c5; do
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -49,5 +59,5 @@ done
 # 4. matrix-pipe busy share of the MFMA kernels
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY -d $O/pmc_mfma -o x -- python $R/bench.py --steps 1 --warmup 1 --no-epoch --no-cpu-baseline --no-pricing > /dev/null 2>&1
 python $R/scripts/pmc_db.py $O/pmc_mfma/x_results.db advgrpo > $O/pmc_mfma.txt
-rm -rf $O/kt_c2 $O/kt_c3 $O/kt_c5 $O/kt_gstep $O/kt_gq $O/pmc_c2* $O/pmc_c4_* $O/pmc_c4 $O/pmc_c5_* $O/pmc_c5 $O/pmc_mfma
+rm -rf $O/kt_c2 $O/kt_c3 $O/kt_c5 $O/kt_gstep $O/kt_gstep_s $O/kt_gq $O/pmc_c2* $O/pmc_c4_* $O/pmc_c4 $O/pmc_c5_* $O/pmc_c5 $O/pmc_mfma
 ls -la $O
