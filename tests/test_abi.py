@@ -65,3 +65,36 @@ def test_scheduler_matches_oracle():
         assert np.array_equal(a.timesteps.numpy(), b.timesteps.numpy())
         for i in range(n):
             assert a.index_for_timestep(a.timesteps[i]) == i
+
+
+def test_header_is_plain_c_and_struct_layouts_match_the_ctypes_mirrors(tmp_path):
+    """include/advgrpo.h is what a foreign binding (cgo / JNI / ctypes) compiles against: it must compile as C (gcc, no C++), and
+    every descriptor struct the Python side mirrors in adv_grpo_amd/_lib.py must have the same size and the same field offsets, name by name."""
+    import ctypes, re, shutil, subprocess
+    from adv_grpo_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "advgrpo.h")).read()
+    mirrors = {"advgrpo_gemm_desc": _lib.GemmDesc, "advgrpo_ln_desc": _lib.LnDesc, "advgrpo_mmdit_block_desc": _lib.MMDiTBlockDesc,
+               "advgrpo_lora_merge_item": _lib.LoraMergeItem, "advgrpo_tn_desc": _lib.TnDesc, "advgrpo_fp8_scales": _lib.Fp8Scales}
+    declared = set(re.findall(r"^\} (advgrpo_\w+);", header, flags=re.M)) | set(re.findall(r"typedef struct \w+ \{[^}]*\} (advgrpo_\w+);", header))
+    assert declared == set(mirrors), (declared, set(mirrors))          # a struct added to the header needs its mirror (and this test)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "advgrpo.h"', 'int main(void) {']
+    for cname, cls in mirrors.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = {}
+    for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        cname, fname, val = ln.split()
+        got[(cname, fname)] = int(val)
+    for cname, cls in mirrors.items():
+        assert got[(cname, "size")] == ctypes.sizeof(cls), (cname, got[(cname, "size")], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
