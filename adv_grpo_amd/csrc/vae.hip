@@ -132,10 +132,48 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restric
     }
 }
 
+// Cancellation guard of the two finalize kernels below.  The partial sums they combine are f32 {sum, sum of squares} over a
+// few dozen values each; variance = E[x^2] - E[x]^2 then carries the f32 rounding of the squares, 6e-8 E[x^2] / sqrt(partials) -- invisible
+// while |mean| is of the order of the standard deviation (every activation of a working decoder), but relative to the variance it grows
+// with (mean / std)^2: 9e-5 of the output at mean / std = 34, 7e-3 at 340 (tests/test_gpu_vae.py).  When the first estimate says
+// mean^2 > 256 var the workgroup re-reads its (image, group) and sums the DEVIATIONS from that estimate in f64, in a fixed order
+// (thread t: pixels t, t + NT, ...; xor tree; waves in order): exact to f64 whatever the mean.  Never taken on ordinary inputs, so
+// their bits are what they were.
+template <int NT>
+__device__ inline void groupnorm_refine(const float* __restrict__ x, int b, int g, int C, int G, int HW, double cnt, double& mean, double& var,
+                                        double* red /* [2 * NT / 64] shared */) {
+    const int cpg = C / G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xg = x + (int64_t)b * HW * C + g * cpg;
+    double s = 0.0, q = 0.0;
+    for (int p = tid; p < HW; p += NT) {
+        const float* e = xg + (int64_t)p * C;
+        for (int c = 0; c < cpg; ++c) {
+            const double d = (double)e[c] - mean;
+            s += d;
+            q += d * d;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        s += __shfl_xor(s, m, 64);
+        q += __shfl_xor(q, m, 64);
+    }
+    __syncthreads();                          // (red is reused by the caller)
+    if (lane == 0) { red[2 * wave] = s; red[2 * wave + 1] = q; }
+    __syncthreads();
+    double ss = 0.0, qq = 0.0;
+    for (int w = 0; w < NT / 64; ++w) { ss += red[2 * w]; qq += red[2 * w + 1]; }
+    const double dm = ss / cnt;
+    var = qq / cnt - dm * dm;
+    mean += dm;
+}
+
 // per-(image, group) mean and 1/std in f32 from the blocks' f64 partial sums (added in block order), once: done per element
 // group inside the apply kernel the f64 division (and two f64 loads) per 4 channels slowed a streaming kernel down
 __global__ __launch_bounds__(64) void groupnorm_finalize_kernel(const double* __restrict__ partial, float* __restrict__ mr, int B,
-                                                                int G, int nchunks, double cnt, float eps) {
+                                                                int G, int nchunks, double cnt, float eps,
+                                                                const float* __restrict__ x_f32 = nullptr, int C = 0, int HW = 0) {
+    __shared__ double red1[2];
     // one wave per (image, group): lane l adds chunks l, l + 64, ... in order, then a fixed xor tree over the lanes -- the same
     // order on every run (the first version walked all chunks in ONE thread: 216 us for the 512 chunks of a 512^2 image)
     const int i = blockIdx.x, lane = threadIdx.x;
@@ -151,9 +189,9 @@ __global__ __launch_bounds__(64) void groupnorm_finalize_kernel(const double* __
         s += __shfl_xor(s, m, 64);
         q += __shfl_xor(q, m, 64);
     }
+    double mean = s / cnt, var = q / cnt - mean * mean;          // (every lane holds the totals after the xor tree)
+    if (x_f32 && mean * mean > 256.0 * var) groupnorm_refine<64>(x_f32, b, g, C, G, HW, cnt, mean, var, red1);
     if (lane == 0) {
-        const double mean = s / cnt;
-        const double var = q / cnt - mean * mean;
         mr[2 * i] = (float)mean;
         mr[2 * i + 1] = rsqrtf(fmaxf((float)var, 0.f) + eps);
     }
@@ -164,8 +202,10 @@ __global__ __launch_bounds__(64) void groupnorm_finalize_kernel(const double* __
 // in order, then the fixed xor tree inside each wave and the four wave sums in wave order -- nothing depends on where the image stands
 // in the batch.  (One wave per (image, group) took up to 0.56 ms at 512^2: 128 waves on 256 CUs walking 256 strided blocks each.)
 __global__ __launch_bounds__(256) void groupnorm_finalize_tiles_kernel(const float* __restrict__ partial, float* __restrict__ mr, int B,
-                                                                       int G, int C, int HW, int tile_rows, double cnt, float eps) {
+                                                                       int G, int C, int HW, int tile_rows, double cnt, float eps,
+                                                                       const float* __restrict__ x_f32) {
     __shared__ double red[8];
+    __shared__ double est[2];
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = i / G, g = i - b * G;
     const int nch = C >> 2, cpg4 = (C / G) >> 2;
@@ -188,8 +228,13 @@ __global__ __launch_bounds__(256) void groupnorm_finalize_tiles_kernel(const flo
     __syncthreads();
     if (tid == 0) {
         const double ss = ((red[0] + red[2]) + red[4]) + red[6], qq = ((red[1] + red[3]) + red[5]) + red[7];
-        const double mean = ss / cnt;
-        const double var = qq / cnt - mean * mean;
+        est[0] = ss / cnt;
+        est[1] = qq / cnt - est[0] * est[0];
+    }
+    __syncthreads();
+    double mean = est[0], var = est[1];
+    if (x_f32 && mean * mean > 256.0 * var) groupnorm_refine<256>(x_f32, b, g, C, G, HW, cnt, mean, var, red);
+    if (tid == 0) {
         mr[2 * i] = (float)mean;
         mr[2 * i + 1] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
     }
@@ -491,7 +536,7 @@ extern "C" int advgrpo_groupnorm_nhwc_x3(const float* x, void* y3, double* stats
     ADVGRPO_LAUNCH_CHECK();
     float* mr = reinterpret_cast<float*>(stats + (size_t)B * nchunks * G * 2);
     hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(B * G), dim3(64), 0, s, stats, mr, B, G, nchunks,
-                       (double)HW * (C / G), eps);
+                       (double)HW * (C / G), eps, x, C, HW);
     ADVGRPO_LAUNCH_CHECK();
     const int64_t total8 = (int64_t)B * HW * (C / 8);
     int64_t blocks = (total8 + 255) / 256;
@@ -514,12 +559,12 @@ extern "C" int advgrpo_groupnorm_nhwc_f16x2(const float* x, void* y3, double* st
     if (tile_partial) {     // the statistics came out of the producing convolution's epilogue: no pass over x for them
         ADVGRPO_CHECK(tile_rows > 0 && HW % tile_rows == 0, "groupnorm_f16x2: tile_rows %d must divide HW = %d", tile_rows, HW);
         hipLaunchKernelGGL(groupnorm_finalize_tiles_kernel, dim3(B * G), dim3(256), 0, s, tile_partial, mr, B, G, C, HW, tile_rows,
-                           (double)HW * (C / G), eps);
+                           (double)HW * (C / G), eps, x);
     } else {
         hipLaunchKernelGGL(groupnorm_stats_kernel<float>, dim3(nchunks, B), dim3(256), 0, s, x, stats, HW, C, G, ppb);
         ADVGRPO_LAUNCH_CHECK();
         hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(B * G), dim3(64), 0, s, stats, mr, B, G, nchunks,
-                           (double)HW * (C / G), eps);
+                           (double)HW * (C / G), eps, x, C, HW);
     }
     ADVGRPO_LAUNCH_CHECK();
     const int64_t total8 = (int64_t)B * HW * (C / 8);

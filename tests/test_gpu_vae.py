@@ -361,6 +361,41 @@ def test_vae_decode_f16x2_path_for_an_fp16_checkpoint(B, hw):
     assert not any(k.endswith("@f16") for k in dec_inexact.w)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("offset,tol", [(40.0, 3e-5), (400.0, 3e-5), (4000.0, 3e-4)])
+def test_groupnorm_statistics_with_a_mean_far_from_zero(offset, tol):
+    """the group statistics are f32 {sum, sum of squares} over blocks of 64 values (conv epilogue) or a thread's pixels (own
+    pass), combined in f64, variance = E[x^2] - E[x]^2: cancellation when |mean| >> std.  What is lost is the f32 rounding of the squares,
+    so the relative error of the variance grows as (mean / std)^2: without a guard 9e-5 of the output at mean / std = 34 (own pass; 1.6e-5
+    from the epilogue sums) and 7e-3 at 340.  Guard (vae.hip groupnorm_refine): when the first estimate has mean^2 > 256 var the finalize
+    workgroup re-reads its (image, group) and sums deviations from that estimate in f64 -- fp32-equivalent again at any mean (what is left
+    at 3 000 is the f32 subtraction x - mean of the apply pass, one ulp of x); never taken on ordinary inputs, whose bits are unchanged."""
+    from adv_grpo_amd import ops
+    B, H, W, C, Co = 2, 32, 32, 128, 128
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn(B, H, W, C, device="cuda", generator=g)
+    gw, gb = 1 + 0.1 * torch.randn(C, device="cuda", generator=g), 0.1 * torch.randn(C, device="cuda", generator=g)
+    w16 = (torch.randn(Co, 9 * C, device="cuda", generator=g) / (C * 9) ** 0.5).half()
+    bias = offset + 0.1 * torch.randn(Co, device="cuda", generator=g)
+    res = torch.randn(B, H, W, Co, device="cuda", generator=g)
+    a = ops.groupnorm_nhwc_f16x2(x, gw, gb, 32, 1e-6, True)
+    y = ops.conv3x3_f16x2(a, w16, bias=bias, residual=res, gn_stats=True)
+    ratio = (y.mean() / y.std()).item()
+    assert 0.5 * offset / 1.5 < ratio < 2 * offset
+    gw2, gb2 = 1 + 0.1 * torch.randn(Co, device="cuda", generator=g), 0.1 * torch.randn(Co, device="cuda", generator=g)
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(y.permute(0, 3, 1, 2).double(), 32, gw2.double(), gb2.double(), 1e-6)).permute(0, 2, 3, 1)
+
+    def value(n):       # fp16 pair -> f32
+        h = n.view(torch.float16).view(B, H, W, 3, Co)
+        return h[..., 0, :].float() + h[..., 2, :].float()
+    for n in (ops.groupnorm_nhwc_f16x2(y, gw2, gb2, 32, 1e-6, True, tile_stats=y.gn_tile_stats), ops.groupnorm_nhwc_f16x2(y, gw2, gb2, 32, 1e-6, True),
+              None):
+        v = value(n) if n is not None else ops.groupnorm_nhwc_x3(y, gw2, gb2, 32, 1e-6, True).float().view(B, H, W, 3, Co)[..., [0, 2], :].sum(-2)
+        assert torch.isfinite(v).all()
+        err = (v.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < tol, (offset, ratio, err)
+
+
 @pytest.mark.parametrize("B,H,W,C,Co,up", [(3, 24, 24, 128, 256, False), (2, 16, 16, 512, 512, True), (5, 40, 24, 256, 128, False)])
 def test_groupnorm_statistics_from_the_conv_epilogue(B, H, W, C, Co, up):
     """advgrpo_conv3x3_nhwc_f16x2's gn_partial: {sum, sum of squares} per block of 16 pixels x 4 output channels (HW is not a
