@@ -12,6 +12,11 @@ pooled_projections, ..., return_dict=False)[0]`` -- so that ``pipeline_with_logp
     timestep / 1000 and the model's Timesteps(scale=1000) multiplies it back: the same sinusoid argument;
   * ``pooled_projections`` is accepted and ignored (Qwen-Image conditions on the timestep only).
 Weights are loaded from a diffusers-named state dict (oracle/qwen_mmdit.py has the restated architecture, PARITY UNPINNED).
+Assumption: every prompt of a batch -- the negative and the positive half of the CFG batch included -- is handed over at ONE text length
+N_txt and no ``encoder_hidden_states_mask`` is applied: QwenImagePipeline pads to the longest prompt and masks the padding keys; here the caller
+(qwen_text_encoder.py, the trainer's data path) pads with the tokenizer's pad token and the padding positions attend and are attended like any other token.
+scripts/verify_against_diffusers.py pins the restatement against diffusers' masked forward on ragged lengths by running the shorter prompt unpadded here
+(what the mask makes of it there).
 
 Data layout in HBM (bf16), B = batch incl. the CFG halves, S = N_img + N_txt, D = 3072, 24 heads x 128:
   x [B*N_img, D], c [B*N_txt, D] residual streams, updated in place by the out-projection / FF2 epilogues
