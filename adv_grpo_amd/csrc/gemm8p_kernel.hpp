@@ -134,6 +134,11 @@ enum { EPI_PLAIN = 0, EPI_BIAS = F_BIAS, EPI_BIAS_RMS = F_BIAS | F_RMS, EPI_BIAS
        EPI_BIAS_GELU_AUX = F_BIAS | F_GELU | F_AUX_OUT, EPI_DGELU = F_DGELU };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// which classes write their output tile with streaming (nt) stores: 0 all (product), 1 all but gate + residual (its output is the next
+// LayerNorm's input), 2 none  -- A/B knob of scripts/probes/rollout_ab_inprocess.py builds
+#ifndef P8_NT_MODE
+#define P8_NT_MODE 0
+#endif
 #ifndef P8_EPI_AHEAD
 #define P8_EPI_AHEAD 3
 #endif
@@ -432,7 +437,8 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p_in, f32x4 (&acc)
                 }
                 const uint32_t o = __umul24(orow, (uint32_t)p.ldc) + n;
                 if (out_bf16) {
-                    p8_gst16_nt(p.C, (size_t)(o * 2u), pack4(v));
+                    if constexpr (P8_NT_MODE == 0 || (P8_NT_MODE == 1 && !G && !(EPI & F_GATE_RES))) p8_gst16_nt(p.C, (size_t)(o * 2u), pack4(v));
+                    else p8_gst16(p.C, (size_t)(o * 2u), pack4(v));
                 } else {
                     p8_gst16(p.C, (size_t)o * 4u, __builtin_bit_cast(uint4, make_float4(v[0].x, v[0].y, v[1].x, v[1].y)));
                     p8_gst16(p.C, (size_t)o * 4u + 16, __builtin_bit_cast(uint4, make_float4(v[2].x, v[2].y, v[3].x, v[3].y)));
