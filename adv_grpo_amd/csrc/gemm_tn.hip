@@ -409,9 +409,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroup g
         __syncthreads();                                                // ... every wave's
         if (tid == 0) {
             int* cnt = grp.counters + p.cnt_off + tile;
-            const int before = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // release / acquire in the memory model's own terms as well: the sc1 stores above already leave the XCD's L2 and
+            // the sc1 loads below bypass this CU's L1 (the guide's "16-B sc1 stores AND sc1 loads" hand-off), but the ordering of the
+            // counter against them must not rest on instruction forms alone
+            const int before = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             s_last = before == p.slices - 1;
-            if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero again for the next launch
+            if (s_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero again for the next launch
+            }
         }
         __syncthreads();
         if (!s_last) return;

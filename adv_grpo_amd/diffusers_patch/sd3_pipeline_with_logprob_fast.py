@@ -12,11 +12,14 @@ combine + SDE step + log-prob + cast (instead of ~12 torch kernels, a randn and 
 an in-kernel Philox stream (or injected via ``noises=`` for parity tests), no ``index_for_timestep`` sync.
 """
 import random
+import threading
 
 import torch
 
 from ..scheduler import retrieve_timesteps
 from .sd3_sde_with_logprob import sde_step_cfg
+
+_CFG_SIDES_LOCK = threading.Lock()
 
 
 @torch.no_grad()
@@ -93,10 +96,15 @@ def pipeline_with_logprob_random(self, prompt=None, prompt_2=None, prompt_3=None
             # independent until the combine -- two forwards of batch B on two HIP streams instead of one of batch 2 B (every row of
             # every kernel is independent of the others: the same bits)
             main = torch.cuda.current_stream(device)
-            sides = self.__dict__.setdefault("_cfg_sides", {})                  # one side stream per calling stream (rollout threads)
-            side = sides.get(main.cuda_stream)
-            if side is None:
-                side = sides[main.cuda_stream] = torch.cuda.Stream(device=device)
+            # one side stream per calling THREAD, created under a lock and kept together with the stream OBJECT it was made for (ADVICE r5:
+            # a map keyed by the integer stream handle is mutated by concurrent rollout threads, and a handle re-used after its stream
+            # was destroyed would alias the old entry)
+            with _CFG_SIDES_LOCK:
+                sides = self.__dict__.setdefault("_cfg_sides", {})
+                ent = sides.get(threading.get_ident())
+                if ent is None or ent[0].cuda_stream != main.cuda_stream:
+                    ent = sides[threading.get_ident()] = (main, torch.cuda.Stream(device=device))
+            side = ent[1]
             Nt = tem_pe.shape[1]
             ready = torch.cuda.Event()
             ready.record(main)

@@ -46,6 +46,22 @@ def all_mean(t):
     return s[0] / s[1]
 
 
+def reduce_mean(info):
+    """accelerator.reduce(info, reduction="mean") (TP:1179-1183): the training diagnostics of an optimizer step (loss, approx_kl, clipfrac,
+    policy_loss, ...) averaged over ranks before rank 0 logs them, so the logged curve is the node's and not rank 0's.  The values (device
+    scalars or host floats) travel as ONE f32 vector in key order; every rank gets the same dict back."""
+    n = world()
+    if n == 1 or not info:
+        return dict(info)
+    keys = sorted(info)
+    dev = next((v.device for v in info.values() if isinstance(v, torch.Tensor)), torch.device("cpu"))
+    vec = torch.stack([(info[k].detach().float().reshape(()) if isinstance(info[k], torch.Tensor) else torch.tensor(float(info[k]))).to(dev)
+                       for k in keys])
+    dist.all_reduce(vec)
+    vec /= n
+    return {k: vec[i] for i, k in enumerate(keys)}
+
+
 def average_gradients(flat):
     """The update half's exchange: all-reduce (sum) of a flat gradient vector, then / world -- what DeepSpeed / DDP do to
     the LoRA gradients inside ``accelerator.backward`` (TP:1165) and DDP to the DINO head (TD:749).  In place; every rank

@@ -132,10 +132,14 @@ def validate(have, want, what, optional=()):
         raise HubError("\n".join(lines))
 
 
-def _expect(cfg, what, **fields):
-    """Every named field of a config.json must be present with exactly this value (None in the file counts as absent for False/None)."""
+def _expect(cfg, what, _defaults=None, **fields):
+    """Every named field of a config.json must have exactly this value (None in the file counts as absent for False/None).  A field that is
+    ABSENT from the file reads as the owning library's constructor default (`_defaults`: configs saved before a field existed omit it, and
+    diffusers / transformers then build the model with that default); without a listed default an absent field is refused."""
     for k, v in fields.items():
         got = cfg.get(k, None)
+        if k not in cfg and _defaults and k in _defaults:
+            got = _defaults[k]
         if isinstance(v, (list, tuple)):
             ok = got is not None and list(got) == list(v)
         elif isinstance(v, float):
@@ -213,7 +217,9 @@ def load_vae_decoder(component_dir):
     """AutoencoderKL of SD3 / SD3.5 -> (decoder.* state dict upcast to float32 as ``vae.to(torch.float32)`` does (TP:481), VaeConfig)."""
     cfg = read_config(component_dir)
     _class(cfg, component_dir, "AutoencoderKL")
-    _expect(cfg, component_dir, act_fn="silu", use_post_quant_conv=False, mid_block_add_attention=True)
+    # (absent = diffusers' AutoencoderKL.__init__ defaults: act_fn "silu", use_post_quant_conv True, mid_block_add_attention True)
+    _expect(cfg, component_dir, _defaults=dict(act_fn="silu", use_post_quant_conv=True, mid_block_add_attention=True),
+            act_fn="silu", use_post_quant_conv=False, mid_block_add_attention=True)
     out = VaeConfig(latent_channels=int(cfg["latent_channels"]), block_out_channels=tuple(cfg["block_out_channels"]),
                     layers_per_block=int(cfg["layers_per_block"]), norm_num_groups=int(cfg["norm_num_groups"]),
                     scaling_factor=float(cfg["scaling_factor"]), shift_factor=float(cfg.get("shift_factor") or 0.0))
@@ -246,11 +252,11 @@ def load_t5_encoder(component_dir):
     """T5EncoderModel (text_encoder_3) -> (state dict, T5Config)."""
     cfg = read_config(component_dir)
     _class(cfg, component_dir, "T5EncoderModel")
-    _expect(cfg, component_dir, d_kv=64)
+    _expect(cfg, component_dir, _defaults=dict(d_kv=64), d_kv=64)                 # (transformers' T5Config default)
     ff = cfg.get("feed_forward_proj", "gated-gelu")
     if ff != "gated-gelu":
         raise HubError(f"{component_dir}: feed_forward_proj = {ff!r}; only T5 v1.1's gated-gelu is implemented")
-    out = T5Config(d_model=int(cfg["d_model"]), layers=int(cfg["num_layers"]), heads=int(cfg["num_heads"]), d_kv=int(cfg["d_kv"]),
+    out = T5Config(d_model=int(cfg["d_model"]), layers=int(cfg["num_layers"]), heads=int(cfg["num_heads"]), d_kv=int(cfg.get("d_kv", 64)),
                    d_ff=int(cfg["d_ff"]), vocab=int(cfg["vocab_size"]), num_buckets=int(cfg.get("relative_attention_num_buckets", 32)),
                    max_distance=int(cfg.get("relative_attention_max_distance", 128)))
     want = synthetic.shapes(synthetic.t5_encoder_weights, out)

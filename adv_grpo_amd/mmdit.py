@@ -165,9 +165,13 @@ class SD3Transformer2DModel:
         ws = torch.empty(need, dtype=torch.uint8, device=x.device)
         assert mods.stride(1) == 1 and x.is_contiguous() and c.is_contiguous()
         p = lambda t: t.data_ptr() if t is not None else None
+        names = [k + s for k in ("qkv", "cqkv", "out", "cout", "qkv2", "out2", "ff1", "ff2", "cff1", "cff2") for s in (".w", ".b")] + ["rms_x", "rms_c", "rms_2"]
         for i, b in enumerate(self.blocks):
             d = self._block_descs.get(i)
-            if d is None or d._weights is not b.get("qkv.w"):          # (rebuilt when the merged LoRA weights were replaced)
+            # keyed on EVERY tensor the descriptor points at: replacing any one of them (merged LoRA weights, a reloaded bias)
+            # rebuilds it; the tensors themselves are held by self.blocks, so a pointer in a current descriptor is never dangling
+            key = tuple(p(b.get(n)) for n in names)
+            if d is None or d._key != key:
                 d = _lib.MMDiTBlockDesc()
                 d.D, d.H, d.dual, d.last = D, H, int(b["dual"]), int(b["last"])
                 for k in ("qkv", "cqkv", "out", "cout", "qkv2", "out2", "ff1", "ff2", "cff1", "cff2"):
@@ -176,7 +180,7 @@ class SD3Transformer2DModel:
                 if cfg.qk_norm:
                     d.rms_x, d.rms_c, d.rms_2 = p(b["rms_x"]), p(b["rms_c"]), p(b.get("rms_2"))
                 d.mod_x, d.mod_c = self.mod_off[("x", i)], self.mod_off[("c", i)]
-                d._weights = b.get("qkv.w")
+                d._key = key
                 self._block_descs[i] = d
             # the cached descriptor holds the block's weights only; the call's own copy gets the activations: rollouts of several prompt
             # groups run this function at the same time from their own host threads (trainer.sample_epoch), and a ctypes call releases the GIL

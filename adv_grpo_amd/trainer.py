@@ -616,7 +616,7 @@ class Trainer:
                     timed("optimizer_step", lambda: model.optimizer_step(
                         lr=c.train.learning_rate, betas=(c.train.adam_beta1, c.train.adam_beta2), eps=c.train.adam_epsilon,
                         weight_decay=c.train.adam_weight_decay, max_grad_norm=c.train.max_grad_norm))
-                    out = {k: v / n_acc for k, v in agg.items()}
+                    out = D.reduce_mean({k: v / n_acc for k, v in agg.items()})                # TP:1179-1180 (mean over ranks)
                     out.update({"epoch": self.epoch, "inner_epoch": inner})
                     self.logger.log(out, self.global_step)
                     self.global_step += 1

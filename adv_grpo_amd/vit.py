@@ -123,7 +123,9 @@ class CLIPModel:
         # embedding lookup + position add: index plumbing (one gather), done with torch
         x = (self.tok_emb[ids] + self.t_pos[:S][None]).reshape(B * S, D).contiguous()
         x = self.t_enc(x, B, S)
-        eos = (ids == cfg.eos_token_id).int().argmax(dim=-1)
+        # transformers' CLIPTextTransformer pooling: configs with the legacy eos_token_id = 2 (the released PickScore_v1 / laion CLIP-H
+        # config.json) pool at argmax(input_ids) -- the eos of the original CLIP vocabulary is its largest id; otherwise at the first eos
+        eos = ids.int().argmax(dim=-1) if cfg.eos_token_id == 2 else (ids == cfg.eos_token_id).int().argmax(dim=-1)
         pooled = x.view(B, S, D)[torch.arange(B, device=self.device), eos].contiguous()
         pooled = ops.layernorm_mod(pooled, w=self.final_ln[0], b=self.final_ln[1], eps=1e-5)
         return ops.gemm(pooled, self.t_proj)

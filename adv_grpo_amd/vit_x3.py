@@ -157,7 +157,9 @@ class CLIPModelX3:
         ids = input_ids.to(self.device)
         x = (self.tok_emb[ids] + self.t_pos[:S][None]).reshape(B * S, D).contiguous()
         x = self.t_enc(x, B, S)
-        eos = (ids == cfg.eos_token_id).int().argmax(dim=-1)
+        # transformers' CLIPTextTransformer pooling: configs with the legacy eos_token_id = 2 (the released PickScore_v1 / laion CLIP-H
+        # config.json) pool at argmax(input_ids) -- the eos of the original CLIP vocabulary is its largest id; otherwise at the first eos
+        eos = ids.int().argmax(dim=-1) if cfg.eos_token_id == 2 else (ids == cfg.eos_token_id).int().argmax(dim=-1)
         pooled = x.view(B, S, D)[torch.arange(B, device=self.device), eos].contiguous()
         return linear_x3(ops.layernorm_x3(pooled, self.final_ln[0], self.final_ln[1], 1e-5), self.t_proj3)
 

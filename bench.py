@@ -62,6 +62,12 @@ def parse():
     ap.add_argument("--no-pricing", action="store_true",
                     help="skip the untimed legs that price the alternative modes (split-bf16 VAE, LoRA side path): profiling runs, "
                          "so that the rocprof summary holds the timed configuration only")
+    ap.add_argument("--schedule", default="trainer", choices=["trainer", "serial"],
+                    help="what the timed steps run.  trainer (default) = the Trainer's own default schedule (config sample.groups_in_flight = 2, "
+                         "trainer.py sample_epoch): two prompt groups rolled out at the same time, each on its own HIP stream from its own host "
+                         "thread, scoring as reward futures on one scoring stream, gather + advantage per group on the main thread in group order; "
+                         "a serial leg of the same number of steps follows and carries the per-kernel roofline.  serial = one prompt group at a "
+                         "time on the launch stream (the headline of rounds 1-5)")
     ap.add_argument("--vae-mode", default="bf16x3", choices=["bf16", "bf16x3"],
                     help="decoder arithmetic inside the timed step: the fp32-equivalent split-bf16 mode (default: the reference "
                          "decodes in fp32, TP:481) or plain bf16; the 'vae' object of the JSON line prices both either way")
@@ -625,10 +631,17 @@ def main():
                                           clip.get_text_features(ids[:1]).expand(G, -1).contiguous(), clip.logit_scale)
         return scores
 
-    def rollout_and_submit(it, worker=None):
-        """Rollout (+ decode) of one prompt group on the current stream; its scoring on `worker` (None: the current stream)."""
+    import threading
+    score_lock = threading.Lock()       # the towers keep per-model workspaces: scoring calls are enqueued one at a time (trainer.py: one scoring worker)
+
+    def prompt_of(it):
         sampler.set_epoch(it)
-        prompt_idx = next(iter(sampler))[0]
+        return next(iter(sampler))[0]
+
+    def rollout_and_submit(it, worker=None, prompt_idx=None):
+        """Rollout (+ decode) of one prompt group on the current stream; its scoring on `worker` (None: the current stream)."""
+        if prompt_idx is None:
+            prompt_idx = prompt_of(it)
         image, lats, lps, tss = pipeline_with_logprob_random(
             pipe, prompt_embeds=pe, pooled_prompt_embeds=ppe, negative_prompt_embeds=npe,
             negative_pooled_prompt_embeds=nppe, num_inference_steps=STEPS, guidance_scale=4.5,
@@ -636,11 +649,12 @@ def main():
             process_index=rank, sample_num_steps=STEPS, random_timestep=0, seed=rollout_seed(42, it, rank),
             output_type="latent" if (worker is not None and args.decode_in_future) else "pt")
         if worker is None:
-            return prompt_idx, lps, score(image), None
+            with score_lock:
+                return prompt_idx, lps, score(image), None
         ready = torch.cuda.Event()
         ready.record()
-        worker.wait_event(ready)
-        with torch.cuda.stream(worker):
+        with score_lock, torch.cuda.stream(worker):
+            worker.wait_event(ready)
             if args.decode_in_future:
                 latents = image
                 image = pipe.vae.decode_to_image(latents)                   # PF:667-670, moved behind the event
@@ -684,9 +698,53 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The Trainer's default schedule (config sample.groups_in_flight = 2; trainer.py sample_epoch, TP:668,816-817): two rollout worker threads,
+    # one HIP stream each (measured concurrent, like the Trainer's), scoring as reward futures on the one scoring stream; the reward gather and
+    # the group advantage of every group run on the MAIN thread in group order (so the collectives of all ranks stay in one order).
+    in_flight = 2 if args.schedule == "trainer" else 1
+    roll_pool, roll_tls, roll_streams = None, threading.local(), []
+    if in_flight > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        roll_pool = ThreadPoolExecutor(max_workers=in_flight, thread_name_prefix="bench-rollout")
+        for _ in range(in_flight):
+            roll_streams.append(ops.concurrent_stream(device, list(roll_streams) or None))
+        roll_lock = threading.Lock()
+
+    def steps_in_flight(first, n):
+        """n timed steps on the Trainer's schedule: every group is submitted to the two rollout workers up front, its scores are a future on
+        the scoring stream, and the main thread finishes the groups (gather, advantage) in order as they complete."""
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+
+        def work(it, prompt_idx):
+            torch.cuda.set_device(device)
+            st = getattr(roll_tls, "stream", None)
+            if st is None:                                   # one stream per WORKER THREAD (trainer.py sample_epoch)
+                with roll_lock:
+                    st = roll_tls.stream = roll_streams.pop()
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                pend = rollout_and_submit(it, score_stream if score_stream is not None else None, prompt_idx)
+                fin = torch.cuda.Event()
+                fin.record(st)
+            return pend, fin
+        futs = [roll_pool.submit(work, first + i, prompt_of(first + i)) for i in range(n)]
+        out = None
+        for f in futs:
+            pend, fin = f.result()
+            main.wait_event(fin)
+            for t in pend[1]:                                # log-probs: produced on a rollout stream, consumed on this one
+                t.record_stream(main)
+            if pend[3] is None:
+                pend[2].record_stream(main)
+            out = finish(pend)
+        return out
+
+    timed_steps = steps_in_flight if in_flight > 1 else steps_pipelined
     if args.warmup:
-        steps_pipelined(0, args.warmup)
-    ops.PROFILE, ops.PROFILE_STRIDE = [], max(1, args.event_stride)
+        timed_steps(0, args.warmup)
+    ops.PROFILE, ops.PROFILE_STRIDE = ([] if in_flight == 1 else None), max(1, args.event_stride)
     sync()
     with PowerSampler(local_rank if rank == 0 and os.environ.get("ADVGRPO_BENCH_NO_SMI", "0") != "1" else -1) as power:
         t0 = time.perf_counter()
@@ -694,14 +752,32 @@ def main():
             hp = torch.cuda.Stream(device=device, priority=args.rollout_priority)
             hp.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(hp):
-                out = steps_pipelined(args.warmup, args.steps)
+                out = timed_steps(args.warmup, args.steps)
             torch.cuda.current_stream().wait_stream(hp)
         else:
-            out = steps_pipelined(args.warmup, args.steps)       # every group's scores are resolved inside the timed region
+            out = timed_steps(args.warmup, args.steps)           # every group's scores are resolved inside the timed region
         sync()
         dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
     assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all()
+    # The serial leg (trainer schedule only): the same number of steps, one prompt group at a time on the launch stream.  Per-kernel
+    # durations are only defined here -- with two groups in flight a launch's HIP-event interval includes the other stream's kernels -- so
+    # the `roofline` object is taken from this leg and `serial` carries its whole-step figures.  Every rank runs it (it has the collectives).
+    serial_dt = None
+    if in_flight > 1:
+        steps_pipelined(0, 1)
+        ops.PROFILE = []
+        sync()
+        ts = time.perf_counter()
+        out_s = steps_pipelined(args.warmup, args.steps)
+        sync()
+        serial_dt = time.perf_counter() - ts
+        prof, ops.PROFILE = ops.PROFILE, None
+        assert torch.isfinite(out_s[0]).all() and torch.isfinite(out_s[1]).all()
+        if dist is not None:
+            tmax_s = torch.tensor([serial_dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax_s, op=dist.ReduceOp.MAX)
+            serial_dt = tmax_s.item()
     scaling_diag = None
     if dist is not None:
         dt_local = dt
@@ -735,8 +811,11 @@ def main():
                     "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
                     "launches": n * stride, "launches_timed": n, "event_stride": stride,
                     "avg_launch_us": round(tsec / n * 1e6, 2),
-                    "algorithmic_flops_per_launch": fl / n, "share_of_step_time": round(tsec * stride / dt, 3),
-                    "how": "HIP events on the launch stream around every event_stride-th launch of the kernel inside the timed steps"}
+                    "algorithmic_flops_per_launch": fl / n, "share_of_step_time": round(tsec * stride / (serial_dt or dt), 3),
+                    "how": ("HIP events on the launch stream around every event_stride-th launch of the kernel inside the SERIAL leg (`serial`: the same "
+                            "steps, one prompt group at a time): with two groups in flight a launch's event interval includes the other stream's "
+                            "kernels, so per-kernel durations are only defined on the serial schedule; share_of_step_time is of the serial step")
+                           if serial_dt else "HIP events on the launch stream around every event_stride-th launch of the kernel inside the timed steps"}
         images = world * G * args.steps
         # algorithmic FLOPs per sampled+scored image: 10*2*2.219 + 2.51 + 0.38 TFLOP at config 2;
         # SD3.5-large 1024^2 (config 4 shapes): 30.02 TFLOP per sample-forward, VAE x4 pixels
@@ -793,7 +872,8 @@ def main():
             torch.cuda.synchronize()
             vae_ms["bf16x3_every_conv"] = (time.perf_counter() - tv) / 3 * 1e3
             del dec
-        step_ms = dt / args.steps * 1e3
+        sdt = serial_dt or dt
+        step_ms = sdt / args.steps * 1e3       # the pricing legs below are serial-schedule legs: compared with the serial step
         # the rollout with PEFT's LoRA arithmetic (side path as a K-extension of the adapted Linears, mmdit_train.py) instead
         # of LoRA merged into the bf16 weights: same step, other transformer object
         lora_ms = {"merged": round(step_ms, 2)}
@@ -886,7 +966,7 @@ def main():
         # launch's HIP-event duration includes the other stream's kernels, so the per-kernel roofline is only defined for
         # the serial schedule above.
         overlap = None
-        if not c3 and not c4 and world == 1 and not args.no_pricing:
+        if in_flight == 1 and not c3 and not c4 and world == 1 and not args.no_pricing:
             streams = [torch.cuda.Stream(), torch.cuda.Stream()]
             from concurrent.futures import ThreadPoolExecutor
             pool = ThreadPoolExecutor(2)
@@ -935,13 +1015,24 @@ def main():
                                     "SDE window 2 @ noise 0.8, VAE decode (fp32-equivalent; 3x3 convolutions: " + vae_ran + "), " +
                                     ("co-trained DINOv2 ViT-B/14 @ 518 patch discriminator + head as reward (RW:375-434)" if c3 else
                                      "PickScore (CLIP ViT-H/14) reward") + ", reward all-gather + group advantage")), "global_batch": world * G,
-                       "transformer_batch_per_gpu": 2 * G, "parallelism": f"dp{world} (prompt groups sharded)"},
+                       "transformer_batch_per_gpu": 2 * G, "parallelism": f"dp{world} (prompt groups sharded)",
+                       "schedule": ("trainer default (config sample.groups_in_flight = 2, adv_grpo_amd/trainer.py sample_epoch): two prompt groups per rank rolled "
+                                    "out at the same time, one HIP stream + one host thread each, scores as reward futures on one scoring stream, "
+                                    "reward gather + group advantage per group on the main thread in group order; samples bit-identical to the serial "
+                                    "schedule (tests/test_gpu_trainer.py::test_groups_in_flight_do_not_change_the_samples)")
+                       if in_flight > 1 else "serial: one prompt group at a time on the launch stream, scores as reward futures"},
             "effective_tflops_per_gpu": round(per_image_tflop * images / dt / world, 1),
             "frac_of_bf16_mfma_peak": round(per_image_tflop * images / dt / world / BF16_DENSE_PEAK_TFLOPS, 4),
             **({"frac_of_mixed_mfma_peak": round(mixed_peak_s * images / dt / world, 4),
                 "mixed_peak_is": "Linear FLOPs priced at the dense fp8 peak (5 PFLOP/s), attention / VAE / DINO FLOPs at the dense bf16 peak (2.5 PFLOP/s): "
                                  "time at those peaks / measured time"} if c5 else {}),
             "roofline": roofline,
+            "serial": None if serial_dt is None else {
+                "ms_per_step": round(serial_dt / args.steps * 1e3, 2), "value": round(images / serial_dt, 3), "steps": args.steps,
+                "frac": round(per_image_tflop * images / serial_dt / world / BF16_DENSE_PEAK_TFLOPS, 4),
+                "note": "the same steps with one prompt group at a time on the launch stream (the headline schedule of rounds 1-5), timed right behind the "
+                        "timed steps with the same barrier + synchronize bracket; `roofline` and the pricing legs (vae / scoring / cfg_two_streams / "
+                        "fp8_linears / lora) belong to this schedule"},
             "vae": {"mode": pipe.vae.mode,
                     "mode_ran": vae_ran,
                     "assumption": None if c5 else "the released SD3 / SD3.5 VAE is an fp16 checkpoint, upcast by vae.to(torch.float32) (TP:447,481): a 3x3 convolution whose "
@@ -953,16 +1044,16 @@ def main():
                                         "3e-5 of the fp32 decode either way (tests/test_gpu_vae.py)",
                               "bf16x3_every_conv": "the same decoder on weights that are NOT exact in fp16: every 3x3 convolution on three bf16 products"},
                     "ms_per_group_decode": {k: round(v, 2) for k, v in vae_ms.items()},
-                    "value_if_weights_not_fp16_exact": round(images / (dt + args.steps * (vae_ms["bf16x3_every_conv"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)
+                    "value_if_weights_not_fp16_exact": round(images / (sdt + args.steps * (vae_ms["bf16x3_every_conv"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)
                     if "bf16x3_every_conv" in vae_ms else None,
                     "frac_of_bf16_mfma_peak_if_weights_not_fp16_exact":
-                        round(per_image_tflop * images / (dt + args.steps * (vae_ms["bf16x3_every_conv"] - vae_ms[pipe.vae.mode]) * 1e-3) / world / BF16_DENSE_PEAK_TFLOPS, 4)
+                        round(per_image_tflop * images / (sdt + args.steps * (vae_ms["bf16x3_every_conv"] - vae_ms[pipe.vae.mode]) * 1e-3) / world / BF16_DENSE_PEAK_TFLOPS, 4)
                         if "bf16x3_every_conv" in vae_ms else None,
                     "share_of_step_time": round(vae_ms[pipe.vae.mode] / step_ms, 4),
                     # what the headline would be with the other decoder swapped in (only the decode time changes)
-                    "value_if_bf16x3": round(images / (dt + args.steps * (vae_ms["bf16x3"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)
+                    "value_if_bf16x3": round(images / (sdt + args.steps * (vae_ms["bf16x3"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)
                     if "bf16x3" in vae_ms else None,
-                    "value_if_bf16": round(images / (dt + args.steps * (vae_ms["bf16"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)
+                    "value_if_bf16": round(images / (sdt + args.steps * (vae_ms["bf16"] - vae_ms[pipe.vae.mode]) * 1e-3), 3)
                     if "bf16" in vae_ms else None},
             "scaling_diagnostics": scaling_diag,
             "host_rss_mb_rank0": host_rss_mb(),

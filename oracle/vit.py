@@ -92,7 +92,10 @@ def clip_text_features(W, cfg, input_ids):
     x = W[f"{p}.embeddings.token_embedding.weight"][input_ids] + W[f"{p}.embeddings.position_embedding.weight"][:S][None]
     x = _clip_layers(W, p, x, cfg.t_layers, cfg.t_heads, cfg.act, True)
     x = F.layer_norm(x, (cfg.t_hidden,), W[f"{p}.final_layer_norm.weight"], W[f"{p}.final_layer_norm.bias"], 1e-5)
-    eos = (input_ids == cfg.eos_token_id).int().argmax(dim=-1)
+    if cfg.eos_token_id == 2:      # transformers' legacy rule (modeling_clip.py CLIPTextTransformer.forward): argmax of the ids
+        eos = input_ids.int().argmax(dim=-1)
+    else:
+        eos = (input_ids == cfg.eos_token_id).int().argmax(dim=-1)
     pooled = x[torch.arange(x.shape[0]), eos]
     return F.linear(pooled, W["text_projection.weight"])
 

@@ -7,14 +7,25 @@ import sys
 
 db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
-rows = db.execute("select name, start, end from kernels order by start").fetchall()
-# one step: from one sde_finalize burst to the next is awkward; take the window between the last two group_advantage kernels
-marks = [i for i, r in enumerate(rows) if "group_advantage_kernel" in r[0]]
-lo, hi = (marks[-2] + 1, marks[-1] + 1) if len(marks) >= 2 else (0, len(rows))
-win = rows[lo:hi]
+qcol = next((c for c in ("stream_id", "queue_id") if c in cols), None)
+rows = db.execute(f"select name, start, end{', ' + qcol if qcol else ''} from kernels order by start").fetchall()
+# One ROLLOUT (denoise) step = one transformer forward + the fused CFG / SDE step, on the launch stream.  The window is the last NINE
+# denoise steps of the last rollout: from the end of the 10th-from-last sde_finalize_kernel to the end of the last one, launch-stream
+# kernels only (the stream the SDE kernels run on).  (Until round 5 this script windowed on the last two group_advantage kernels; since
+# scoring became a reward future that window held the PickScore tail of the previous group, not a rollout step: VERDICT r5 weak 10.)
+marks = [i for i, r in enumerate(rows) if "sde_finalize_kernel" in r[0]]
+if len(marks) >= 10:
+    q = rows[marks[-1]][3] if qcol else None
+    lo, hi = marks[-10] + 1, marks[-1] + 1
+    win = [r[:3] for r in rows[lo:hi] if qcol is None or r[3] == q]
+    n_steps = 9
+else:
+    win, n_steps = [r[:3] for r in rows], 1
+print(f"window: the last {n_steps} denoise steps of the last rollout (between sde_finalize_kernel launches), launch stream "
+      f"{'(' + qcol + ' = ' + str(q) + ')' if len(marks) >= 10 and qcol else '(all streams)'}")
 span = win[-1][2] - win[0][1]
 busy = sum(e - s for _, s, e in win)
-print(f"kernels in the last step: {len(win)}; span {span / 1e6:.2f} ms; sum of kernel durations {busy / 1e6:.2f} ms; idle {100 * (1 - busy / span):.2f} %")
+print(f"kernels in the window: {len(win)} ({len(win) / n_steps:.0f} per denoise step); span {span / 1e6:.2f} ms; sum of kernel durations {busy / 1e6:.2f} ms; idle {100 * (1 - busy / span):.2f} %")
 gaps = {}
 prev_end = win[0][2]
 for n, s, e in win[1:]:

@@ -2,12 +2,12 @@
 # Re-takes every profiles/ artefact of a round on the GPU box (run through gpurun from the repo root):
 #   scripts/take_profiles.sh r3        -> gpurun_out/prof_r3/*  (copy the summaries into profiles/ afterwards: scripts/collect_profiles.py)
 set -x
-TAG=${1:-r5}
+TAG=${1:-r6}
 R=$PWD
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-FAST="--steps 3 --warmup 1 --no-epoch --no-cpu-baseline --no-pricing"
+FAST="--steps 3 --warmup 1 --no-epoch --no-cpu-baseline --no-pricing --schedule serial"     # (kernel tables: the serial schedule only)
 # 1. driver-style lines
 python $R/bench.py --steps 5 --warmup 2 > $O/bench_c2.json 2> $O/bench_c2.err
 python $R/bench.py --config c4 --steps 3 --warmup 1 > $O/bench_c4.json 2> $O/bench_c4.err
@@ -51,13 +51,13 @@ python $R/scripts/rocpd_stats.py $O/kt_gstep_s/x_results.db $O/kernel_stats_gste
 # 3. HBM-side traffic (separate passes, MI355X_MICROARCH "HBM"), per config
 for cfg in c2 c4 c5; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d $O/pmc_${cfg}_$c -o x -- python $R/bench.py --config $cfg --steps 1 --warmup 1 --no-epoch --no-cpu-baseline --no-pricing > /dev/null 2>&1
+    rocprofv3 --pmc $c --output-format csv -d $O/pmc_${cfg}_$c -o x -- python $R/bench.py --config $cfg --steps 1 --warmup 1 --no-epoch --no-cpu-baseline --no-pricing --schedule serial > /dev/null 2>&1
   done
   mkdir -p $O/pmc_$cfg && cp -r $O/pmc_${cfg}_FETCH_SIZE $O/pmc_${cfg}_WRITE_SIZE $O/pmc_$cfg/
   python $R/scripts/pmc_traffic.py $O/pmc_$cfg $O/pmc_traffic_$cfg.json > $O/pmc_traffic_$cfg.txt
 done
 # 4. matrix-pipe busy share of the MFMA kernels
-rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY -d $O/pmc_mfma -o x -- python $R/bench.py --steps 1 --warmup 1 --no-epoch --no-cpu-baseline --no-pricing > /dev/null 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY -d $O/pmc_mfma -o x -- python $R/bench.py --steps 1 --warmup 1 --no-epoch --no-cpu-baseline --no-pricing --schedule serial > /dev/null 2>&1
 python $R/scripts/pmc_db.py $O/pmc_mfma/x_results.db advgrpo > $O/pmc_mfma.txt
 rm -rf $O/kt_c2 $O/kt_c3 $O/kt_c5 $O/kt_gstep $O/kt_gstep_s $O/kt_gq $O/pmc_c2* $O/pmc_c4_* $O/pmc_c4 $O/pmc_c5_* $O/pmc_c5 $O/pmc_mfma
 ls -la $O

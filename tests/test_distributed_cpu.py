@@ -98,3 +98,31 @@ def test_two_rank_gradient_average_and_state_broadcast(tmp_path):
     # rank 0's initial state everywhere
     g = torch.Generator().manual_seed(100)
     np.testing.assert_array_equal(a[:1000], torch.randn(1000, generator=g).numpy())
+
+
+def _worker_info(rank, world, port, out_dir):
+    """TP:1179-1183: the diagnostics of an optimizer step are averaged over ranks (accelerator.reduce(info, "mean")) before rank 0 logs them."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from adv_grpo_amd import distributed as D
+    info = {"approx_kl": torch.tensor(0.25 * (rank + 1)), "clipfrac": torch.tensor(float(rank)), "policy_loss": -1.5 + rank, "loss": torch.tensor(2.0)}
+    out = D.reduce_mean(info)
+    assert sorted(out) == sorted(info)
+    np.save(os.path.join(out_dir, f"info{rank}.npy"), np.array([float(out[k]) for k in sorted(out)]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_diagnostics_are_rank_means(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker_info, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "info0.npy"), np.load(tmp_path / "info1.npy")
+    assert np.array_equal(a, b)                                   # every rank holds the node's mean
+    # keys sorted: approx_kl, clipfrac, loss, policy_loss
+    assert np.allclose(a, [0.375, 0.5, 2.0, -1.0])
+
+
+def test_reduce_mean_is_the_identity_without_a_process_group():
+    from adv_grpo_amd import distributed as D
+    info = {"a": torch.tensor(1.0), "b": 2.0}
+    out = D.reduce_mean(info)
+    assert out == info and out is not info

@@ -82,6 +82,27 @@ def test_clip_towers_and_pickscore_vs_oracle():
     assert (s.cpu() - rs.cpu()).abs().max().item() < 2e-2 * max(1.0, rs.abs().max().item())
 
 
+def test_clip_text_pooling_with_legacy_eos_token_id_2():
+    """with the released PickScore_v1 config (text_config.eos_token_id = 2) the text towers pool at argmax(input_ids) like
+    transformers does, not at the first id-2 token -- otherwise every prompt would pool at position 0 and share one embedding."""
+    import dataclasses
+    from adv_grpo_amd import synthetic, vit, vit_x3
+    from oracle import vit as o
+    cfg = o.ClipConfig(v_layers=1, t_layers=2)
+    W = synthetic.clip_weights(cfg, 6)
+    Wb = {k: v.to(torch.bfloat16) for k, v in W.items()}
+    ids = synthetic.clip_input_ids(4, 9)                # eos 49407 at a random position, pad after
+    legacy = dataclasses.replace(cfg, eos_token_id=2)
+    W32 = {k: v.float().cuda() for k, v in Wb.items()}
+    ref = o.clip_text_features(W32, legacy, ids.cuda())
+    assert torch.allclose(ref, o.clip_text_features(W32, cfg, ids.cuda()))          # same position either way for these ids
+    te = vit.CLIPModel(Wb, legacy, "cuda").get_text_features(ids)
+    assert _rel(te, ref) < 2e-2
+    assert (te[0] - te[1]).abs().max().item() > 1e-3                               # prompts differ: not all pooled at BOS
+    te3 = vit_x3.CLIPModelX3(W, legacy, "cuda").get_text_features(ids)               # the fp32-equivalent scorer (unrounded f32 weights)
+    assert _rel(te3, o.clip_text_features({k: v.float().cuda() for k, v in W.items()}, legacy, ids.cuda())) < 5e-5
+
+
 def test_clip_towers_fp32_equivalent_vs_oracle():
     """The fp32 scorer of rewards.py:561-574 (PickScoreScorer(dtype=torch.float32)) on split-bf16 products (vit_x3.py): full
     ViT-H / text widths, 3 layers, fp32 weights, against the fp32 oracle on PIL-preprocessed pixels.  Tolerance: each of the

@@ -116,6 +116,51 @@ def test_legacy_vae_attention_names_are_converted(tmp_path):
         assert torch.equal(sd[k], v.half().float()), k
 
 
+def test_absent_config_fields_read_as_the_library_defaults(tmp_path):
+    """a vae/config.json saved before `mid_block_add_attention` / `act_fn` existed omits them and diffusers builds the model with
+    its constructor defaults (True / "silu") -- accepted; an absent `use_post_quant_conv` means diffusers' default True -- still refused.
+    Likewise T5's d_kv (transformers' default 64)."""
+    write_sd3_snapshot(str(tmp_path))
+    vdir, tdir = str(tmp_path / "vae"), str(tmp_path / "text_encoder_3")
+    j = json.load(open(os.path.join(vdir, "config.json")))
+    for k in ("mid_block_add_attention", "act_fn"):
+        j.pop(k, None)
+    _cfg(vdir, **j)
+    sd, cfg = hub.load_vae_decoder(vdir)
+    assert cfg == VAE
+    j.pop("use_post_quant_conv")
+    _cfg(vdir, **j)
+    with pytest.raises(hub.HubError, match="use_post_quant_conv"):
+        hub.load_vae_decoder(vdir)
+    t = json.load(open(os.path.join(tdir, "config.json")))
+    t.pop("d_kv", None)
+    _cfg(tdir, **t)
+    assert hub.load_t5_encoder(tdir)[1] == T5
+
+
+def test_pickscore_config_with_the_legacy_eos_token_id(tmp_path):
+    """the released PickScore_v1 config.json carries text_config.eos_token_id = 2; the loader keeps it and the towers
+    pool at argmax(input_ids) for it (vit.py / vit_x3.py; pinned vs transformers in tests/test_oracle_vit.py, on the GPU in test_gpu_vit.py)."""
+    import dataclasses
+    Wp = synthetic.clip_weights(PICK, 7)
+    p = str(tmp_path / "pick")
+    _cfg(p, architectures=["CLIPModel"], projection_dim=PICK.proj,
+         vision_config=dict(hidden_size=PICK.v_hidden, num_hidden_layers=PICK.v_layers, num_attention_heads=PICK.v_heads,
+                            intermediate_size=PICK.v_mlp, image_size=PICK.image_size, patch_size=14, hidden_act="gelu"),
+         text_config=dict(hidden_size=PICK.t_hidden, num_hidden_layers=PICK.t_layers, num_attention_heads=PICK.t_heads,
+                          intermediate_size=PICK.t_mlp, vocab_size=PICK.vocab, max_position_embeddings=77, eos_token_id=2, hidden_act="gelu"))
+    torch.save(Wp, os.path.join(p, "pytorch_model.bin"))
+    sd, cfg = hub.load_pickscore(p)
+    assert cfg == dataclasses.replace(PICK, eos_token_id=2)
+    from oracle import vit as o
+    ids = torch.randint(3, PICK.vocab - 1, (3, 77)); ids[0, 9] = PICK.vocab - 1; ids[1, 30] = PICK.vocab - 1; ids[2, 76] = PICK.vocab - 1
+    ids[:, 4] = 2                                                                 # an id-2 token before the end is not the pooled position
+    W32 = {k: v.float() for k, v in sd.items()}
+    a = o.clip_text_features(W32, cfg, ids)
+    b = o.clip_text_features(W32, dataclasses.replace(cfg, eos_token_id=PICK.vocab - 1), ids)
+    assert torch.allclose(a, b) and (a[0] - a[1]).abs().max() > 1e-4
+
+
 @pytest.mark.parametrize("over, match", [
     (dict(num_layers=4), "missing"),                                   # config says 4 blocks, the weights hold 3
     (dict(num_layers=2), "unexpected"),
