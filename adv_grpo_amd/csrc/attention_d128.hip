@@ -16,7 +16,7 @@
 //     measured as well, D128_VAR bit 1: the two wave groups -- waves w and w + 4 share a SIMD -- ONE HALF APART, a barrier per
 //     half, so that a wave in its VALU-heavy half sits beside a partner in the MFMA-only one: 2 % slower than lock-step,
 //     3.31 vs 3.25 ms at B = 16, 24 heads, S = 4224; as were s_setprio around the MFMA-only half, static priority for the second
-//     group, operand reads 3 or 4 slots ahead and an unpinned first half: all within 1 % -- DESIGN.md section 6, round 4.)
+//     group, operand reads 3 or 4 slots ahead and an unpinned first half: all within 1 % -- LABNOTES.md section 6, round 4.)
 //   * everything that addresses LDS is a compile-time constant: the tile loop is unrolled over the ring period (4), so a
 //     fragment read is "per-lane base + immediate" and the DMA destinations are literals (the first version computed the
 //     ring slot at run time: 150 VALU + 61 SALU instructions per 32 MFMAs, 47 spilled SGPRs; the instruction stream of the

@@ -92,7 +92,7 @@ def pipeline_with_logprob_random(self, prompt=None, prompt_2=None, prompt_3=None
         else:
             cur = 0
         if do_cfg and getattr(self, "cfg_two_streams", False) and mods_all is not None and ctx_rows is not None:
-            # optional schedule (config `sample.cfg_two_streams`, bench.py's `cfg_two_streams` leg): the unconditional and the conditional half of the CFG batch are
+            # optional schedule (config `sample.cfg_two_streams`, bench.py's `cfg_two_streams` leg; LABNOTES.md 6 round 5): the unconditional and the conditional half of the CFG batch are
             # independent until the combine -- two forwards of batch B on two HIP streams instead of one of batch 2 B (every row of
             # every kernel is independent of the others: the same bits)
             main = torch.cuda.current_stream(device)

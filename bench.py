@@ -45,12 +45,12 @@ def parse():
     ap.add_argument("--event-stride", type=int, default=13,
                     help="HIP events around every Nth launch of each GEMM kernel in the timed steps (1 = every launch).  The roofline's "
                          "per-launch average is then a 1-in-N sample; a prime N walks through the 4 / 6 launches of a block.  Events "
-                         "around all ~1220 GEMM launches of a step cost 1.7 %% of the step (measured, DESIGN.md 6)")
+                         "around all ~1220 GEMM launches of a step cost 1.7 %% of the step (measured, LABNOTES.md 6)")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 = the headline (BASELINE config 2); c3 = BASELINE config 3's rank-local work (config 2's rollout with the co-trained "
                          "DINOv2-patch discriminator as reward; its epoch leg runs one D epoch and one G epoch); c4 = secondary line, SD3.5-large 1024^2 G=4 (BASELINE config 4 shapes); "
                          "c5 = secondary line, Qwen-Image MMDiT 1024^2 G=8, DINO reward, fp8 Linears (BASELINE config 5 shapes)")
-    ap.add_argument("--decode-in-future", type=int, default=0, help="experiment (measured, no gain: DESIGN 6 round 5): 1 = the VAE decode runs inside "
+    ap.add_argument("--decode-in-future", type=int, default=0, help="experiment (measured, no gain: LABNOTES 6 round 5): 1 = the VAE decode runs inside "
                     "the reward future as well (the rollout returns latents, output_type='latent')")
     ap.add_argument("--rollout-priority", type=int, default=0, help="experiment (measured, no gain): -1 = the timed rollouts on a high-priority HIP stream")
     ap.add_argument("--dry-run", action="store_true",
@@ -991,7 +991,7 @@ def main():
                        "effective_tflops_per_gpu": round(per_image_tflop * G / (ov_ms * 1e-3), 1),
                        "frac_of_bf16_mfma_peak": round(per_image_tflop * G / (ov_ms * 1e-3) / BF16_DENSE_PEAK_TFLOPS, 4),
                        "gemm8p_by_events_when_overlapped": "not meaningful: 0.28 of peak by per-launch HIP events, because a launch's "
-                                                           "event interval then includes the other stream's kernels (DESIGN.md 6)",
+                                                           "event interval then includes the other stream's kernels (LABNOTES.md 6)",
                        "note": "two independent prompt groups on two HIP streams, one host thread each; same kernels, same results"}
         res = {
             "metric": "sampled+scored images/sec (whole node), SD3.5-large 1024^2 10-step G=4 (secondary line, BASELINE config 4 shapes)"

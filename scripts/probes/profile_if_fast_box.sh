@@ -1,5 +1,5 @@
 #!/bin/bash
-# Boxes of the pool differ by up to 8 % (377 - 408 ms per serial config-2 step in round 5): gauge the lease with the 20-second attention
+# Boxes of the pool differ by up to 8 % (377 - 408 ms per serial config-2 step in round 5, LABNOTES.md 6): gauge the lease with the 20-second attention
 # benchmark first and take the profile set only on a box at or above the round's median (S = 1229 attention forward <= LIMIT us).
 LIMIT=${1:-169}
 us=$(python scripts/bench_attention.py 2>/dev/null | grep "S=1229" | sed 's/.*min \([0-9.]*\) us.*/\1/')

@@ -1,6 +1,6 @@
 """Same-process A/B of two builds of the library on the config-2 rollout (10 denoise steps of the CFG batch 16 + the VAE decode of 8 images; no
 scorer): the pipeline is built once, `_lib._lib` is swapped between the builds, R rounds of N rollouts each, alternating order.  Repeats to ~0.1 %
-(alternating PROCESSES carries a position effect of 1 - 3 %).   Usage: rollout_ab_inprocess.py [base.so [new.so [N [R]]]]"""
+(alternating PROCESSES carries a position effect of 1 - 3 %, LABNOTES.md 7).   Usage: rollout_ab_inprocess.py [base.so [new.so [N [R]]]]"""
 import ctypes, os, sys, time, torch
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
