@@ -49,6 +49,17 @@ class MMDiTBlockDesc(ctypes.Structure):
                                    "ff1_w", "ff1_b", "ff2_w", "ff2_b", "cff1_w", "cff1_b", "cff2_w", "cff2_b", "rms_x", "rms_c", "rms_2")])
 
 
+class VitLayer(ctypes.Structure):
+    """advgrpo_vit_layer (include/advgrpo.h), field for field."""
+    _fields_ = [(n, _P) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ls1", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+
+
+class VitDesc(ctypes.Structure):
+    """advgrpo_vit_desc (include/advgrpo.h), field for field."""
+    _fields_ = ([(n, c_int32) for n in ("B", "S", "D", "H", "mlp", "n_layers", "act", "causal")] + [("eps", c_float), ("x", _P),
+                ("layers", POINTER(VitLayer))])
+
+
 class LoraMergeItem(ctypes.Structure):
     """advgrpo_lora_merge_item (include/advgrpo.h), field for field."""
     _fields_ = ([(n, _P) for n in ("A", "B", "base", "w", "wT", "a_cat", "b_bd")] + [(n, c_int64) for n in ("ld_base", "ld_w", "ld_wT", "ld_bd")] +
@@ -109,6 +120,8 @@ SIGNATURES = {
     "advgrpo_gemm_tn_workspace_bytes": (c_int64, [c_int, c_int]),
     "advgrpo_mmdit_block_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "advgrpo_mmdit_block_forward": (c_int, [POINTER(MMDiTBlockDesc), _P, c_int64, _P]),
+    "advgrpo_vit_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "advgrpo_vit_forward": (c_int, [POINTER(VitDesc), _P, c_int64, _P]),
     "advgrpo_gemm_tn_grouped_workspace_bytes": (c_int64, [POINTER(TnDesc), c_int]),
     "advgrpo_gemm_tn_grouped": (c_int, [POINTER(TnDesc), c_int, _P, c_int64, c_int, _P]),
     "advgrpo_lora_merge": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P]),

@@ -9,7 +9,7 @@ GELU / residual epilogues.
 """
 import torch
 
-from . import ops, preprocess
+from . import _lib, ops, preprocess
 
 
 def _bf(t, dev):
@@ -22,7 +22,43 @@ class _Encoder:
     def __init__(self, layers, heads, eps, act, causal=False):
         self.layers, self.heads, self.eps, self.act, self.causal = layers, heads, eps, act, causal
 
+    c_stack = True             # forward through advgrpo_vit_forward (one C-ABI call for the whole stack); False: the launches one by one
+
+    _FIELDS = ("ln1.w", "ln1.b", "qkv.w", "qkv.b", "out.w", "out.b", "ls1", "ln2.w", "ln2.b", "fc1.w", "fc1.b", "fc2.w", "fc2.b", "ls2")
+
+    def _table(self):
+        """The stack's weights as the C entry's host array of advgrpo_vit_layer, cached on the data pointers of every tensor it names (the
+        D-steps swap `layers` lists and re-merge weights: any change rebuilds it; the tensors themselves are held by `layers`)."""
+        p = lambda t: t.data_ptr() if t is not None else None
+        key = tuple(p(L.get(n)) for L in self.layers for n in self._FIELDS)
+        cache = self.__dict__.setdefault("_tables", {})
+        tab = cache.get(key)
+        if tab is None:
+            if len(cache) > 8:
+                cache.clear()
+            tab = (_lib.VitLayer * len(self.layers))()
+            for t, L in zip(tab, self.layers):
+                for n in self._FIELDS:
+                    setattr(t, n.replace(".", "_"), p(L.get(n)))
+            cache[key] = tab
+        return tab
+
+    def _forward_c(self, x, B, S):
+        import ctypes
+        lib = _lib.load()
+        D, F = x.shape[1], self.layers[0]["fc1.w"].shape[0]
+        assert x.is_contiguous() and x.dtype == torch.bfloat16
+        d = _lib.VitDesc()
+        d.B, d.S, d.D, d.H, d.mlp, d.n_layers, d.act, d.causal, d.eps = B, S, D, self.heads, F, len(self.layers), ops.ACT[self.act], int(self.causal), self.eps
+        tab = self._table()
+        d.x, d.layers = x.data_ptr(), ctypes.cast(tab, ctypes.POINTER(_lib.VitLayer))
+        ws = torch.empty(int(lib.advgrpo_vit_workspace_bytes(B, S, D, F)), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.advgrpo_vit_forward(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        return x
+
     def __call__(self, x, B, S):
+        if self.c_stack and self.layers:
+            return self._forward_c(x, B, S)
         D = x.shape[1]
         H = self.heads
         for L in self.layers:

@@ -440,6 +440,28 @@ int64_t advgrpo_mmdit_block_workspace_bytes(int B, int Ni, int Nt, int D, int du
 int advgrpo_mmdit_block_forward(const advgrpo_mmdit_block_desc* block, void* workspace /* 256-byte aligned */, int64_t workspace_bytes,
                                 void* stream);
 
+/* ------------------------------------------------------------------ a ViT encoder stack behind one entry (csrc/vit_encoder.cpp)
+ * The pre-LN transformer encoder of the reward towers: transformers' CLIPEncoderLayer x n behind CLIPModel.get_image_features /
+ * get_text_features (adv_grpo/pickscore_scorer.py:40-44, adv_grpo/pick_score_training.py:95-106; ViT-H/14: 32 layers, 16 heads x 80; text:
+ * 24 causal layers, 16 x 64) and timm's vit_base_patch14_dinov2 blocks with LayerScale behind forward_features (adv_grpo/rewards.py:397,
+ * scripts/train_sd3_fast_dino_patch.py:183-184; 12 layers, 12 x 64).  Per layer: x += [ls1 *] attn(LN(x)); x += [ls2 *] fc2(act(fc1(LN(x)))),
+ * q | k | v stacked along N in qkv_w / qkv_b, weights in nn.Linear layout [N, K], all bf16; x [B S, D] token rows, updated in place;
+ * `layers` is a HOST array (device pointers inside).  act: the GEMM activation codes (2 GELU-erf, 4 quick-GELU); head dim D / H must be 64
+ * or 80.  The embedding in front and the final norm / projection behind stay with the caller.  Bit-identical to the same launches issued one
+ * by one (adv_grpo_amd/vit.py keeps that sequencing as the check). */
+typedef struct advgrpo_vit_layer {
+    const void *ln1_w, *ln1_b, *qkv_w, *qkv_b, *out_w, *out_b, *ls1;      /* ls1 / ls2: LayerScale gamma [D] or NULL */
+    const void *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ls2;
+} advgrpo_vit_layer;
+typedef struct advgrpo_vit_desc {
+    int32_t B, S, D, H, mlp, n_layers, act, causal;
+    float eps;
+    void* x;
+    const advgrpo_vit_layer* layers;
+} advgrpo_vit_desc;
+int64_t advgrpo_vit_workspace_bytes(int B, int S, int D, int mlp);
+int advgrpo_vit_forward(const advgrpo_vit_desc* tower, void* workspace /* 256-byte aligned */, int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ fp8 Linears (BASELINE config 5: "fp8 MFMA path")
  * The reference has no fp8 code (config 5 changes pretrained.model / resolution only); the scheme is this
  * library's: OCP e4m3 codes, one f32 scale per token row of the activation and per output channel of the weight,

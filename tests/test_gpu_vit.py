@@ -260,3 +260,41 @@ def test_pickscore_text_tower_runs_once_per_distinct_prompt(dtype):
         calls.clear()
         s_full = scorer(ids, imgs)                       # bare ids: nothing to compare on the host, the whole batch runs
         assert calls == [6] and torch.equal(s_dedup, s_full)
+
+
+def test_vit_stack_through_the_c_entry_is_bit_identical_to_the_python_sequencing():
+    """advgrpo_vit_forward (csrc/vit_encoder.cpp) runs the same launches in the same order as vit._Encoder's Python loop: CLIP ViT-H
+    width (head dim 80), the causal CLIP text tower (head dim 64) and DINOv2 (LayerScale as the gate operand), bit for bit."""
+    from adv_grpo_amd import synthetic, vit
+    from adv_grpo_amd.model_configs import DinoConfig
+    from oracle import vit as o
+    cfg = o.ClipConfig(v_layers=3, t_layers=2)
+    clip = vit.CLIPModel({k: v.to(torch.bfloat16) for k, v in synthetic.clip_weights(cfg, 5).items()}, cfg, "cuda")
+    g = torch.Generator().manual_seed(4)
+    img = torch.rand(3, 3, 512, 512, generator=g).to(torch.bfloat16).cuda()
+    ids = synthetic.clip_input_ids(3, 7)
+    dcfg = DinoConfig(layers=2)
+    dino = vit.DinoV2(synthetic.dino_weights(dcfg, 8), dcfg, "cuda")
+    outs = {}
+    for c_stack in (True, False):
+        vit._Encoder.c_stack = c_stack
+        try:
+            outs[c_stack] = (clip.get_image_features(images=img), clip.get_text_features(ids), dino.forward_features(images=img[:2]))
+        finally:
+            vit._Encoder.c_stack = True
+    for a, b in zip(outs[True], outs[False]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert torch.isfinite(outs[True][2].float()).all()
+
+
+def test_vit_c_entry_refuses_what_it_does_not_implement():
+    import ctypes
+    from adv_grpo_amd import _lib
+    lib = _lib.load()
+    d = _lib.VitDesc()
+    d.B, d.S, d.D, d.H, d.mlp, d.n_layers, d.act, d.causal, d.eps = 1, 16, 96, 1, 128, 0, 2, 0, 1e-5      # head dim 96
+    x = torch.zeros(16, 96, dtype=torch.bfloat16, device="cuda")
+    ws = torch.empty(int(lib.advgrpo_vit_workspace_bytes(1, 16, 96, 128)), dtype=torch.uint8, device="cuda")
+    d.x = x.data_ptr()
+    assert lib.advgrpo_vit_forward(ctypes.byref(d), ws.data_ptr(), ws.numel(), None) != 0
+    assert b"head dim" in lib.advgrpo_last_error()
