@@ -49,6 +49,16 @@ class MMDiTBlockDesc(ctypes.Structure):
                                    "ff1_w", "ff1_b", "ff2_w", "ff2_b", "cff1_w", "cff1_b", "cff2_w", "cff2_b", "rms_x", "rms_c", "rms_2")])
 
 
+class MMDiTBlockBwdDesc(ctypes.Structure):
+    """advgrpo_mmdit_block_bwd_desc (include/advgrpo.h), field for field."""
+    _fields_ = ([(n, c_int32) for n in ("B", "Ni", "Nt", "D", "H", "dual", "last", "first")] + [("mods", _P)] +
+                [(n, c_int64) for n in ("mod_stride", "mod_x", "mod_c", "mod_x_prev", "mod_c_prev", "ld_att")] +
+                [(n, _P) for n in ("ff2_wT", "ff1_wT", "cff2_wT", "cff1_wT", "out_wT", "cout_wT", "qkv_wT", "cqkv_wT", "out2_wT", "qkv2_wT",
+                                   "rms_x", "rms_c", "rms_2",
+                                   "x_in", "c_in", "x_mid", "c_mid", "pre", "cpre", "qkv", "rs", "att", "lse", "qkv2", "rs2", "att2", "lse2",
+                                   "dx", "dc", "dyg", "dcyg", "dx_out", "dc_out", "dyg_prev", "dcyg_prev", "dyo", "dyc", "dqkv")])
+
+
 class VitLayer(ctypes.Structure):
     """advgrpo_vit_layer (include/advgrpo.h), field for field."""
     _fields_ = [(n, _P) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ls1", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
@@ -120,6 +130,8 @@ SIGNATURES = {
     "advgrpo_gemm_tn_workspace_bytes": (c_int64, [c_int, c_int]),
     "advgrpo_mmdit_block_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "advgrpo_mmdit_block_forward": (c_int, [POINTER(MMDiTBlockDesc), _P, c_int64, _P]),
+    "advgrpo_mmdit_block_backward_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "advgrpo_mmdit_block_backward": (c_int, [POINTER(MMDiTBlockBwdDesc), _P, c_int64, _P]),
     "advgrpo_vit_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "advgrpo_vit_forward": (c_int, [POINTER(VitDesc), _P, c_int64, _P]),
     "advgrpo_gemm_tn_grouped_workspace_bytes": (c_int64, [POINTER(TnDesc), c_int]),
@@ -167,6 +179,8 @@ SIGNATURES = {
     "advgrpo_split_f16x2": (c_int, [_P, _P, _P, c_int64, c_int, c_float, _P]),
     "advgrpo_conv3x3_nhwc_f16x2": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_float, _P, _P]),
     "advgrpo_conv3x3_nhwc_f16x2_pair": (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_float, _P]),
+    "advgrpo_conv3x3_nhwc_f16x1": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_float, _P, _P]),
+    "advgrpo_conv3x3_nhwc_f16x1_pair": (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_float, _P]),
     "advgrpo_conv3x3_nhwc_bf16x2": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_float, _P, _P]),
     "advgrpo_softmax_rows_x3": (c_int, [_P, _P, c_int64, c_int, _P]),
     "advgrpo_layernorm_x3": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P]),

@@ -82,11 +82,17 @@ __device__ __forceinline__ void x3_tie(bf16x8_t (&a)[N]) {
 // checkpoint): activations as the bf16 pair of the three-product path in the same [hi | unwritten | lo] rows (16 significant bits),
 // weights as ONE bf16 piece per tap, x_hi w + x_lo w on v_mfma_f32_16x16x32_bf16 -- the three-product form would multiply by a
 // weight "lo" that is identically zero.
+// PIECE = 3 ("f16x1", round 6): the TF32-CLASS form of f16x2 -- ONE fp16 product per f32 product: the activation's hi half only (11 significant
+// bits, what a TF32 operand keeps; the weights are exact), f32 accumulation, f32 between kernels.  The reference runs with allow_tf32 = True
+// (config/base.py:22-23, TP:537-538), i.e. its fp32 convolutions round both operands to 10 explicit mantissa bits on Ampere+; this is that
+// arithmetic class on the fp16 MFMA.  Same pipeline and the same DMA (the lo pieces still travel: the hand-counted waits stay valid), the lo
+// fragment reads and products are left out.  Priced as a leg of the bench line, never the default.
 // DBG (experiments build only, scripts/probes/x3_decompose.sh): 1 = no DMA after the prologue, 2 = no MFMAs, 3 = fragments read
 // once -- WRONG results, used to price the three activities of the k loop against each other
 template <int X3_WM, int X3_WN, int DBG = 0, int PIECE = 0>
 __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const GemmParams p) {
-    constexpr bool F16 = PIECE != 0;                  // one-piece weights, two products (1: fp16 pieces; 2: bf16 pieces)
+    constexpr bool F16 = PIECE != 0;                  // one-piece weights, two products (1: fp16 pieces; 2: bf16 pieces; 3: fp16 pieces, hi product only)
+    constexpr bool X1 = PIECE == 3;
     constexpr int WPI = F16 ? 1 : 2;                  // weight pieces per tap (DMA instructions per 8 output channels)
     constexpr int NW = X3_WM * X3_WN, TM = X3_BM / X3_WM, TN = X3_BN / X3_WN, FM = TM / 16, FN = TN / 16;
     constexpr int XI = (X3_XINST + NW - 1) / NW;     // pixel-piece DMA instructions per wave (the last one on some waves only)
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-                    if constexpr (PIECE == 1) {
+                    if constexpr (PIECE == 1 || PIECE == 3) {
                         typedef _Float16 x3_f16x8 __attribute__((ext_vector_type(8)));
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(x3_f16x8, b[j]), __builtin_bit_cast(x3_f16x8, a[i]),
                                                                            acc[i][j], 0, 0, 0);
@@ -249,7 +255,38 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
             bf16x8_t ah0[FM], al0[FM], bh0[FN], bl0[FN], ah1[FM], al1[FM], bh1[FN], bl1[FN];
             const bool more = kt + 2 < nk;                   // (then group g + 1 exists as well when dxi == 2)
             const bool rd = DBG != 3 || kt == 0;
-            if constexpr (F16 && dxi < 2) {
+            if constexpr (X1 && dxi < 2) {
+                // hi product only: both 32-deep steps' x_hi and w fragments requested up front
+                if (rd) { read_x(xa[dxi][0], ah0, al0, true, false); read_wh(wb0, bh0); read_x(xa[dxi][1], ah1, al1, true, false); read_wh(wb1, bh1); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && DBG != 1) stage_w((dxi + 2) % 3, dxi == 0 ? g : g + 1, (dxi + 2) % 3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) { x3_wait_reads<FM + FN>(); x3_tie(ah0); x3_tie(bh0); }
+                mask(ah0);
+                product(ah0, bh0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) { x3_wait_reads<0>(); x3_tie(ah1); x3_tie(bh1); }
+                mask(ah1);
+                product(ah1, bh1);
+            } else if constexpr (X1) {
+                if (rd) { read_x(xa[dxi][0], ah0, al0, true, false); read_x(xa[dxi][1], ah1, al1, true, false); }
+                if (rd) { x3_wait_reads<0>(); x3_tie(ah0); x3_tie(ah1); }
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < ngroups && DBG != 1) {
+                    stage_x(g + 1);
+                    stage_w(1, g + 1, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) { read_wh(wb0, bh0); read_wh(wb1, bh1); }
+                if (rd) { x3_wait_reads<FN>(); x3_tie(bh0); }
+                mask(ah0);
+                product(ah0, bh0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rd) { x3_wait_reads<0>(); x3_tie(bh1); }
+                mask(ah1);
+                product(ah1, bh1);
+            } else if constexpr (F16 && dxi < 2) {
                 // one weight piece: per 32-deep step x_hi (FM reads), w (FN), x_lo (FM); products x_hi w, x_lo w
                 if (rd) { read_x(xa[dxi][0], ah0, al0, true, false); read_wh(wb0, bh0); read_x(xa[dxi][0], ah0, al0, false, true); }
                 __builtin_amdgcn_sched_barrier(0);
@@ -393,7 +430,7 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
 }  // namespace
 
 // fp16 pair activations x one-piece fp16 weights: p as filled by advgrpo_conv3x3_nhwc_f16x2 (Cin = 3C, lda = 3C, ldw = 9C, f32_io)
-int conv3x3_f16x2_launch(const GemmParams& p, hipStream_t s, bool bf16_pieces) {
+int conv3x3_f16x2_launch(const GemmParams& p, hipStream_t s, int form /* 0: f16x2, 1: bf16x2, 2: f16x1 */) {
     ADVGRPO_CHECK(p.conv && p.f32_io && p.Cin % 192 == 0 && p.zero_page && p.batch == 1 && p.splitk == 1, "conv3x3_f16x2: bad parameter block");
     constexpr int WM = X3_GRID_M, WN = X3_GRID_N;
     static bool attr_set = false;
@@ -401,12 +438,15 @@ int conv3x3_f16x2_launch(const GemmParams& p, hipStream_t s, bool bf16_pieces) {
         ADVGRPO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<WM, WN, 0, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) == hipSuccess &&
                       hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<WM, WN, 0, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) == hipSuccess &&
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<WM, WN, 0, 3>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) == hipSuccess,
                       "conv3x3_f16x2: %d bytes of LDS refused", X3_LDS);
         attr_set = true;
     }
     const int tiles = ((p.M + X3_BM - 1) / X3_BM) * ((p.N + X3_BN - 1) / X3_BN);
-    if (bf16_pieces) hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, 2>), dim3(tiles), dim3(64 * WM * WN), X3_LDS, s, p);
+    if (form == 1) hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, 2>), dim3(tiles), dim3(64 * WM * WN), X3_LDS, s, p);
+    else if (form == 2) hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, 3>), dim3(tiles), dim3(64 * WM * WN), X3_LDS, s, p);
     else hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, 1>), dim3(tiles), dim3(64 * WM * WN), X3_LDS, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;

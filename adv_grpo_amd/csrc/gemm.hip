@@ -469,7 +469,7 @@ extern "C" int advgrpo_conv3x3_nhwc(const void* x, const void* w, void* y, int o
  * [hi | hi | lo], w3 [Cout, 9*Cin3] with each tap's channels [hi | lo | hi]; bias / residual / y are f32 */
 static int conv3x3_two_products(const void* x2, const void* w16, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
                                 int upsample, const float* bias, int act, const float* residual, const void* zero_page,
-                                float alpha, float* gn_partial, void* stream, bool bf16_pieces, void* pair_out = nullptr,
+                                float alpha, float* gn_partial, void* stream, int form, void* pair_out = nullptr,
                                 float pair_prescale = 1.0f) {
     GemmParams p{};
     p.A = (const bf16_t*)x2; p.W = (const bf16_t*)w16; p.C = y;
@@ -489,13 +489,27 @@ static int conv3x3_two_products(const void* x2, const void* w16, float* y, int B
     ADVGRPO_CHECK(x2 && w16 && y && zero_page, "conv3x3_f16x2: null pointer");
     ADVGRPO_CHECK(!gn_partial || ((Hout * Wout) % 16 == 0 && Cout % 4 == 0), "conv3x3_f16x2: block sums need 16 | Hout Wout");
     ADVGRPO_CHECK(Cin3 % 192 == 0 && Cout >= 128, "conv3x3_f16x2: Cin3 must be 3 x (a multiple of 64), Cout >= 128 (Cin3=%d Cout=%d)", Cin3, Cout);
-    return conv3x3_f16x2_launch(p, as_stream(stream), bf16_pieces);
+    return conv3x3_f16x2_launch(p, as_stream(stream), form);
 }
 
 extern "C" int advgrpo_conv3x3_nhwc_f16x2(const void* x2, const void* w16, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
                                           int upsample, const float* bias, int act, const float* residual, const void* zero_page,
                                           float alpha, float* gn_partial, void* stream) {
-    return conv3x3_two_products(x2, w16, y, B, Hout, Wout, Cin3, Cout, upsample, bias, act, residual, zero_page, alpha, gn_partial, stream, false);
+    return conv3x3_two_products(x2, w16, y, B, Hout, Wout, Cin3, Cout, upsample, bias, act, residual, zero_page, alpha, gn_partial, stream, 0);
+}
+
+extern "C" int advgrpo_conv3x3_nhwc_f16x1(const void* x2, const void* w16, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
+                                          int upsample, const float* bias, int act, const float* residual, const void* zero_page,
+                                          float alpha, float* gn_partial, void* stream) {
+    return conv3x3_two_products(x2, w16, y, B, Hout, Wout, Cin3, Cout, upsample, bias, act, residual, zero_page, alpha, gn_partial, stream, 2);
+}
+
+extern "C" int advgrpo_conv3x3_nhwc_f16x1_pair(const void* x2, const void* w16, void* pair_out, float pair_prescale, int B, int Hout, int Wout,
+                                               int Cin3, int Cout, int upsample, const float* bias, int act, const float* residual,
+                                               const void* zero_page, float alpha, void* stream) {
+    ADVGRPO_CHECK(pair_out, "conv3x3_f16x1_pair: null output");
+    return conv3x3_two_products(x2, w16, reinterpret_cast<float*>(pair_out), B, Hout, Wout, Cin3, Cout, upsample, bias, act, residual, zero_page,
+                                alpha, nullptr, stream, 2, pair_out, pair_prescale);
 }
 
 extern "C" int advgrpo_conv3x3_nhwc_f16x2_pair(const void* x2, const void* w16, void* pair_out, float pair_prescale, int B, int Hout, int Wout,
@@ -503,13 +517,13 @@ extern "C" int advgrpo_conv3x3_nhwc_f16x2_pair(const void* x2, const void* w16, 
                                                const void* zero_page, float alpha, void* stream) {
     ADVGRPO_CHECK(pair_out, "conv3x3_f16x2_pair: null output");
     return conv3x3_two_products(x2, w16, reinterpret_cast<float*>(pair_out), B, Hout, Wout, Cin3, Cout, upsample, bias, act, residual, zero_page,
-                                alpha, nullptr, stream, false, pair_out, pair_prescale);
+                                alpha, nullptr, stream, 0, pair_out, pair_prescale);
 }
 
 extern "C" int advgrpo_conv3x3_nhwc_bf16x2(const void* x2, const void* w16, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
                                            int upsample, const float* bias, int act, const float* residual, const void* zero_page,
                                            float alpha, float* gn_partial, void* stream) {
-    return conv3x3_two_products(x2, w16, y, B, Hout, Wout, Cin3, Cout, upsample, bias, act, residual, zero_page, alpha, gn_partial, stream, true);
+    return conv3x3_two_products(x2, w16, y, B, Hout, Wout, Cin3, Cout, upsample, bias, act, residual, zero_page, alpha, gn_partial, stream, 1);
 }
 
 extern "C" int advgrpo_conv3x3_nhwc_x3(const void* x3, const void* w3, float* y, int B, int Hout, int Wout, int Cin3,

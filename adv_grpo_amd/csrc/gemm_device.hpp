@@ -468,7 +468,7 @@ struct GemmPair { GemmParams a, b; int tiles_a; };
 
 // split-bf16 3x3 convolution of the fp32-equivalent VAE decode (conv_x3.hip); fp16-pair activations x fp16 weights
 int conv3x3_x3_launch(const GemmParams& p, hipStream_t s);
-int conv3x3_f16x2_launch(const GemmParams& p, hipStream_t s, bool bf16_pieces = false);
+int conv3x3_f16x2_launch(const GemmParams& p, hipStream_t s, int form = 0 /* 0: f16x2, 1: bf16x2, 2: f16x1 */);
 
 // 256x256 eight-phase kernel (gemm8p.hip)
 bool gemm8p_ok(const GemmParams& p);

@@ -523,6 +523,44 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
                 descs.append(ops.tn_desc(X, u[:, cols], self.A_view(ad, self.grads), alpha=self.scale, M=M, p_seg=x_seg, transpose_out=True))
         ops.gemm_tn_grouped(descs)                       # (2 problems per adapter: 12 for the q | k | v groups of both streams, 4 for the output projections)
 
+    c_block_bwd = True         # the data-gradient chain of a block through advgrpo_mmdit_block_backward (one C-ABI call); False: launch by launch
+
+    def _block_backward_c(self, i, b, s, dx, dc, dyg, dcyg, mods, B, Ni, Nt, ws):
+        """Block i's data-gradient chain through the C entry, then its adapter-gradient launches (side stream) -> (dx, dc, dyg, dcyg) for block i - 1."""
+        import ctypes
+        lib, D, H = _lib.load(), self.cfg.dim, self.cfg.num_heads
+        S, dev, bf16 = Ni + Nt, mods.device, torch.bfloat16
+        p = lambda t: t.data_ptr() if t is not None else None
+        new = lambda rows, cols: torch.empty(rows, cols, dtype=bf16, device=dev)
+        first, last = i == 0, bool(b["last"])
+        dx_out, dc_out = new(B * Ni, D), new(B * Nt, D)
+        dyg_prev, dcyg_prev = (None, None) if first else (new(B * Ni, D), new(B * Nt, D))
+        dyo, dyc, dqkv = new(B * Ni, D), (None if last else new(B * Nt, D)), new(B * S, 3 * D)
+        att = s["att"]
+        assert att.stride(2) == 1 and att.stride(0) == S * att.stride(1) and mods.stride(1) == 1
+        d = _lib.MMDiTBlockBwdDesc()
+        d.B, d.Ni, d.Nt, d.D, d.H, d.dual, d.last, d.first = B, Ni, Nt, D, H, int(b["dual"]), int(last), int(first)
+        d.mods, d.mod_stride, d.mod_x, d.mod_c = mods.data_ptr(), mods.stride(0), self.mod_off[("x", i)], self.mod_off[("c", i)]
+        if not first:
+            d.mod_x_prev, d.mod_c_prev = self.mod_off[("x", i - 1)], self.mod_off[("c", i - 1)]
+        d.ld_att = att.stride(1)
+        for k in ("ff2", "ff1", "cff2", "cff1", "out", "cout", "qkv", "cqkv", "out2", "qkv2"):
+            setattr(d, k + "_wT", p(b.get(k + ".wT")))
+        d.rms_x, d.rms_c, d.rms_2 = p(b.get("rms_x")), p(b.get("rms_c")), p(b.get("rms_2"))
+        for k in ("x_in", "c_in", "x_mid", "c_mid", "pre", "cpre", "qkv", "rs", "att", "lse", "qkv2", "rs2", "att2", "lse2"):
+            t = s.get(k)
+            assert t is None or t.is_contiguous() or k == "att"
+            setattr(d, k, p(t))
+        d.dx, d.dc, d.dyg, d.dcyg = p(dx), p(dc), p(dyg), p(dcyg)
+        d.dx_out, d.dc_out, d.dyg_prev, d.dcyg_prev, d.dyo, d.dyc, d.dqkv = p(dx_out), p(dc_out), p(dyg_prev), p(dcyg_prev), p(dyo), p(dyc), p(dqkv)
+        _lib.check(lib.advgrpo_mmdit_block_backward(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        att2d = att.reshape(B * S, D) if att.is_contiguous() else att.view(B * S, att.stride(1))[:, :D]
+        self._lora_wgrad_group([((i, "out"), att2d, B * Ni, (Ni, S, 0), dyo, None)] +
+                               ([] if last else [((i, "cout"), att2d, B * Nt, (Nt, S, Ni), dyc, None)]))
+        self._lora_wgrad_group([((i, "qkv"), s["nx"], B * Ni, None, dqkv, (Ni, S, 0)),
+                                ((i, "cqkv"), s["nc"], B * Nt, None, dqkv, (Nt, S, Ni))])
+        return dx_out, dc_out, dyg_prev, dcyg_prev
+
     fuse_gates = True          # the norms' backward writes the gated copies of its result as well (backward; False: ops.gate_mul, for A/Bs)
 
     # ------------------------------------------------------------------ explicit backward
@@ -560,9 +598,19 @@ class SD3TransformerLoRA(SD3Transformer2DModel):
             return dxx, [ops.gate_mul(dxx, g, rows) for g in gates]
         dx, (dyg,) = ln_bwd(ctx["x_final"], dnx, [mod(("x", L - 1), 5)], Ni, scale0=mod(("out",), 0))
         dc = dcyg = None
+        # one C-ABI call per block for the data-gradient chain (csrc/mmdit_block_bwd.cpp; the launches below, in the same order: bit-identical);
+        # the side-path LoRA mode keeps its K-extended buffers out of that entry's dense-row contract and stays on the Python sequencing
+        use_c = self.c_block_bwd and self.lora_mode == "merged" and fuse
+        if use_c:
+            lib = _lib.load()
+            need = max(int(lib.advgrpo_mmdit_block_backward_workspace_bytes(B, Ni, Nt, D, H, int(d))) for d in {bool(b["dual"]) for b in self.blocks})
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
         for i in reversed(range(L)):
             b, s = self.blocks[i], ctx["blocks"][i]
             kx, kc = ("x", i), ("c", i)
+            if use_c:
+                dx, dc, dyg, dcyg = self._block_backward_c(i, b, s, dx, dc, dyg, dcyg, mods, B, Ni, Nt, ws)
+                continue
             # ---- image MLP
             # (the text-stream data-gradient GEMMs ride in the launches of their image-stream twins, as in the forward)
             d2 = [ops.gemm_desc(dyg, b["ff2.wT"], act="dgelu_tanh", aux_in=s["pre"])]

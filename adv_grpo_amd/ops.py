@@ -652,7 +652,7 @@ def groupnorm_nhwc_f16x2(x, weight, bias, groups=32, eps=1e-6, silu=False, presc
     return y
 
 
-def conv3x3_f16x2_pair(x2, w16, prescale, bias=None, upsample=False, act=None, residual=None, alpha=1.0):
+def conv3x3_f16x2_pair(x2, w16, prescale, bias=None, upsample=False, act=None, residual=None, alpha=1.0, single=False):
     """conv3x3_f16x2 whose output leaves as the fp16-pair rows of prescale * y ([B,Hout,Wout,3 Cout], = split_f16x2(y, prescale) bit for
     bit) instead of f32 y: for an output that only the next f16x2 convolution reads."""
     lib = _lib.load()
@@ -664,13 +664,13 @@ def conv3x3_f16x2_pair(x2, w16, prescale, bias=None, upsample=False, act=None, r
     Hout, Wout = (Hin * 2, Win * 2) if upsample else (Hin, Win)
     out = torch.empty(B, Hout, Wout, 3 * Cout, dtype=torch.bfloat16, device=x2.device)      # (16-bit container; the values are fp16)
     with _Prof(B * Hout * Wout, Cout, 2 * 3 * Cin3, 1, 1):
-        _lib.check(lib.advgrpo_conv3x3_nhwc_f16x2_pair(_lib.ptr(x2), _lib.ptr(w16), out.data_ptr(), float(prescale), B, Hout, Wout, Cin3, Cout,
+        _lib.check((lib.advgrpo_conv3x3_nhwc_f16x1_pair if single else lib.advgrpo_conv3x3_nhwc_f16x2_pair)(_lib.ptr(x2), _lib.ptr(w16), out.data_ptr(), float(prescale), B, Hout, Wout, Cin3, Cout,
                                                        int(upsample), _lib.ptr(bias), ACT[act], _lib.ptr(residual),
                                                        zero_page(x2.device).data_ptr(), float(alpha), _lib.stream_ptr()))
     return out
 
 
-def conv3x3_f16x2(x2, w16, bias=None, upsample=False, act=None, residual=None, alpha=1.0, gn_stats=False, bf16_pieces=False):
+def conv3x3_f16x2(x2, w16, bias=None, upsample=False, act=None, residual=None, alpha=1.0, gn_stats=False, bf16_pieces=False, single=False):
     """x2 NHWC fp16-pair rows [B,Hin,Win,3C]; w16 [Cout, 9C] fp16 (k = (ky*3+kx)*C + c); bias / residual f32 -> f32 [B,Hout,Wout,Cout].
     bf16_pieces: the "bf16x2" form -- x2 = bf16 [hi | unwritten | lo] rows, w16 one bf16 piece (weights exact in bf16).
     gn_stats: the epilogue also leaves the 16-pixel x 4-channel block sums of the GroupNorm that reads the output, as `y.gn_tile_stats` (an attribute
@@ -679,7 +679,9 @@ def conv3x3_f16x2(x2, w16, bias=None, upsample=False, act=None, residual=None, a
     B, Hin, Win, Cin3 = x2.shape
     Cout = w16.shape[0]
     assert w16.dtype == (torch.bfloat16 if bf16_pieces else torch.float16) and w16.is_contiguous() and w16.shape[1] == 3 * Cin3
-    fn = lib.advgrpo_conv3x3_nhwc_bf16x2 if bf16_pieces else lib.advgrpo_conv3x3_nhwc_f16x2
+    assert not (single and bf16_pieces)
+    # single: the TF32-class "f16x1" form (the hi product only; include/advgrpo.h)
+    fn = lib.advgrpo_conv3x3_nhwc_bf16x2 if bf16_pieces else (lib.advgrpo_conv3x3_nhwc_f16x1 if single else lib.advgrpo_conv3x3_nhwc_f16x2)
     Hout, Wout = (Hin * 2, Win * 2) if upsample else (Hin, Win)
     assert bias is None or bias.dtype == torch.float32
     assert residual is None or (residual.dtype == torch.float32 and residual.is_contiguous())

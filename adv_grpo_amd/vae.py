@@ -35,13 +35,17 @@ class _PairRows:
 
 
 class AutoencoderKLDecoder:
-    def __init__(self, state_dict, cfg, device="cuda", mode="bf16x3", f16_weights=True):
+    def __init__(self, state_dict, cfg, device="cuda", mode="bf16x3", f16_weights=True, f16_single=False):
         """f16_weights (bf16x3 mode): run a 3x3 convolution whose weight tensor is EXACT in fp16 on the two-product f16x2 kernel
-        (decided per tensor at load time; False: always the three split-bf16 products)."""
+        (decided per tensor at load time; False: always the three split-bf16 products).
+        f16_single (opt-in, round 6): those convolutions on ONE fp16 product per f32 product instead of two ("f16x1": the activation's fp16 hi
+        half only = a TF32-class operand; the reference runs with allow_tf32 = True, config/base.py:22-23 / TP:537-538).  Not the default:
+        bench.py prices it as `vae.value_if_tf32_class`; tests/test_gpu_vae.py holds it to the error of a simulated-TF32 decode."""
         if mode not in ("bf16", "bf16x3"):
             raise ValueError(f"AutoencoderKLDecoder: mode must be 'bf16' or 'bf16x3', got {mode!r}")
         self.mode = mode
         self.f16_weights = bool(f16_weights)
+        self.f16_single = bool(f16_single)
         self.cfg = cfg
         self.config = type("Cfg", (), {"scaling_factor": cfg.scaling_factor, "shift_factor": cfg.shift_factor})()
         self.dtype = torch.float32          # what the reference's vae.dtype says (PF:668 casts latents to it)
@@ -138,13 +142,14 @@ class AutoencoderKLDecoder:
         if self.mode == "bf16":
             n = sum(1 for k, v in self.w.items() if k.endswith(".weight") and ".conv" in k and "shortcut" not in k and v.dim() == 2 and
                     v.shape[1] % 9 == 0 and "to_" not in k)
-            return {"f16x2": 0, "bf16x3": 0, "bf16": n, "total": n, "text": f"bf16 ({n}/{n} convs)"}
+            return {"f16x2": 0, "f16x1": 0, "bf16x3": 0, "bf16": n, "total": n, "text": f"bf16 ({n}/{n} convs)"}
         f16 = sum(1 for k in self.w if k.endswith(".weight@f16"))
         x3 = sum(1 for k, v in self.w.items() if k.endswith(".weight") and v.dim() == 2 and ("conv_in" in k or "conv_out" in k or ".conv1." in k or
                                                                                             ".conv2." in k or ".upsamplers." in k))
         tot = f16 + x3
-        parts = [f"{name} ({n}/{tot}{' convs' if i == 0 else ''})" for i, (name, n) in enumerate(p for p in (("f16x2", f16), ("bf16x3", x3)) if p[1])]
-        return {"f16x2": f16, "bf16x3": x3, "bf16": 0, "total": tot, "text": ", ".join(parts)}
+        fname = "f16x1" if self.f16_single else "f16x2"
+        parts = [f"{name} ({n}/{tot}{' convs' if i == 0 else ''})" for i, (name, n) in enumerate(p for p in ((fname, f16), ("bf16x3", x3)) if p[1])]
+        return {"f16x2": 0 if self.f16_single else f16, "f16x1": f16 if self.f16_single else 0, "bf16x3": x3, "bf16": 0, "total": tot, "text": ", ".join(parts)}
 
     def _conv3(self, name, x3, **kw):
         return ops.conv3x3_x3(x3, self.w[name + ".weight"], bias=self.w[name + ".bias"], **kw)
@@ -163,11 +168,11 @@ class AutoencoderKLDecoder:
         if isinstance(x, _PairRows):                     # operand rows made by the producing convolution's epilogue
             assert gn is None and name + ".weight@f16" in w
             return ops.conv3x3_f16x2(x.rows, w[name + ".weight@f16"], bias=w[name + ".bias"], alpha=1.0 / self.RAW_PRESCALE,
-                                     gn_stats=self.fused_gn_stats, **kw)
+                                     gn_stats=self.fused_gn_stats, single=self.f16_single, **kw)
         if pair_for is not None and self.fused_pair_out and name + ".weight@f16" in w and pair_for + ".weight@f16" in w and gn is not None:
             a = ops.groupnorm_nhwc_f16x2(x, w[gn + ".weight"], w[gn + ".bias"], self.G, 1e-6, True,
                                          tile_stats=getattr(x, "gn_tile_stats", None) if self.fused_gn_stats else None)
-            return _PairRows(ops.conv3x3_f16x2_pair(a, w[name + ".weight@f16"], self.RAW_PRESCALE, bias=w[name + ".bias"], **kw))
+            return _PairRows(ops.conv3x3_f16x2_pair(a, w[name + ".weight@f16"], self.RAW_PRESCALE, bias=w[name + ".bias"], single=self.f16_single, **kw))
         if name + ".weight@f16" in w:
             # (every f16x2 convolution's output is read by a GroupNorm -- the next resnet's norm1 or this resnet's norm2 -- so its
             #  epilogue leaves that norm's per-tile sums (`gn_tile_stats`) and the norm skips its statistics pass over the activations)
@@ -175,9 +180,10 @@ class AutoencoderKLDecoder:
             if gn is not None:
                 a = ops.groupnorm_nhwc_f16x2(x, w[gn + ".weight"], w[gn + ".bias"], self.G, 1e-6, True,
                                              tile_stats=getattr(x, "gn_tile_stats", None) if st else None)
-                return ops.conv3x3_f16x2(a, w[name + ".weight@f16"], bias=w[name + ".bias"], gn_stats=st, **kw)
+                return ops.conv3x3_f16x2(a, w[name + ".weight@f16"], bias=w[name + ".bias"], gn_stats=st, single=self.f16_single, **kw)
             a = ops.split_f16x2(x, prescale=self.RAW_PRESCALE)
-            return ops.conv3x3_f16x2(a, w[name + ".weight@f16"], bias=w[name + ".bias"], alpha=1.0 / self.RAW_PRESCALE, gn_stats=st, **kw)
+            return ops.conv3x3_f16x2(a, w[name + ".weight@f16"], bias=w[name + ".bias"], alpha=1.0 / self.RAW_PRESCALE, gn_stats=st,
+                                     single=self.f16_single, **kw)
         wide = w[name + ".weight"].shape[0] >= 128      # >= 128 output channels: the kernel that reads the hi and lo thirds only
         a = self._gn3(gn, x, True, pair_only=wide) if gn is not None else ops.split_x3(x, order=2 if wide else 0)
         return self._conv3(name, a, **kw)

@@ -326,6 +326,17 @@ int advgrpo_rmsnorm_nhwc(const void* x, int x_dtype, void* y, const float* gamma
 int advgrpo_conv3x3_nhwc_f16x2_pair(const void* x2, const void* w16, void* pair_out, float pair_prescale, int B, int Hout, int Wout,
                                     int Cin3, int Cout, int upsample, const float* bias, int act, const float* residual,
                                     const void* zero_page, float alpha, void* stream);
+/* "f16x1" (round 6): the TF32-CLASS form of the two entries above -- same operands, same arguments, ONE fp16 product per f32 product (the
+ * activation's hi half only: 11 significant bits, what a TF32 operand keeps; weights exact; f32 accumulation, f32 between kernels).  The
+ * reference sets allow_tf32 = True (config/base.py:22-23, train_sd3_fast_pickscore.py:537-538), so its fp32 VAE convolutions round both
+ * operands to TF32 on the hardware it was written for; this is that arithmetic class on the fp16 MFMA.  An opt-in decoder mode
+ * (AutoencoderKLDecoder(f16_single=True)), priced as a leg of the bench line; the default stays the fp32-equivalent two-product form. */
+int advgrpo_conv3x3_nhwc_f16x1(const void* x2, const void* w16, float* y, int B, int Hout, int Wout, int Cin3, int Cout,
+                               int upsample, const float* bias, int act, const float* residual, const void* zero_page,
+                               float alpha, float* gn_partial, void* stream);
+int advgrpo_conv3x3_nhwc_f16x1_pair(const void* x2, const void* w16, void* pair_out, float pair_prescale, int B, int Hout, int Wout,
+                                    int Cin3, int Cout, int upsample, const float* bias, int act, const float* residual,
+                                    const void* zero_page, float alpha, void* stream);
 /* "bf16x2": the same two-product convolution for weights that are EXACT in bf16 (the released Qwen-Image VAE is a bf16
  * checkpoint; BASELINE config 5's decode, see advgrpo_rmsnorm_nhwc): x2 = split rows [hi | unwritten | lo] of bf16 pieces
  * (advgrpo_split_bf16x3 order 2, advgrpo_rmsnorm_nhwc out_mode 2), w16 = ONE bf16 piece [Cout, 9 C]; x_hi w + x_lo w on the bf16
@@ -439,6 +450,34 @@ typedef struct advgrpo_mmdit_block_desc {
 int64_t advgrpo_mmdit_block_workspace_bytes(int B, int Ni, int Nt, int D, int dual);
 int advgrpo_mmdit_block_forward(const advgrpo_mmdit_block_desc* block, void* workspace /* 256-byte aligned */, int64_t workspace_bytes,
                                 void* stream);
+
+/* ------------------------------------------------------------------ one MMDiT block's BACKWARD behind one entry (csrc/mmdit_block_bwd.cpp)
+ * The data-gradient chain of the same JointTransformerBlock inside loss.backward() (train_sd3_fast_pickscore.py:1165) of the transformer call of
+ * compute_log_prob (:233-267): feed-forward data gradients with GELU' in the epilogue, LayerNorm-modulate backward of both norms (writing the
+ * gated copies the next data-gradient GEMMs read), output-projection data gradients scattered into the joint rows, attention backward,
+ * QK-norm backward, q | k | v data gradients -- both streams, ~14 launches on `stream`.  *_wT: the forward weights TRANSPOSED, in nn.Linear
+ * layout ([in, out] -> a [N = in, K = out] matrix); saved activations as advgrpo_mmdit_block_forward's caller kept them: x_in / c_in (block
+ * inputs), x_mid / c_mid (streams after the attention residual), pre / cpre (feed-forward pre-activations, [M, 4 D]), qkv [B S, 3 D] (after
+ * QK-norm), rs [B S, 2 H] f32 (1 / rms), att [B, S, D] (row pitch ld_att, 0 = D), lse [B, H, S] f32 (base 2), and the second attention's
+ * qkv2 / rs2 / att2 / lse2 over the image rows.  Gradients: dx / dc of the block outputs, dyg / dcyg = gate_mlp * dx / c_gate_mlp * dc (written by
+ * the pass that produced dx / dc: block i + 1's call, or advgrpo_layernorm_mod_bwd_gated of the final layer); outputs dx_out / dc_out and, unless
+ * `first`, their copies gated with block i - 1's feed-forward gates (modulation rows at mod_x_prev / mod_c_prev).  dyo [B Ni, D], dyc [B Nt, D]
+ * (= gate_msa * d(stream after attention)) and dqkv [B S, 3 D] are OUTPUTS too: with att and the block's normalised inputs they are the
+ * operands of the LoRA adapter gradients (advgrpo_gemm_tn_grouped), which stay with the caller.  last: no text-stream output projection /
+ * feed-forward (context_pre_only block; dc, dcyg, dyc, c_mid, cpre unused).  bf16 unless noted, dense rows; bit-identical to the same launches
+ * issued one by one (adv_grpo_amd/mmdit_train.py keeps that sequencing for the LoRA side-path mode). */
+typedef struct advgrpo_mmdit_block_bwd_desc {
+    int32_t B, Ni, Nt, D, H, dual, last, first;
+    const void* mods; int64_t mod_stride, mod_x, mod_c, mod_x_prev, mod_c_prev, ld_att;
+    const void *ff2_wT, *ff1_wT, *cff2_wT, *cff1_wT, *out_wT, *cout_wT, *qkv_wT, *cqkv_wT, *out2_wT, *qkv2_wT;
+    const void *rms_x, *rms_c, *rms_2;
+    const void *x_in, *c_in, *x_mid, *c_mid, *pre, *cpre, *qkv, *rs, *att, *lse, *qkv2, *rs2, *att2, *lse2;
+    const void *dx, *dc, *dyg, *dcyg;
+    void *dx_out, *dc_out, *dyg_prev, *dcyg_prev, *dyo, *dyc, *dqkv;
+} advgrpo_mmdit_block_bwd_desc;
+int64_t advgrpo_mmdit_block_backward_workspace_bytes(int B, int Ni, int Nt, int D, int H, int dual);
+int advgrpo_mmdit_block_backward(const advgrpo_mmdit_block_bwd_desc* block, void* workspace /* 256-byte aligned */, int64_t workspace_bytes,
+                                 void* stream);
 
 /* ------------------------------------------------------------------ a ViT encoder stack behind one entry (csrc/vit_encoder.cpp)
  * The pre-LN transformer encoder of the reward towers: transformers' CLIPEncoderLayer x n behind CLIPModel.get_image_features /

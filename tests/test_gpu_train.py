@@ -178,6 +178,35 @@ def test_gated_copies_from_the_norm_backward_have_the_bits_of_gate_mul(layers, d
     assert torch.equal(dx0, dx1) and torch.equal(ya, ops.gate_mul(dx0, ga, rows)) and torch.equal(yb, ops.gate_mul(dx0, gb, rows))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("layers,dual,heads,overlap", [(4, (0, 2), 4, False), (2, (), 38, False), (3, (0, 1, 2), 24, True)])
+def test_block_backward_through_the_c_entry_is_bit_identical_to_the_python_sequencing(layers, dual, heads, overlap):
+    """advgrpo_mmdit_block_backward (csrc/mmdit_block_bwd.cpp): one C-ABI call per block for the data-gradient chain -- the same
+    launches in the same order as SD3TransformerLoRA.backward's Python loop: every LoRA gradient and both input gradients have the same bits
+    (dual and plain blocks, the context-pre-only last block, block 0 without gated copies; with and without the adapter gradients on the
+    side stream)."""
+    from adv_grpo_amd.mmdit_train import SD3TransformerLoRA
+    from oracle import mmdit as o
+    cfg = o.MMDiTConfig(num_layers=layers, num_heads=heads, joint_attention_dim=128, pooled_projection_dim=64,
+                        pos_embed_max_size=96, dual_attention_layers=dual)
+    W, lora, lat, t, ctx, pooled, g = _setup(cfg, 41, B=4, hw=16, Nt=13)
+    model = SD3TransformerLoRA(W, cfg, "cuda", lora_state=lora)
+    model.overlap_wgrad = overlap
+    dv = torch.randn(lat.shape, generator=g).to(torch.bfloat16).cuda()
+    res = []
+    for c_entry in (True, False):
+        model.c_block_bwd = c_entry
+        model.grads.zero_()
+        v, saved = model.forward_train(lat.cuda(), t.cuda(), ctx.cuda(), pooled.cuda())
+        dx, dc = model.backward(saved, dv)
+        torch.cuda.synchronize()
+        res.append((model.grads.clone(), dx.clone(), dc.clone()))
+    model.c_block_bwd = True
+    assert res[0][0].abs().max().item() > 0
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("layers,dual,heads", [(3, (0,), 4), (4, (0, 1), 4), (2, (), 38)])
 def test_mmdit_lora_backward_vs_autograd(layers, dual, heads):
     """(heads = 38: the SD3.5-large width D = 2432 of BASELINE config 4 -- more than 2048 columns per LayerNorm row, a width
