@@ -59,6 +59,25 @@ class MMDiTBlockBwdDesc(ctypes.Structure):
                                    "dx", "dc", "dyg", "dcyg", "dx_out", "dc_out", "dyg_prev", "dcyg_prev", "dyo", "dyc", "dqkv")])
 
 
+class VaeConv(ctypes.Structure):
+    """advgrpo_vae_conv (include/advgrpo.h), field for field."""
+    _fields_ = [("w", _P), ("bias", _P), ("cin", c_int32), ("cout", c_int32), ("form", c_int32), ("reserved", c_int32)]
+
+
+class VaeResnet(ctypes.Structure):
+    """advgrpo_vae_resnet (include/advgrpo.h), field for field."""
+    _fields_ = [(n, _P) for n in ("norm1_w", "norm1_b", "norm2_w", "norm2_b")] + [("conv1", VaeConv), ("conv2", VaeConv), ("shortcut_w", _P)]
+
+
+class VaeDecoderDesc(ctypes.Structure):
+    """advgrpo_vae_decoder_desc (include/advgrpo.h), field for field."""
+    _fields_ = ([(n, c_int32) for n in ("B", "h", "w", "latent_channels", "groups", "n_up", "resnets_per_up", "f16_single")] +
+                [("scaling_factor", c_float), ("shift_factor", c_float), ("conv_in", VaeConv), ("conv_out", VaeConv), ("norm_out_w", _P), ("norm_out_b", _P),
+                 ("mid", VaeResnet * 2)] +
+                [(n, _P) for n in ("attn_norm_w", "attn_norm_b", "attn_q_w", "attn_k_w", "attn_v_w", "attn_o_w", "attn_q_b", "attn_k_b", "attn_v_b", "attn_o_b")] +
+                [("up_resnets", POINTER(VaeResnet)), ("upsamplers", POINTER(VaeConv)), ("zero_page", _P)])
+
+
 class VitLayer(ctypes.Structure):
     """advgrpo_vit_layer (include/advgrpo.h), field for field."""
     _fields_ = [(n, _P) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ls1", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
@@ -132,6 +151,8 @@ SIGNATURES = {
     "advgrpo_mmdit_block_forward": (c_int, [POINTER(MMDiTBlockDesc), _P, c_int64, _P]),
     "advgrpo_mmdit_block_backward_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "advgrpo_mmdit_block_backward": (c_int, [POINTER(MMDiTBlockBwdDesc), _P, c_int64, _P]),
+    "advgrpo_vae_decode_workspace_bytes": (c_int64, [POINTER(VaeDecoderDesc)]),
+    "advgrpo_vae_decode": (c_int, [POINTER(VaeDecoderDesc), _P, c_int, _P, _P, c_int64, _P]),
     "advgrpo_vit_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "advgrpo_vit_forward": (c_int, [POINTER(VitDesc), _P, c_int64, _P]),
     "advgrpo_gemm_tn_grouped_workspace_bytes": (c_int64, [POINTER(TnDesc), c_int]),

@@ -85,8 +85,8 @@ __device__ __forceinline__ void x3_tie(bf16x8_t (&a)[N]) {
 // PIECE = 3 ("f16x1", round 6): the TF32-CLASS form of f16x2 -- ONE fp16 product per f32 product: the activation's hi half only (11 significant
 // bits, what a TF32 operand keeps; the weights are exact), f32 accumulation, f32 between kernels.  The reference runs with allow_tf32 = True
 // (config/base.py:22-23, TP:537-538), i.e. its fp32 convolutions round both operands to 10 explicit mantissa bits on Ampere+; this is that
-// arithmetic class on the fp16 MFMA.  Same pipeline and the same DMA (the lo pieces still travel: the hand-counted waits stay valid), the lo
-// fragment reads and products are left out.  Priced as a leg of the bench line, never the default.
+// arithmetic class on the fp16 MFMA.  Same pipeline; the lo pieces are neither requested nor read nor multiplied.  Priced as a leg of the bench
+// line, never the default.
 // DBG (experiments build only, scripts/probes/x3_decompose.sh): 1 = no DMA after the prologue, 2 = no MFMAs, 3 = fragments read
 // once -- WRONG results, used to price the three activities of the k loop against each other
 template <int X3_WM, int X3_WN, int DBG = 0, int PIECE = 0>
@@ -146,7 +146,9 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
             const bf16_t* lo = ok ? hi + 2 * C : hi;                          // [hi | hi | lo]
             char* dst = base + (wave + it * NW) * 1024;
             __builtin_amdgcn_global_load_lds((x3_gptr_t)hi, (x3_lds_ptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((x3_gptr_t)lo, (x3_lds_ptr_t)(dst + X3_XPIECE), 16, 0, 0);
+            // (f16x1 reads the hi pieces only.  Every wait of the k loop allows the WPI * WI most recent requests -- a weight stage -- to be outstanding
+            // and nothing older, so leaving the lo requests out changes no count)
+            if constexpr (!X1) __builtin_amdgcn_global_load_lds((x3_gptr_t)lo, (x3_lds_ptr_t)(dst + X3_XPIECE), 16, 0, 0);
         }
     };
     auto stage_w = [&](int buf, int g, int dxi) {

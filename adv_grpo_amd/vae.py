@@ -223,7 +223,78 @@ class AutoencoderKLDecoder:
         y = ops.gemm(o3, w[f"{p}.to_out.0.weight"], out_dtype=f32)
         return ops.add_rows_f32(y, x.view(B * T, C), bias=w[f"{p}.to_out.0.bias"]).view(B, H, W, C)
 
+    c_decode = True                  # the chain through advgrpo_vae_decode (one C-ABI call per decode); False: launch by launch
+
+    def _c_desc(self):
+        """The decoder's weights as advgrpo_vae_decoder_desc (built once: the tensors it points at live in self.w; B / h / w are set per call on a copy)."""
+        d = self.__dict__.get("_cdesc")
+        if d is not None:
+            return d
+        import ctypes
+        from . import _lib
+        w, cfg = self.w, self.cfg
+
+        def conv(name):
+            c = _lib.VaeConv()
+            if name + ".weight@f16" in w:
+                t = w[name + ".weight@f16"]
+                c.w, c.cin, c.cout, c.form = t.data_ptr(), t.shape[1] // 9, t.shape[0], 1
+            else:
+                t = w[name + ".weight"]
+                c.w, c.cin, c.cout, c.form = t.data_ptr(), t.shape[1] // 27, t.shape[0], 0
+            c.bias = w[name + ".bias"].data_ptr()
+            return c
+
+        def resnet(r, p):
+            r.norm1_w, r.norm1_b = w[f"{p}.norm1.weight"].data_ptr(), w[f"{p}.norm1.bias"].data_ptr()
+            r.norm2_w, r.norm2_b = w[f"{p}.norm2.weight"].data_ptr(), w[f"{p}.norm2.bias"].data_ptr()
+            r.conv1, r.conv2 = conv(f"{p}.conv1"), conv(f"{p}.conv2")
+            sc = w.get(f"{p}.conv_shortcut.weight")
+            r.shortcut_w = sc.data_ptr() if sc is not None else None
+        n, per = len(cfg.block_out_channels), cfg.layers_per_block + 1
+        d = _lib.VaeDecoderDesc()
+        d.latent_channels, d.groups, d.n_up, d.resnets_per_up, d.f16_single = cfg.latent_channels, self.G, n, per, int(self.f16_single)
+        d.scaling_factor, d.shift_factor = cfg.scaling_factor, cfg.shift_factor
+        d.conv_in, d.conv_out = conv("decoder.conv_in"), conv("decoder.conv_out")
+        d.norm_out_w, d.norm_out_b = w["decoder.conv_norm_out.weight"].data_ptr(), w["decoder.conv_norm_out.bias"].data_ptr()
+        resnet(d.mid[0], "decoder.mid_block.resnets.0")
+        resnet(d.mid[1], "decoder.mid_block.resnets.1")
+        a = "decoder.mid_block.attentions.0"
+        d.attn_norm_w, d.attn_norm_b = w[f"{a}.group_norm.weight"].data_ptr(), w[f"{a}.group_norm.bias"].data_ptr()
+        for k, nm in (("q", "to_q"), ("k", "to_k"), ("v", "to_v"), ("o", "to_out.0")):
+            setattr(d, f"attn_{k}_w", w[f"{a}.{nm}.weight"].data_ptr())
+            setattr(d, f"attn_{k}_b", w[f"{a}.{nm}.bias"].data_ptr())
+        ups = (_lib.VaeResnet * (n * per))()
+        for i in range(n):
+            for j in range(per):
+                resnet(ups[i * per + j], f"decoder.up_blocks.{i}.resnets.{j}")
+        samp = (_lib.VaeConv * max(1, n - 1))()
+        for i in range(n - 1):
+            samp[i] = conv(f"decoder.up_blocks.{i}.upsamplers.0.conv")
+        d.up_resnets, d.upsamplers = ctypes.cast(ups, ctypes.POINTER(_lib.VaeResnet)), ctypes.cast(samp, ctypes.POINTER(_lib.VaeConv))
+        self._czero = ops.zero_page(self.device)
+        d.zero_page = self._czero.data_ptr()
+        self._cdesc, self._cdesc_arrays = d, (ups, samp)
+        return d
+
+    def _decode_x3_chain_c(self, latents):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        B, C, h, wd = latents.shape
+        d = _lib.VaeDecoderDesc.from_buffer_copy(self._c_desc())       # per call: decodes run from several host threads
+        d.B, d.h, d.w, d.f16_single = B, h, wd, int(self.f16_single)
+        z = latents.contiguous()
+        up = 2 ** (len(self.cfg.block_out_channels) - 1)               # one x2 upsampler between consecutive up blocks
+        img = torch.empty(B, 3, h * up, wd * up, dtype=torch.float32, device=z.device)
+        ws = torch.empty(int(lib.advgrpo_vae_decode_workspace_bytes(ctypes.byref(d))), dtype=torch.uint8, device=z.device)
+        _lib.check(lib.advgrpo_vae_decode(ctypes.byref(d), z.data_ptr(), _lib.dtype_code(z.dtype), img.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          _lib.stream_ptr()))
+        return img
+
     def _decode_x3_chain(self, latents):
+        if self.c_decode and self.fused_gn_stats and self.fused_pair_out:
+            return self._decode_x3_chain_c(latents)
         cfg = self.cfg
         x = self._conv3("decoder.conv_in", ops.latents_to_nhwc_x3(latents, 64, cfg.scaling_factor, cfg.shift_factor))
         x = self._res3("decoder.mid_block.resnets.0", x)

@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="N > 1 (or --spawn): bring the process group up, check that every rank is there (all-reduce of ones, device "
                          "names), time the path's two collectives alone, print that as the JSON line and stop -- no model is built")
+    ap.add_argument("--groups-in-flight", type=int, default=2, help="experiment: prompt groups in flight per rank on the trainer schedule (the Trainer default is 2)")
+    ap.add_argument("--vae-one-stream", action="store_true", help="experiment: decode a group on ONE stream (default: two half batches on two streams)")
     ap.add_argument("--cfg-streams", action="store_true", help="experiment: the two halves of the CFG batch as two forwards on two HIP streams")
     ap.add_argument("--sync-scoring", action="store_true",
                     help="score each group on the launch stream right after its decode instead of on the reward-future stream (SURVEY 8a11)")
@@ -267,7 +269,8 @@ def full_epoch(device, world=1, rank=0, adversarial=False, qwen=False, large=Fal
     g_inside = {}
     for kind, e0, e1 in getattr(trainer, "gstep_events", []):
         g_inside.setdefault(kind, []).append(e0.elapsed_time(e1))
-    g_inside = {k: {"n": len(v), "mean_ms": round(sum(v) / len(v), 2), "min_ms": round(min(v), 2), "max_ms": round(max(v), 2)}
+    g_inside = {k: {"n": len(v), "mean_ms": round(sum(v) / len(v), 2), "min_ms": round(min(v), 2), "max_ms": round(max(v), 2),
+                    **({"ms_in_order": [round(x, 1) for x in v]} if len(v) <= 8 else {})}
                 for k, v in g_inside.items()}
     phases = dict(trainer.timers)
     if world > 1:                              # slowest rank per phase (every rank walks the phases in the same order)
@@ -581,6 +584,8 @@ def main():
     G, STEPS, T, RES = (4, 10, 2, 1024) if c4 else ((8, 10, 2, 1024) if c5 else (8, 10, 2, 512))
     if args.cfg_streams:
         pipe.cfg_two_streams = True
+    if args.vae_one_stream and hasattr(pipe.vae, "two_streams"):
+        pipe.vae.two_streams = False
     sampler = DistributedKRepeatSampler(range(25432), 1, 1, world, rank, seed=42)   # k = 1: one group per rank
     # synthetic prompts: one embedding set per dataset index is not needed for timing; a fixed set per rank
     text_tower = None
@@ -701,7 +706,7 @@ def main():
     # The Trainer's default schedule (config sample.groups_in_flight = 2; trainer.py sample_epoch, TP:668,816-817): two rollout worker threads,
     # one HIP stream each (measured concurrent, like the Trainer's), scoring as reward futures on the one scoring stream; the reward gather and
     # the group advantage of every group run on the MAIN thread in group order (so the collectives of all ranks stay in one order).
-    in_flight = 2 if args.schedule == "trainer" else 1
+    in_flight = max(2, args.groups_in_flight) if args.schedule == "trainer" else 1
     roll_pool, roll_tls, roll_streams = None, threading.local(), []
     if in_flight > 1:
         from concurrent.futures import ThreadPoolExecutor
@@ -742,6 +747,11 @@ def main():
         return out
 
     timed_steps = steps_in_flight if in_flight > 1 else steps_pipelined
+    # as Trainer.sample_epoch: with two groups in flight the decoder keeps a group on ONE stream (its two-half-batches split is for a decoder
+    # that has the GPU to itself: the serial leg and the pricing legs below)
+    vae_split = getattr(pipe.vae, "two_streams", None)
+    if vae_split is not None and in_flight > 1:
+        pipe.vae.two_streams = False
     if args.warmup:
         timed_steps(0, args.warmup)
     ops.PROFILE, ops.PROFILE_STRIDE = ([] if in_flight == 1 else None), max(1, args.event_stride)
@@ -760,6 +770,8 @@ def main():
         dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
     assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all()
+    if vae_split is not None and not args.vae_one_stream:
+        pipe.vae.two_streams = vae_split
     # The serial leg (trainer schedule only): the same number of steps, one prompt group at a time on the launch stream.  Per-kernel
     # durations are only defined here -- with two groups in flight a launch's HIP-event interval includes the other stream's kernels -- so
     # the `roofline` object is taken from this leg and `serial` carries its whole-step figures.  Every rank runs it (it has the collectives).
@@ -1031,7 +1043,7 @@ def main():
                                      "PickScore (CLIP ViT-H/14) reward") + ", reward all-gather + group advantage")), "global_batch": world * G,
                        "transformer_batch_per_gpu": 2 * G, "parallelism": f"dp{world} (prompt groups sharded)",
                        "schedule": ("trainer default (config sample.groups_in_flight = 2, adv_grpo_amd/trainer.py sample_epoch): two prompt groups per rank rolled "
-                                    "out at the same time, one HIP stream + one host thread each, scores as reward futures on one scoring stream, "
+                                    "out at the same time, one HIP stream + one host thread each (a group's VAE decode on that one stream), scores as reward futures on one scoring stream, "
                                     "reward gather + group advantage per group on the main thread in group order; samples bit-identical to the serial "
                                     "schedule (tests/test_gpu_trainer.py::test_groups_in_flight_do_not_change_the_samples)")
                        if in_flight > 1 else "serial: one prompt group at a time on the launch stream, scores as reward futures"},

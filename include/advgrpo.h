@@ -479,6 +479,44 @@ int64_t advgrpo_mmdit_block_backward_workspace_bytes(int B, int Ni, int Nt, int 
 int advgrpo_mmdit_block_backward(const advgrpo_mmdit_block_bwd_desc* block, void* workspace /* 256-byte aligned */, int64_t workspace_bytes,
                                  void* stream);
 
+/* ------------------------------------------------------------------ the VAE decoder behind one entry (csrc/vae_decode.cpp)
+ * `pipeline.vae.decode(latents / scaling_factor + shift_factor)` + `image_processor.postprocess(image, "pt")` of the rollout
+ * (adv_grpo/diffusers_patch/sd3_pipeline_with_logprob_fast.py:667-670) in the fp32-EQUIVALENT arithmetic (the reference decodes in fp32,
+ * train_sd3_fast_pickscore.py:481): diffusers' AutoencoderKL decoder of SD3 / SD3.5 -- conv_in, mid block (resnet, single-head attention,
+ * resnet), n_up up blocks of resnets_per_up resnets with a nearest x2 upsample + convolution between them, GroupNorm + SiLU + conv_out --
+ * ~190 launches on `stream`.  A 3x3 convolution is described by advgrpo_vae_conv: form 1 = w is ONE fp16 piece [cout, 9 cin] (weights exact
+ * in fp16: the two-product "f16x2" kernels, or the one-product "f16x1" ones when f16_single != 0), form 0 = w is the split-bf16 operand
+ * [cout, 9 * 3 cin] (advgrpo_split_bf16x3 order 1 per tap: three products); cin is the padded channel count (a multiple of 64); bias f32.
+ * A resnet's 1x1 shortcut weight is the split-bf16 [cout, 3 cin] operand and its bias is already added to conv2's.  The attention projections
+ * are split-bf16 [C, 3 C] operands with f32 biases; GroupNorm affines f32.  up_resnets / upsamplers are HOST arrays.  latents [B, C, h, w]
+ * f32 or bf16 as the rollout holds them (pre-scaling); image [B, 3, 8 h, 8 w] f32 in [0, 1].  Bit-identical to the launches issued one by one
+ * (adv_grpo_amd/vae.py keeps that sequencing as the check). */
+typedef struct advgrpo_vae_conv {
+    const void* w; const float* bias;
+    int32_t cin, cout, form, reserved;
+} advgrpo_vae_conv;
+typedef struct advgrpo_vae_resnet {
+    const float *norm1_w, *norm1_b, *norm2_w, *norm2_b;
+    advgrpo_vae_conv conv1, conv2;
+    const void* shortcut_w;
+} advgrpo_vae_resnet;
+typedef struct advgrpo_vae_decoder_desc {
+    int32_t B, h, w, latent_channels, groups, n_up, resnets_per_up, f16_single;
+    float scaling_factor, shift_factor;
+    advgrpo_vae_conv conv_in, conv_out;
+    const float *norm_out_w, *norm_out_b;
+    advgrpo_vae_resnet mid[2];
+    const float *attn_norm_w, *attn_norm_b;
+    const void *attn_q_w, *attn_k_w, *attn_v_w, *attn_o_w;
+    const float *attn_q_b, *attn_k_b, *attn_v_b, *attn_o_b;
+    const advgrpo_vae_resnet* up_resnets;      /* [n_up * resnets_per_up] */
+    const advgrpo_vae_conv* upsamplers;        /* [n_up - 1] */
+    const void* zero_page;                     /* >= 256 zero bytes of device memory (the padding taps read it) */
+} advgrpo_vae_decoder_desc;
+int64_t advgrpo_vae_decode_workspace_bytes(const advgrpo_vae_decoder_desc* decoder);
+int advgrpo_vae_decode(const advgrpo_vae_decoder_desc* decoder, const void* latents, int latents_dtype, float* image,
+                       void* workspace /* 256-byte aligned */, int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ a ViT encoder stack behind one entry (csrc/vit_encoder.cpp)
  * The pre-LN transformer encoder of the reward towers: transformers' CLIPEncoderLayer x n behind CLIPModel.get_image_features /
  * get_text_features (adv_grpo/pickscore_scorer.py:40-44, adv_grpo/pick_score_training.py:95-106; ViT-H/14: 32 layers, 16 heads x 80; text:

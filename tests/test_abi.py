@@ -78,7 +78,8 @@ def test_header_is_plain_c_and_struct_layouts_match_the_ctypes_mirrors(tmp_path)
     header = open(os.path.join(root, "include", "advgrpo.h")).read()
     mirrors = {"advgrpo_gemm_desc": _lib.GemmDesc, "advgrpo_ln_desc": _lib.LnDesc, "advgrpo_mmdit_block_desc": _lib.MMDiTBlockDesc,
                "advgrpo_lora_merge_item": _lib.LoraMergeItem, "advgrpo_tn_desc": _lib.TnDesc, "advgrpo_fp8_scales": _lib.Fp8Scales,
-               "advgrpo_vit_layer": _lib.VitLayer, "advgrpo_vit_desc": _lib.VitDesc, "advgrpo_mmdit_block_bwd_desc": _lib.MMDiTBlockBwdDesc}
+               "advgrpo_vit_layer": _lib.VitLayer, "advgrpo_vit_desc": _lib.VitDesc, "advgrpo_mmdit_block_bwd_desc": _lib.MMDiTBlockBwdDesc,
+               "advgrpo_vae_conv": _lib.VaeConv, "advgrpo_vae_resnet": _lib.VaeResnet, "advgrpo_vae_decoder_desc": _lib.VaeDecoderDesc}
     declared = set(re.findall(r"^\} (advgrpo_\w+);", header, flags=re.M)) | set(re.findall(r"typedef struct \w+ \{[^}]*\} (advgrpo_\w+);", header))
     assert declared == set(mirrors), (declared, set(mirrors))          # a struct added to the header needs its mirror (and this test)
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "advgrpo.h"', 'int main(void) {']

@@ -535,3 +535,28 @@ def test_f16_pair_split_saturates_instead_of_overflowing():
         want = x.clamp(-65504.0 / s, 65504.0 / s)
         assert torch.isfinite(rows[:, :K]).all() and torch.isfinite(rows[:, 2 * K:]).all()
         assert ((got - want).abs() <= want.abs() * 2.0 ** -20 + 1e-30).all(), (s, got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fp16_checkpoint,single", [(True, False), (False, False), (True, True)])
+def test_vae_decode_through_the_c_entry_is_bit_identical_to_the_python_sequencing(fp16_checkpoint, single):
+    """advgrpo_vae_decode (csrc/vae_decode.cpp): the decoder's ~190 launches behind one C-ABI call -- the same kernels in the same order
+    with the same fusions (GroupNorm sums from the producing epilogue, pair-row outputs in front of the upsamplers) as vae.py's Python chain:
+    the image has the same bits, for an fp16-exact checkpoint (f16x2 kernels), a non-exact one (three products everywhere), the f16x1 opt-in,
+    and through the two-stream split of a batch."""
+    from adv_grpo_amd import synthetic
+    from adv_grpo_amd.vae import AutoencoderKLDecoder
+    from oracle import vae as o
+    cfg = o.VaeConfig()
+    dec = AutoencoderKLDecoder(synthetic.vae_decoder_weights(cfg, 99, fp16_checkpoint=fp16_checkpoint), cfg, "cuda", mode="bf16x3", f16_single=single)
+    lat = torch.randn(3, 16, 24, 40, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16).cuda()      # odd batch, non-square
+    imgs = {}
+    for c_entry in (True, False):
+        dec.c_decode = c_entry
+        imgs[c_entry] = dec.decode_to_image(lat)
+        torch.cuda.synchronize()
+    dec.c_decode = True
+    assert imgs[True].shape == (3, 3, 192, 320) and torch.equal(imgs[True], imgs[False])
+    dec.two_streams = False
+    assert torch.equal(dec.decode_to_image(lat), imgs[True])
+    assert torch.equal(dec.decode_to_image(lat.float()), dec.decode_to_image(lat.float()))     # f32 latents take the same entry
