@@ -210,6 +210,9 @@ class Trainer:
         # lazily on the scoring worker, the device-wide synchronisations of the probe waited for every thread's kernels)
         if hasattr(scorer, "prepare_streams") and torch.cuda.is_available():
             scorer.prepare_streams(([self._score_stream] if self.async_reward else []) + [torch.cuda.current_stream(torch.device(self.device))])
+        if hasattr(self.pipe.vae, "prepare_streams") and torch.cuda.is_available() and getattr(self.pipe.vae, "mode", None) == "bf16x3":
+            self.pipe.vae.prepare_streams([torch.cuda.current_stream(torch.device(self.device))],
+                                          also=[self._score_stream] if self.async_reward else [])
         self.epoch, self.global_step = 0, 0
         self.logger = JsonlLogger(log_path, enabled=(rank == 0))
         self.timers = {}

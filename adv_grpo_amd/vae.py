@@ -311,6 +311,18 @@ class AutoencoderKLDecoder:
         y = self._conv3("decoder.conv_out", self._gn3("decoder.conv_norm_out", x, True))
         return ops.image_postprocess(y)
 
+    def prepare_streams(self, streams, also=()):
+        """Choose NOW, by measurement (ops.concurrent_stream), the side stream(s) the two-half-batches decode will use when called on each of
+        `streams` -- concurrent with that stream and with the streams in `also` (a scoring stream).  A side stream created lazily inside the
+        first decode is whatever hardware queue HIP hands out next: round 6 saw the serial bench leg at 423 instead of 385 ms per step when that
+        queue happened to be shared (the decode's halves and the reward future then take turns).  Call at construction time (it synchronises the
+        device), as PickScoreScorer.prepare_streams."""
+        with self._side_lock:
+            for st in streams:
+                sides = self._side.setdefault(st.cuda_stream, [])
+                while len(sides) < self.n_streams - 1:
+                    sides.append(ops.concurrent_stream(self.device, [st] + list(also) + sides))
+
     def _decode_x3(self, latents):
         """The decoder is one serial chain in which MFMA-bound convolutions (one workgroup per CU, all of its LDS) alternate with
         HBM-bound GroupNorm / split passes that need no LDS at all.  A batch of two or more images is decoded as two half

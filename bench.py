@@ -624,6 +624,10 @@ def main():
     # serial (one prompt group at a time on the launch stream).  --sync-scoring puts it back on the launch stream.
     score_stream = None if args.sync_scoring else torch.cuda.Stream(device=device)
 
+    # the decoder's side stream for decodes issued on the launch stream (serial leg, pricing legs): chosen by measurement now, before any other stream exists
+    if hasattr(pipe.vae, "prepare_streams") and getattr(pipe.vae, "mode", None) == "bf16x3":
+        pipe.vae.prepare_streams([torch.cuda.current_stream(device)], also=[score_stream] if score_stream is not None else [])
+
     def score(image):
         if c5 or c3:    # the co-trained DINOv2 patch scorer (RW:375-434): bicubic -> 518, ViT-B/14, 64 random patches, head
             scores, _ = dino_score(dino, dino_head, image.to(torch.bfloat16), None, None)
