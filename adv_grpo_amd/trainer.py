@@ -210,12 +210,49 @@ class Trainer:
         # lazily on the scoring worker, the device-wide synchronisations of the probe waited for every thread's kernels)
         if hasattr(scorer, "prepare_streams") and torch.cuda.is_available():
             scorer.prepare_streams(([self._score_stream] if self.async_reward else []) + [torch.cuda.current_stream(torch.device(self.device))])
-        if hasattr(self.pipe.vae, "prepare_streams") and torch.cuda.is_available() and getattr(self.pipe.vae, "mode", None) == "bf16x3":
-            self.pipe.vae.prepare_streams([torch.cuda.current_stream(torch.device(self.device))],
-                                          also=[self._score_stream] if self.async_reward else [])
+        # the rollout workers' streams (config sample.groups_in_flight, default 2) exist from construction as well, and the decoder's side stream for
+        # decodes on the launch stream (one group at a time, evaluate()) is one of them: they are idle whenever such a decode runs, and a fifth
+        # live stream beside them cost the in-flight schedule 2.5 % (vae.py: set_side_streams)
+        self._rollout_pool = None
+        if torch.cuda.is_available() and torch.device(self.device).type == "cuda":
+            self._make_rollout_streams(int(c.sample.get("groups_in_flight", 2)))
+            vae = self.pipe.vae
+            if hasattr(vae, "prepare_streams") and getattr(vae, "mode", None) == "bf16x3":
+                main = torch.cuda.current_stream(torch.device(self.device))
+                if self._rollout_pool is not None:
+                    vae.set_side_streams(main, self._rollout_stream_list)
+                else:
+                    vae.prepare_streams([main], also=[self._score_stream] if self.async_reward else [])
+            # ... and so is the G-step's adapter-gradient side stream (no group is in flight during the update half).  The model measured one of its
+            # own when it was built, but a stream measured BEFORE other streams came to life does not stay concurrent with the launch stream
+            # (LABNOTES 6 round 5; round 6: 110 instead of 87 ms per micro-step on the stream the model had chosen before this constructor ran)
+            tr = self.pipe.transformer
+            if getattr(tr, "_wgrad_stream", None) is not None:
+                tr._wgrad_stream = self._rollout_stream_list[-1] if self._rollout_pool is not None else \
+                    ops.concurrent_stream(torch.device(self.device), [torch.cuda.current_stream(torch.device(self.device))])
         self.epoch, self.global_step = 0, 0
         self.logger = JsonlLogger(log_path, enabled=(rank == 0))
         self.timers = {}
+
+    def _make_rollout_streams(self, in_flight):
+        """One worker thread + one HIP stream per prompt group in flight; the streams are chosen by measurement (ops.concurrent_stream: concurrent
+        with the launch stream, with each other and with the scoring stream), which synchronises the device: construction time, or the first
+        sample_epoch after groups_in_flight changed."""
+        if in_flight < 2:
+            return
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        if self._rollout_pool is not None:
+            self._rollout_pool.shutdown(wait=True)
+        self._rollout_pool = ThreadPoolExecutor(max_workers=in_flight, thread_name_prefix="advgrpo-rollout")
+        d = torch.device(self.device)
+        self._rollout_dev = d.index if d.index is not None else torch.cuda.current_device()
+        self._rollout_streams = []
+        for _ in range(in_flight):
+            partners = [torch.cuda.current_stream(d)] + ([self._score_stream] if self.async_reward else []) + list(self._rollout_streams)
+            self._rollout_streams.append(ops.concurrent_stream(d, partners))
+        self._rollout_stream_list = list(self._rollout_streams)      # (the workers pop theirs from _rollout_streams)
+        self._rollout_tls, self._rollout_lock = threading.local(), threading.Lock()
 
     def _trainable_state(self):
         """Flat f32 parameter vectors that training changes (LoRA, discriminator head / last CLIP layer)."""
@@ -339,16 +376,8 @@ class Trainer:
         if in_flight == 1:
             done = [rollout(i, *inputs(i)) for i in range(nb)]
         else:
-            if getattr(self, "_rollout_pool", None) is None or self._rollout_pool._max_workers != in_flight:
-                from concurrent.futures import ThreadPoolExecutor
-                self._rollout_pool = ThreadPoolExecutor(max_workers=in_flight, thread_name_prefix="advgrpo-rollout")
-                d = torch.device(self.device)
-                self._rollout_dev = d.index if d.index is not None else torch.cuda.current_device()
-                self._rollout_streams = []           # pairwise concurrent by measurement (ops.concurrent_stream: hardware queues)
-                for _ in range(in_flight):
-                    self._rollout_streams.append(ops.concurrent_stream(d, list(self._rollout_streams) or None))
-                import threading
-                self._rollout_tls, self._rollout_lock = threading.local(), threading.Lock()
+            if self._rollout_pool is None or self._rollout_pool._max_workers != in_flight:
+                self._make_rollout_streams(in_flight)
             main = torch.cuda.current_stream()
 
             def work(i, args, ready):

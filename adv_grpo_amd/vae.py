@@ -323,6 +323,15 @@ class AutoencoderKLDecoder:
                 while len(sides) < self.n_streams - 1:
                     sides.append(ops.concurrent_stream(self.device, [st] + list(also) + sides))
 
+    def set_side_streams(self, stream, sides):
+        """Use THESE streams as the side stream(s) of decodes called on `stream` -- for a caller that already owns streams which are idle whenever
+        such a decode runs (the Trainer's rollout streams: decodes on the launch stream only happen while no group is in flight).  Round 6, one
+        box: with a freshly measured side stream beside two rollout streams and a scoring stream the in-flight schedule lost 2.5 % (377 vs 369 ms
+        per step) although every pair of streams measured as concurrent -- five live streams no longer get a hardware pipe each; without any
+        preparation the lazily created side stream cost the serial schedule 10 % (425 vs 387 ms)."""
+        with self._side_lock:
+            self._side[stream.cuda_stream] = list(sides)[:max(0, self.n_streams - 1)]
+
     def _decode_x3(self, latents):
         """The decoder is one serial chain in which MFMA-bound convolutions (one workgroup per CU, all of its LDS) alternate with
         HBM-bound GroupNorm / split passes that need no LDS at all.  A batch of two or more images is decoded as two half

@@ -166,7 +166,7 @@ def pmc_traffic(kernel, config="c2"):
     WRITE_SIZE in separate runs of this same command, scripts/pmc_traffic.py: (2*FETCH_SIZE + WRITE_SIZE)*1024, the factor 2
     being the gfx950 correction of MI355X_MICROARCH.md); None when no pass of that config is committed."""
     root = os.path.dirname(os.path.abspath(__file__))
-    files = (f"profiles/r5_pmc_traffic_{config}.json", f"profiles/r4_pmc_traffic_{config}.json", f"profiles/r3_pmc_traffic_{config}.json") + \
+    files = (f"profiles/r6_pmc_traffic_{config}.json", f"profiles/r5_pmc_traffic_{config}.json", f"profiles/r4_pmc_traffic_{config}.json", f"profiles/r3_pmc_traffic_{config}.json") + \
         (("profiles/r2_pmc_traffic.json", "profiles/r1_pmc_traffic.json") if config == "c2" else ())
     for rel in files:
         path = os.path.join(root, rel)
@@ -624,10 +624,6 @@ def main():
     # serial (one prompt group at a time on the launch stream).  --sync-scoring puts it back on the launch stream.
     score_stream = None if args.sync_scoring else torch.cuda.Stream(device=device)
 
-    # the decoder's side stream for decodes issued on the launch stream (serial leg, pricing legs): chosen by measurement now, before any other stream exists
-    if hasattr(pipe.vae, "prepare_streams") and getattr(pipe.vae, "mode", None) == "bf16x3":
-        pipe.vae.prepare_streams([torch.cuda.current_stream(device)], also=[score_stream] if score_stream is not None else [])
-
     def score(image):
         if c5 or c3:    # the co-trained DINOv2 patch scorer (RW:375-434): bicubic -> 518, ViT-B/14, 64 random patches, head
             scores, _ = dino_score(dino, dino_head, image.to(torch.bfloat16), None, None)
@@ -715,9 +711,19 @@ def main():
     if in_flight > 1:
         from concurrent.futures import ThreadPoolExecutor
         roll_pool = ThreadPoolExecutor(max_workers=in_flight, thread_name_prefix="bench-rollout")
-        for _ in range(in_flight):
-            roll_streams.append(ops.concurrent_stream(device, list(roll_streams) or None))
+        for _ in range(in_flight):     # measured concurrent with the launch stream, with each other AND with the scoring stream (a rollout stream that
+            # shares a hardware queue with the scoring stream serialises that group's rollout behind the other group's reward future)
+            partners = [torch.cuda.current_stream(device)] + ([score_stream] if score_stream is not None else []) + list(roll_streams)
+            roll_streams.append(ops.concurrent_stream(device, partners))
         roll_lock = threading.Lock()
+    # The decoder's side stream for decodes issued on the launch stream (serial leg, pricing legs), fixed NOW (a lazily created one cost the serial
+    # leg 10 %): a rollout stream when there are any -- they are idle whenever such a decode runs, and a fifth live stream cost the in-flight leg
+    # 2.5 % (vae.py set_side_streams) -- else one chosen by measurement.  Trainer.__init__ does the same.
+    if hasattr(pipe.vae, "prepare_streams") and getattr(pipe.vae, "mode", None) == "bf16x3":
+        if roll_streams:
+            pipe.vae.set_side_streams(torch.cuda.current_stream(device), list(roll_streams))
+        else:
+            pipe.vae.prepare_streams([torch.cuda.current_stream(device)], also=[score_stream] if score_stream is not None else [])
 
     def steps_in_flight(first, n):
         """n timed steps on the Trainer's schedule: every group is submitted to the two rollout workers up front, its scores are a future on
