@@ -35,6 +35,7 @@ class _PairRows:
 
 
 class AutoencoderKLDecoder:
+    f16_single = False               # (class default: subclasses with their own constructor -- the Qwen-Image decoder -- have no such mode)
     def __init__(self, state_dict, cfg, device="cuda", mode="bf16x3", f16_weights=True, f16_single=False):
         """f16_weights (bf16x3 mode): run a 3x3 convolution whose weight tensor is EXACT in fp16 on the two-product f16x2 kernel
         (decided per tensor at load time; False: always the three split-bf16 products).

@@ -1065,7 +1065,9 @@ def main():
             "roofline": roofline,
             "serial": None if serial_dt is None else {
                 "ms_per_step": round(serial_dt / args.steps * 1e3, 2), "value": round(images / serial_dt, 3), "steps": args.steps,
-                "frac": round(per_image_tflop * images / serial_dt / world / BF16_DENSE_PEAK_TFLOPS, 4),
+                "frac": round(mixed_peak_s * images / serial_dt / world, 4) if mixed_peak_s is not None else
+                round(per_image_tflop * images / serial_dt / world / BF16_DENSE_PEAK_TFLOPS, 4),
+                "frac_of": "the mixed fp8 / bf16 MFMA peak (frac_of_mixed_mfma_peak)" if mixed_peak_s is not None else "the bf16 MFMA peak",
                 "note": "the same steps with one prompt group at a time on the launch stream (the headline schedule of rounds 1-5), timed right behind the "
                         "timed steps with the same barrier + synchronize bracket; `roofline` and the pricing legs (vae / scoring / cfg_two_streams / "
                         "fp8_linears / lora) belong to this schedule"},

@@ -369,6 +369,26 @@ def test_groups_in_flight_do_not_change_the_samples():
     assert a["latents"].shape[0] == 3 * tr_.cfg.sample.mini_num_image_per_prompt
 
 
+def test_trainer_side_streams_are_its_rollout_streams():
+    """Round 6: the streams a Trainer needs beside the launch stream exist from construction and are as few as possible -- the scoring stream and
+    one stream per group in flight; the decoder's side stream for decodes on the launch stream and the G-step's adapter-gradient side stream ARE
+    rollout streams (idle whenever those run).  A fifth live stream cost the in-flight schedule 2.5 %, a side stream chosen before the others
+    came to life 27 % of a micro-step (LABNOTES 9)."""
+    tr_, model, _ = _build("pickscore", train_d=False)
+    main = torch.cuda.current_stream()
+    roll = tr_._rollout_stream_list
+    assert len(roll) == 2 and roll[0].cuda_stream != roll[1].cuda_stream and all(r.cuda_stream != main.cuda_stream for r in roll)
+    assert [s.cuda_stream for s in tr_.pipe.vae._side[main.cuda_stream]] == [roll[0].cuda_stream]
+    assert model._wgrad_stream.cuda_stream == roll[-1].cuda_stream
+    a = tr_.run_epoch()                                            # the schedule still runs (two groups in flight, one decode stream each) ...
+    assert a["phase"] == "G" and torch.isfinite(model.params).all()
+    assert tr_.pipe.vae.two_streams is True                        # ... and hands the decoder's split back afterwards
+    tr1, model1, _ = _build("pickscore", train_d=False)
+    tr1.cfg.sample.groups_in_flight = 1
+    b = tr1.run_epoch()
+    assert b["phase"] == "G"
+
+
 def test_bench_self_spawn_path_at_world_1():
     """`bench.py --spawn` takes the launcher path a plain `python bench.py --gpus N` takes for N > 1 (re-exec under
     torch.distributed.run, RCCL process group, all-reduce of ones) on this one-GPU box."""
