@@ -231,6 +231,13 @@ class AutoencoderKLDecoder:
         d = self.__dict__.get("_cdesc")
         if d is not None:
             return d
+        with self._side_lock:            # (decodes start from several rollout threads: one builder, and the host arrays it made stay alive)
+            return self._c_desc_build()
+
+    def _c_desc_build(self):
+        d = self.__dict__.get("_cdesc")
+        if d is not None:
+            return d
         import ctypes
         from . import _lib
         w, cfg = self.w, self.cfg
@@ -275,7 +282,8 @@ class AutoencoderKLDecoder:
         d.up_resnets, d.upsamplers = ctypes.cast(ups, ctypes.POINTER(_lib.VaeResnet)), ctypes.cast(samp, ctypes.POINTER(_lib.VaeConv))
         self._czero = ops.zero_page(self.device)
         d.zero_page = self._czero.data_ptr()
-        self._cdesc, self._cdesc_arrays = d, (ups, samp)
+        self._cdesc_arrays = (ups, samp)
+        self._cdesc = d
         return d
 
     def _decode_x3_chain_c(self, latents):
