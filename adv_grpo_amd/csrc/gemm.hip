@@ -254,6 +254,28 @@ struct ExperimentKnobs {
 static const ExperimentKnobs& knobs() { static ExperimentKnobs k; return k; }
 #endif
 
+static int cu_count() {   // MI355X: 256; asked once (a host without a device, e.g. a build box calling advgrpo_gemm_variant, gets 256)
+    static const int cus = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) {
+            (void)hipGetLastError();
+            return 256;
+        }
+        return prop.multiProcessorCount;
+    }();
+    return cus;
+}
+
+static bool small_m_off() {
+#ifdef ADVGRPO_EXPERIMENTS
+    static const bool off = [] { const char* e = getenv("ADVGRPO_GEMM_SMALLM"); return e && atoi(e) == 0; }();
+    return off;
+#else
+    return false;
+#endif
+}
+
 static int gemm_variant(int M, int N, int K, int batch, int conv, int plain) {   // batch includes the split-K factor
     if (N <= 64) return conv ? 5 : 1;
 #ifdef ADVGRPO_EXPERIMENTS
@@ -270,9 +292,20 @@ static int gemm_variant(int M, int N, int K, int batch, int conv, int plain) {  
     // Wide Linears (M >= 8192 rows, N >= 1024): the 256x256 eight-phase kernel; where its preconditions fail
     // (gemm8p_ok), the 192x128 two-stage tile (80 KB of LDS: still two workgroups per CU, 17 % fewer L2->LDS bytes per
     // flop than 128x128), chosen from in-situ runs of the whole rollout step with one shape forced to each candidate.
-    (void)K;
     if (plain && M >= 8192 && N >= 1024 && batch == 1) return 30;
     if (plain && M >= 8192 && N >= 1024) return 26;
+    if (plain && batch == 1 && M >= 1024 && K >= 1024 && !small_m_off()) {
+        // A reward tower's Linears (CLIP ViT-H: 8 images x 257 tokens = 2056 rows) are one partial round of the chip: count
+        // workgroup slots (two workgroups per CU).  Measured at 2056 / 4112 rows (profiles/r6_vit_tower.txt): a ragged
+        // second round of 128x128 tiles costs more than one round of 192x128 tiles (FC1: 680 -> 440 tiles, 53 -> 45 us), and a
+        // launch that fills under half the slots runs faster as twice as many 128x64 tiles (out-proj / FC2: 170 -> 340 tiles,
+        // 20.7 -> 19.0 and 59.1 -> 52.9 us).
+        const long slots = 2L * cu_count();
+        const long rows128 = (M + 127) / 128, rows192 = (M + 191) / 192, cols = (N + 127) / 128;
+        const long t128 = rows128 * cols, t192 = rows192 * cols;
+        if (t128 * 2 <= slots) return 1;
+        if (t128 > slots && 3 * ((t192 + slots - 1) / slots) <= 2 * ((t128 + slots - 1) / slots)) return 26;
+    }
     return plain ? 15 : 0;
 }
 
@@ -297,7 +330,7 @@ static int gemm_prepare(GemmParams& p) {
     if (knobs().fn == p.N && knobs().fk == p.K && !p.conv && p.splitk == 1 && p.M >= 8192) variant = knobs().fv;
 #endif
     if (variant == 30 && !gemm8p_ok(p)) variant = p.M >= 8192 && p.N >= 1024 ? 26 : 15;
-    if (p.rms_w && variant == 27) variant = 15;   // the fused QK-norm needs 64-wide wave tiles (one head per wave row)
+    if (p.rms_w && (variant == 27 || variant == 1)) variant = 15;   // the fused QK-norm needs 64-wide wave tiles (one head per wave row)
     if (p.conv) {
         ADVGRPO_CHECK(p.Cin % 64 == 0 && p.K == 9 * p.Cin && p.zero_page && p.batch == 1,
                       "conv3x3: need Cin %% 64 == 0, K == 9*Cin, a zero page and batch 1 (Cin=%d K=%d)", p.Cin, p.K);
