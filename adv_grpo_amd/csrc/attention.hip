@@ -238,6 +238,246 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Short sequences with the whole K / V of a (batch, head) resident in LDS: the CLIP ViT-H vision tower of the PickScore
+// scorer (257 tokens, 16 heads x 80; pickscore_scorer.py:40-44 -> transformers' CLIPAttention).  The tiled kernel above walks
+// 5 key tiles with a global load -> register -> LDS round trip and a barrier per tile while 1-2 workgroups per CU have
+// nothing to hide that latency behind (26 us for 2.7 GFLOP: profiles/r6_vit_tower.txt).  Here a workgroup requests every K / V
+// row (and its Q fragments) at once, waits once, and its waves then run their 32-query chunks over the resident tiles with
+// no further barrier.  Two workgroups per (batch, head) -- the two halves of the query chunks, neighbours in the XCD-local
+// order so the second one finds K / V in L2 -- fill the 256 CUs once at 8 images x 16 heads.  K rows keep the 208-byte
+// pitch of the tiled kernel (16 rows of a ds_read_b128 fragment on 16 different 16-byte slots); V rows are packed at 160
+// bytes: the 8 rows x 32 bytes a ds_read_b64_tr_b16 lane group touches then tile the 256 bytes of the banks exactly
+// (0,160,64,224,128,32,192,96), where the padded pitch put rows r and r + 5 on one slot.
+// Same arithmetic in the same order as attention_fwd_kernel<80> (key blocks past the last key are skipped: they add zeros).
+constexpr int RES_MAXT = 5;        // resident key tiles of ATT_KB rows (Skv <= 320)
+constexpr int RES_MAXC = 2;        // query chunks per wave
+constexpr int RES_WAVES = 8;       // waves per workgroup: two per SIMD, so one wave's softmax (VALU) runs beside the other's MFMAs
+constexpr int RES_NQB = 1;         // 16-query blocks per chunk: 257 rows = 17 chunks over 2 x 8 waves (one wave takes two)
+constexpr int RES_THREADS = RES_WAVES * 64;
+constexpr int RES_MAX_SQ = 2 * RES_WAVES * RES_MAXC * RES_NQB * 16;   // 512
+
+template <int HD>
+__global__ __launch_bounds__(RES_THREADS) void attention_fwd_resident_kernel(const AttnParams p) {
+    static_assert(HD % 16 == 0, "head dim must be a multiple of 16");
+    constexpr int KS = (HD + 31) / 32, DB = HD / 16, CPR = HD / 8;
+    constexpr int KP = KS * 32 + 8, VP = HD;                       // LDS row pitches in elements
+    constexpr int PADC = (KS * 32 - HD) / 8;                       // zero chunks behind a K row
+    constexpr int NQB = RES_NQB, QC = NQB * 16;                    // queries per chunk
+    constexpr int NCH = (RES_MAXT * ATT_KB * CPR + RES_THREADS - 1) / RES_THREADS;     // staging chunks per thread
+    extern __shared__ __attribute__((aligned(16))) char res_smem[];
+    const int nt = (p.Skv + ATT_KB - 1) / ATT_KB;
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(res_smem);
+    bf16_t* Vs = Ks + RES_MAXT * ATT_KB * KP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, t = lane & 15;
+    int half, h, b;
+    xcd_local_bh(2, p.H, p.nwg, p.xcd_local, half, h, b);
+    const int nchunks = (p.Sq + QC - 1) / QC;
+    const int c_lo = half ? nchunks / 2 : 0, c_hi = half ? nchunks : nchunks / 2;
+
+    const bf16_t* qp = p.q + (int64_t)b * p.bsq + h * HD;
+    const bf16_t* kp = p.k + (int64_t)b * p.bsk + h * HD;
+    const bf16_t* vp = p.v + (int64_t)b * p.bsv + h * HD;
+
+    // ---- Q fragments of this wave's chunks first (B operand: lane = query t, 8 consecutive d at ks*32 + g*8) ...
+    bf16x8_t qf[RES_MAXC][NQB][KS];
+#pragma unroll
+    for (int c = 0; c < RES_MAXC; ++c) {
+        const int chunk = c_lo + wave + c * RES_WAVES;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            int qr = chunk * QC + qb * 16 + t;
+            qr = qr < p.Sq ? qr : p.Sq - 1;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks * 32 + g * 8 < HD && chunk < c_hi)
+                    qf[c][qb][ks] = *reinterpret_cast<const bf16x8_t*>(qp + (int64_t)qr * p.ldq + ks * 32 + g * 8);
+                else
+                    qf[c][qb][ks] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+    }
+    // ---- ... then every K / V row of the head: all requests in flight together, one wait, one barrier.  The chunk count is the
+    // compile-time maximum (rows past Skv re-read the last row and are masked or never read): predicated staging registers
+    // end up in scratch with a wait per chunk.
+    {
+        constexpr int TOTAL = RES_MAXT * ATT_KB * CPR;
+        static_assert(NCH == 7, "the staging below is written out for 7 chunks per thread (5 tiles x 64 rows x 10 chunks / 512 threads)");
+        auto src = [&](const bf16_t* base, int64_t ld, int i) {
+            const int c = min(tid + i * RES_THREADS, TOTAL - 1);
+            int r = c / CPR;
+            r = r < p.Skv ? r : p.Skv - 1;
+            return *reinterpret_cast<const uint4*>(base + (int64_t)r * ld + (c % CPR) * 8);
+        };
+        auto dst = [&](bf16_t* base, int pitch, int i, const uint4& v) {
+            const int c = min(tid + i * RES_THREADS, TOTAL - 1);       // (the clamped tail writes the last chunk again: same bytes)
+            *reinterpret_cast<uint4*>(base + (c / CPR) * pitch + (c % CPR) * 8) = v;
+        };
+        // (named values, not arrays: with a scheduling fence between the requests and the LDS writes the compiler keeps staging ARRAYS in scratch)
+#define RES_LD(i) const uint4 k##i = src(kp, p.ldk, i), v##i = src(vp, p.ldv, i);
+#define RES_ST(i) dst(Ks, KP, i, k##i); dst(Vs, VP, i, v##i);
+        RES_LD(0) RES_LD(1) RES_LD(2) RES_LD(3) RES_LD(4) RES_LD(5) RES_LD(6)
+        __builtin_amdgcn_sched_barrier(0);   // every request issued before the first LDS write (else: load, wait, write, 7 times over)
+        if constexpr (PADC > 0) {
+            for (int i = tid; i < RES_MAXT * ATT_KB * PADC; i += RES_THREADS)
+                *reinterpret_cast<uint4*>(Ks + (i / PADC) * KP + HD + (i % PADC) * 8) = uint4{0, 0, 0, 0};
+        }
+        RES_ST(0) RES_ST(1) RES_ST(2) RES_ST(3) RES_ST(4) RES_ST(5) RES_ST(6)
+#undef RES_LD
+#undef RES_ST
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int c = 0; c < RES_MAXC; ++c) {
+        const int chunk = c_lo + wave + c * RES_WAVES;
+        if (chunk >= c_hi) continue;                 // wave-uniform
+        const int q0 = chunk * QC;
+        f32x4 o[DB][NQB];
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int j = 0; j < NQB; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float m_run[NQB], l_run[NQB];
+#pragma unroll
+        for (int j = 0; j < NQB; ++j) { m_run[j] = -INFINITY; l_run[j] = 0.f; }
+
+        for (int it = 0; it < nt; ++it) {
+            const int kv0 = it * ATT_KB;
+            const bf16_t* Kt = Ks + kv0 * KP;
+            const bf16_t* Vt = Vs + kv0 * VP;
+            const int nkb = min(4, (p.Skv - kv0 + 15) >> 4);     // 16-key blocks of this tile that hold a key (wave-uniform)
+
+            // ---- S^T[key][q] = K Q^T
+            f32x4 s[4][NQB];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NQB; ++j) s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    if (kb < nkb) {
+                        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Kt + (kb * 16 + t) * KP + ks * 32 + g * 8);
+#pragma unroll
+                        for (int qb = 0; qb < NQB; ++qb)
+                            s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[c][qb][ks], s[kb][qb], 0, 0, 0);
+                    }
+                }
+            }
+            // lane holds S[key = kv0 + kb*16 + g*4 + r][query = q0 + qb*16 + t]
+            if (kv0 + ATT_KB > p.Skv) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (kv0 + kb * 16 + g * 4 + r >= p.Skv) s[kb][qb][r] = -INFINITY;
+            }
+            // ---- online softmax (base-2), per query block
+            bf16x8_t pf[NQB][2];  // [qb][key pair]
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[qb], mx * p.scale_log2e);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
+                m_run[qb] = m_new;
+                float psum = 0.f;
+                float pv[4][4];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(s[kb][qb][r] * p.scale_log2e - m_use);
+                        pv[kb][r] = e;
+                        psum += e;
+                    }
+                l_run[qb] = l_run[qb] * alpha + psum;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) o[db][qb] *= alpha;
+#pragma unroll
+                for (int kpair = 0; kpair < 2; ++kpair) {
+                    bf16x8_t f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        f[r] = (__bf16)pv[2 * kpair][r];
+                        f[4 + r] = (__bf16)pv[2 * kpair + 1][r];
+                    }
+                    pf[qb][kpair] = f;
+                }
+            }
+            // ---- O^T[d][q] += V^T P^T ; A operand = V^T via transpose reads
+#pragma unroll
+            for (int kpair = 0; kpair < 2; ++kpair) {
+                if (2 * kpair < nkb) {
+#pragma unroll
+                    for (int db = 0; db < DB; ++db) {
+                        const bf16_t* a0 = Vt + ((2 * kpair) * 16 + g * 4 + (t >> 2)) * VP + db * 16 + (t & 3) * 4;
+                        const bf16_t* a1 = a0 + 16 * VP;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
+                        typedef __attribute__((ext_vector_type(8))) short s16x8;
+                        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, both);
+#pragma unroll
+                        for (int qb = 0; qb < NQB; ++qb)
+                            o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][kpair], o[db][qb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue: normalise and store bf16x4 (query t, d = db*16 + g*4 .. +3)
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            float l = l_run[qb];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            const int qi = q0 + qb * 16 + t;
+            if (qi >= p.Sq) continue;
+            if (p.lse && g == 0) p.lse[((int64_t)b * p.H + h) * p.Sq + qi] = m_run[qb] + __builtin_amdgcn_logf(l);
+            bf16_t* op = p.o + (int64_t)b * p.bso + (int64_t)qi * p.ldo + h * HD + g * 4;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const f32x4 v = o[db][qb] * inv;
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                *reinterpret_cast<uint2*>(op + db * 16) = pk;
+            }
+        }
+    }
+}
+
+static int attention_fwd_resident_launch(AttnParams p, int B, hipStream_t s) {
+    constexpr int HD = 80, KP = 104, VP = 80;
+    const size_t lds = (size_t)RES_MAXT * ATT_KB * (KP + VP) * sizeof(bf16_t);      // 115 KiB: one workgroup per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        ADVGRPO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_resident_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          RES_MAXT * ATT_KB * (KP + VP) * (int)sizeof(bf16_t)) == hipSuccess,
+                      "attention: cannot raise the dynamic LDS limit of the resident kernel");
+        attr_set = true;
+    }
+    p.nqb = 2;
+    p.nwg = 2 * p.H * B;
+    hipLaunchKernelGGL(attention_fwd_resident_kernel<HD>, dim3((unsigned)p.nwg), dim3(RES_THREADS), lds, s, p);
+    ADVGRPO_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Head dim 64, LDS-DMA variant: K/V tiles go HBM -> LDS with global_load_lds_dwordx4 into a 3-slot ring and stay
 // in flight across the workgroup barrier (counted s_waitcnt vmcnt + raw s_barrier), so a tile is requested two
 // iterations before it is consumed and no VGPRs are spent on staging.  The padded pitch of the register-staged
@@ -499,11 +739,12 @@ int attention_fwd(const AttnParams& p_in, int B, int head_dim, hipStream_t s) {
     ADVGRPO_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0,
                   "attention: row pitches must keep 16-byte (q,k,v) / 8-byte (o) alignment");
     ADVGRPO_CHECK(!p.bias || head_dim == 64, "attention: the score bias is implemented for head dim 64");
-    int use_glds = 1, xcd_local = 1, use_pipe = 1;
+    int use_glds = 1, xcd_local = 1, use_pipe = 1, use_resident = 1;
 #ifdef ADVGRPO_EXPERIMENTS   // A/B knobs of the experiments build only (the product library reads no environment)
     { const char* e = getenv("ADVGRPO_ATTN_REGSTAGE"); if (e && atoi(e)) use_glds = 0; }
     { const char* e = getenv("ADVGRPO_ATTN_NO_XCD"); if (e && atoi(e)) xcd_local = 0; }
     { const char* e = getenv("ADVGRPO_ATTN_NO_PIPE"); if (e && atoi(e)) use_pipe = 0; }
+    { const char* e = getenv("ADVGRPO_ATTN_NO_RESIDENT"); if (e && atoi(e)) use_resident = 0; }
 #endif
     p.nqb = (p.Sq + ATT_QB - 1) / ATT_QB;
     const int64_t nwg = (int64_t)p.nqb * p.H * B;
@@ -522,6 +763,8 @@ int attention_fwd(const AttnParams& p_in, int B, int head_dim, hipStream_t s) {
     if (head_dim == 64 && use_glds && o16 && p.bias) hipLaunchKernelGGL(attention_fwd_glds_kernel<true>, grid, dim3(256), 0, s, p);
     else if (head_dim == 64 && use_glds && o16) hipLaunchKernelGGL(attention_fwd_glds_kernel<false>, grid, dim3(256), 0, s, p);
     else if (head_dim == 64) hipLaunchKernelGGL(attention_fwd_kernel<64>, grid, dim3(256), 0, s, p);
+    else if (use_resident && !p.causal && !p.bias && p.Skv <= RES_MAXT * ATT_KB && p.Sq <= RES_MAX_SQ && (int64_t)2 * p.H * B < (1ll << 31))
+        return attention_fwd_resident_launch(p, B, s);       // the CLIP ViT-H vision tower (257 tokens): K / V of a head resident in LDS
     else hipLaunchKernelGGL(attention_fwd_kernel<80>, grid, dim3(256), 0, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;

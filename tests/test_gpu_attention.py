@@ -33,6 +33,26 @@ def test_attention_matches_fp32_reference(B, H, Sq, Skv):
     assert (out.float() - ref).abs().mean().item() < 2e-3
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv", [(8, 16, 257, 257), (2, 16, 50, 50), (1, 4, 300, 320), (3, 2, 512, 65), (2, 3, 1, 257),
+                                       (1, 2, 513, 257), (1, 2, 257, 321), (2, 16, 577, 577)])
+def test_attention_head_dim_80_matches_fp32_reference(B, H, Sq, Skv):
+    """CLIP ViT-H's vision tower (16 heads x 80): the LDS-resident kernel (Skv <= 320, Sq <= 512: 257 tokens at 224^2) and the tiled
+    one behind it (the last three shapes), ragged tails in both directions, the log-sum-exp output."""
+    from adv_grpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(Sq * 7 + Skv)
+    D, S = 80, max(Sq, Skv)
+    qkv = torch.randn(B, S, 3 * H * D, device="cuda", generator=g).to(torch.bfloat16)
+    q, k, v = qkv[:, :Sq, :H * D], qkv[:, :Skv, H * D:2 * H * D], qkv[:, :Skv, 2 * H * D:]
+    lse = torch.empty(B, H, Sq, dtype=torch.float32, device="cuda")
+    out = ops.attention(q, k, v, H, lse=lse)
+    ref = _ref(q, k, v, H)
+    assert (out.float() - ref).abs().max().item() < 2e-2
+    assert (out.float() - ref).abs().mean().item() < 2e-3
+    qf, kf = (x.float().view(B, -1, H, D).transpose(1, 2) for x in (q, k))
+    ref_lse = torch.logsumexp(qf @ kf.transpose(-1, -2) * D ** -0.5, -1) * 1.4426950408889634      # base 2
+    assert (lse - ref_lse).abs().max().item() < 2e-2
+
+
 def test_attention_online_softmax_rescale_is_exercised():
     """Spike one key per query late in the sequence so the running max jumps in a later tile."""
     from adv_grpo_amd import ops
