@@ -100,3 +100,19 @@ def test_header_is_plain_c_and_struct_layouts_match_the_ctypes_mirrors(tmp_path)
         assert got[(cname, "size")] == ctypes.sizeof(cls), (cname, got[(cname, "size")], ctypes.sizeof(cls))
         for fname, _ in cls._fields_:
             assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_gemm_dispatch_counts_workgroup_slots_for_a_reward_towers_rows():
+    """advgrpo_gemm_variant is host logic (no launch): the wide Linears of the MMDiT take the eight-phase kernel (30), a full round of
+    128 x 128 tiles stays (15), and between 1024 and 8192 rows a launch under half a round of the 2 x 256 workgroup slots becomes
+    128 x 64 tiles (1), one that would need a ragged second round becomes 192 x 128 tiles (26) -- CLIP ViT-H at 8 x 257 rows."""
+    from adv_grpo_amd import _lib
+    lib = _lib.load()
+    v = lambda M, N, K: lib.advgrpo_gemm_variant(M, N, K, 1, 0)
+    assert v(19664, 1536, 1536) == 30 and v(16384, 6144, 1536) == 30
+    assert v(2056, 3840, 1280) == 15          # QKV: 510 tiles, one round
+    assert v(2056, 1280, 1280) == 1           # out-proj: 170 tiles -> 340 of 128 x 64
+    assert v(2056, 1280, 5120) == 1           # FC2
+    assert v(2056, 5120, 1280) == 26          # FC1: 680 tiles (1.33 rounds) -> 440 of 192 x 128
+    assert v(77, 1024, 1024) == 15 and v(1232, 768, 768) == 15      # below the rule's range: unchanged
+    assert v(512, 32, 1536) == 1 and v(32, 1536, 1536) == 2         # skinny shapes keep their narrow tiles
