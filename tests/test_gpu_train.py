@@ -839,3 +839,25 @@ def test_lora_side_path_tracks_exact_policy_change_at_full_size():
     # measured: merged 2.2 %, side 0.18 %
     assert err["side"] <= 0.01 and err["side"] < 0.5 * err["merged"] and err["merged"] <= 0.05, err
 
+
+
+def test_block_backward_c_entry_refuses_bad_arguments_without_launching():
+    """advgrpo_mmdit_block_backward's error behaviour: null arguments, a head dim other than 64, missing buffers and a short workspace are
+    error codes with a message, not launches."""
+    import ctypes
+    from adv_grpo_amd import _lib
+    lib = _lib.load()
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    d = _lib.MMDiTBlockBwdDesc()
+    assert lib.advgrpo_mmdit_block_backward(None, buf.data_ptr(), buf.numel(), None) != 0 and b"null" in lib.advgrpo_last_error()
+    d.B, d.Ni, d.Nt, d.D, d.H = 1, 16, 8, 160, 2                      # head dim 80
+    assert lib.advgrpo_mmdit_block_backward(ctypes.byref(d), buf.data_ptr(), buf.numel(), None) != 0 and b"head dim 64" in lib.advgrpo_last_error()
+    d.D = 128
+    assert lib.advgrpo_mmdit_block_backward(ctypes.byref(d), buf.data_ptr(), buf.numel(), None) != 0 and b"missing" in lib.advgrpo_last_error()
+    p = buf.data_ptr()
+    for name, _ in _lib.MMDiTBlockBwdDesc._fields_:
+        if name not in ("B", "Ni", "Nt", "D", "H", "dual", "last", "first", "mod_stride", "mod_x", "mod_c", "mod_x_prev", "mod_c_prev", "ld_att"):
+            setattr(d, name, p)
+    need = int(lib.advgrpo_mmdit_block_backward_workspace_bytes(1, 16, 8, 128, 2, 0))
+    assert need > 0
+    assert lib.advgrpo_mmdit_block_backward(ctypes.byref(d), buf.data_ptr(), need - 1, None) != 0 and b"workspace" in lib.advgrpo_last_error()

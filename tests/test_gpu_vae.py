@@ -566,3 +566,34 @@ def test_vae_decode_through_the_c_entry_is_bit_identical_to_the_python_sequencin
     dec.two_streams = False
     assert torch.equal(dec.decode_to_image(lat), imgs[True])
     assert torch.equal(dec.decode_to_image(lat.float()), dec.decode_to_image(lat.float()))     # f32 latents take the same entry
+
+
+@pytest.mark.gpu
+def test_vae_c_entry_refuses_bad_arguments_without_launching():
+    """The C entry's error behaviour: a null argument, an empty descriptor and a short or misaligned workspace come back as an error code with a
+    message (advgrpo_last_error), never as a launch."""
+    import ctypes
+    from adv_grpo_amd import _lib, synthetic
+    from adv_grpo_amd.vae import AutoencoderKLDecoder
+    from oracle import vae as o
+    lib = _lib.load()
+    empty = _lib.VaeDecoderDesc()
+    assert lib.advgrpo_vae_decode_workspace_bytes(ctypes.byref(empty)) == -1
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    assert lib.advgrpo_vae_decode(None, buf.data_ptr(), 0, buf.data_ptr(), buf.data_ptr(), buf.numel(), None) != 0
+    assert b"null" in lib.advgrpo_last_error()
+    assert lib.advgrpo_vae_decode(ctypes.byref(empty), buf.data_ptr(), 0, buf.data_ptr(), buf.data_ptr(), buf.numel(), None) != 0
+    assert b"descriptor" in lib.advgrpo_last_error()
+    cfg = o.VaeConfig()
+    dec = AutoencoderKLDecoder(synthetic.vae_decoder_weights(cfg, 3), cfg, "cuda", mode="bf16x3")
+    d = _lib.VaeDecoderDesc.from_buffer_copy(dec._c_desc())
+    d.B, d.h, d.w, d.f16_single = 1, 8, 8, 0
+    need = int(lib.advgrpo_vae_decode_workspace_bytes(ctypes.byref(d)))
+    assert need > 0
+    lat = torch.zeros(1, 16, 8, 8, dtype=torch.bfloat16, device="cuda")
+    img = torch.empty(1, 3, 64, 64, dtype=torch.float32, device="cuda")
+    ws = torch.empty(need + 256, dtype=torch.uint8, device="cuda")
+    assert lib.advgrpo_vae_decode(ctypes.byref(d), lat.data_ptr(), 1, img.data_ptr(), ws.data_ptr(), need - 1, None) != 0      # short
+    assert b"workspace" in lib.advgrpo_last_error()
+    assert lib.advgrpo_vae_decode(ctypes.byref(d), lat.data_ptr(), 1, img.data_ptr(), ws.data_ptr() + 16, need, None) != 0      # misaligned
+    assert b"workspace" in lib.advgrpo_last_error()
