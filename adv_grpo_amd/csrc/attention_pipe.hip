@@ -414,6 +414,12 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
     // probabilities in pA.
     typedef std::integral_constant<bool, true> first_t;
     typedef std::integral_constant<bool, false> steady_t;
+#ifndef ATT_PRIO
+#define ATT_PRIO 0      // experiment (scripts/probes/r6_job31.sh): 1 / 2 = s_setprio 1 / 3 over the main loop, 3 = static priority by workgroup parity: no gain, see LABNOTES 9
+#endif
+    if constexpr (ATT_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    if constexpr (ATT_PRIO == 2) __builtin_amdgcn_s_setprio(3);
+    if constexpr (ATT_PRIO == 3) { if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(1); }
     if (nt >= 2) {
         iteration(0, first_t{}, 0, sA, sB, pB, pA);
         int j = 1;
@@ -439,6 +445,7 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_pipe_kernel(const AttnPa
 
     // ---- tail: P V of tile nt - 2, probabilities of the (possibly ragged) last tile, its P V
     ATT_STAMP(4)
+    if constexpr (ATT_PRIO != 0) __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (nt > 1) tile_pv((3 + (nt - 2) % 3) * TILE_B, pA);
