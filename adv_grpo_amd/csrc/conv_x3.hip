@@ -89,25 +89,32 @@ __device__ __forceinline__ void x3_tie(bf16x8_t (&a)[N]) {
 // line, never the default.
 // DBG (experiments build only, scripts/probes/x3_decompose.sh): 1 = no DMA after the prologue, 2 = no MFMAs, 3 = fragments read
 // once -- WRONG results, used to price the three activities of the k loop against each other
-template <int X3_WM, int X3_WN, int DBG = 0, int PIECE = 0>
+// BN (round 6): output channels per tile.  256 for the one-piece-weight forms where Cout is a multiple of 256 and the launch is many rounds of
+// tiles deep: a wave tile of 48 x 128 (96 MFMAs per wave behind one barrier per k-tile instead of 48; the same pixel stage feeds twice the
+// channels: 26 % fewer L2 -> LDS bytes and 30 % fewer fragment bytes per flop); the weight ring then holds three one-piece stages of 32 KiB
+// (the same 146 KiB).  Same k order and product order per output element as BN = 128: the same bits.
+template <int X3_WM, int X3_WN, int DBG = 0, int PIECE = 0, int BN = X3_BN>
 __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const GemmParams p) {
     constexpr bool F16 = PIECE != 0;                  // one-piece weights, two products (1: fp16 pieces; 2: bf16 pieces; 3: fp16 pieces, hi product only)
     constexpr bool X1 = PIECE == 3;
     constexpr int WPI = F16 ? 1 : 2;                  // weight pieces per tap (DMA instructions per 8 output channels)
-    constexpr int NW = X3_WM * X3_WN, TM = X3_BM / X3_WM, TN = X3_BN / X3_WN, FM = TM / 16, FN = TN / 16;
+    constexpr int NW = X3_WM * X3_WN, TM = X3_BM / X3_WM, TN = BN / X3_WN, FM = TM / 16, FN = TN / 16;
+    static_assert(BN == X3_BN || PIECE != 0, "the wide tile exists for the one-piece-weight forms");
+    constexpr int WPIECE = BN * X3_BK * 2;            // one weight piece of one tap: BN output channels x 64 input channels
+    constexpr int WSTAGE = (BN == X3_BN ? 2 : 1) * WPIECE;
     constexpr int XI = (X3_XINST + NW - 1) / NW;     // pixel-piece DMA instructions per wave (the last one on some waves only)
-    constexpr int WI = X3_BN / 8 / NW;               // weight-piece DMA instructions per wave
+    constexpr int WI = BN / 8 / NW;                  // weight-piece DMA instructions per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / X3_WN, wn = wave % X3_WN;
     const int C = p.Cin / 3;                          // logical channels; pixel pitch of the activations = 3C elements
 
-    const int tiles_n = (p.N + X3_BN - 1) / X3_BN, tiles_m = (p.M + X3_BM - 1) / X3_BM;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + X3_BM - 1) / X3_BM;
     const int swz = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     int tile_m, tile_n;
     tile_coords(swz, tiles_m, tiles_n, 4, tile_m, tile_n);
-    const int m0 = tile_m * X3_BM, n0 = tile_n * X3_BN;
+    const int m0 = tile_m * X3_BM, n0 = tile_n * BN;
 
     // ---- per-lane DMA sources.  LDS row j of a pixel piece holds output pixel m0 - 1 + j displaced by the group's dy
     const int lrow = lane >> 3, schunk = (lane & 7) ^ lrow;
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
         }
     };
     auto stage_w = [&](int buf, int g, int dxi) {
-        char* base = smem + X3_XSTAGE + buf * X3_WSTAGE;
+        char* base = smem + X3_XSTAGE + buf * WSTAGE;
         const int dyi = g / slices, c0 = (g - dyi * slices) * X3_BK;
         const int tap = dyi * 3 + dxi;
 #pragma unroll
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
             char* dst = base + (wave + it * NW) * 1024;
             const bf16_t* wh = w_src[it] + (int64_t)tap * (F16 ? C : p.Cin) + c0;   // per tap [hi | lo | hi]; F16: one piece per tap
             __builtin_amdgcn_global_load_lds((x3_gptr_t)wh, (x3_lds_ptr_t)dst, 16, 0, 0);
-            if constexpr (!F16) __builtin_amdgcn_global_load_lds((x3_gptr_t)(wh + C), (x3_lds_ptr_t)(dst + X3_WPIECE), 16, 0, 0);
+            if constexpr (!F16) __builtin_amdgcn_global_load_lds((x3_gptr_t)(wh + C), (x3_lds_ptr_t)(dst + WPIECE), 16, 0, 0);
         }
     };
 
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
     stage_w(1, 0, 1);
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WPI * WI) : "memory");
     __builtin_amdgcn_s_barrier();
-    static_assert(FM + FN <= 15 && 3 * FN <= 15, "lgkmcnt counts at most 15 reads in flight");
+    static_assert(FM + FN <= 15 && (F16 || 3 * FN <= 15) && (!F16 || 2 * FM + FN <= 15), "lgkmcnt counts at most 15 reads in flight");
     auto product = [&](const bf16x8_t (&a)[FM], const bf16x8_t (&b)[FN]) __attribute__((always_inline)) {
         if constexpr (DBG != 2) {
 #pragma unroll
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
         static_for<3>([&](auto dxi_c) {
             constexpr int dxi = decltype(dxi_c)::value;      // k-tile kt = 3g + dxi reads weight slot dxi
             const int kt = 3 * g + dxi;
-            const uint32_t wb0 = wa[0] + dxi * X3_WSTAGE, wb1 = wa[1] + dxi * X3_WSTAGE;
+            const uint32_t wb0 = wa[0] + dxi * WSTAGE, wb1 = wa[1] + dxi * WSTAGE;
             auto read_x = [&](uint32_t a, bf16x8_t (&h)[FM], bf16x8_t (&l)[FM], bool hi, bool lo) __attribute__((always_inline)) {
                 if (hi) static_for<FM>([&](auto i) { x3_lds_read<decltype(i)::value * 2048>(h[decltype(i)::value], a); });
                 if (lo) static_for<FM>([&](auto i) { x3_lds_read<X3_XPIECE + decltype(i)::value * 2048>(l[decltype(i)::value], a); });
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
                 static_for<FN>([&](auto j) { x3_lds_read<decltype(j)::value * 2048>(b[decltype(j)::value], a); });
             };
             auto read_wl = [&](uint32_t a, bf16x8_t (&b)[FN]) __attribute__((always_inline)) {
-                static_for<FN>([&](auto j) { x3_lds_read<X3_WPIECE + decltype(j)::value * 2048>(b[decltype(j)::value], a); });
+                static_for<FN>([&](auto j) { x3_lds_read<WPIECE + decltype(j)::value * 2048>(b[decltype(j)::value], a); });
             };
             auto mask = [&](bf16x8_t (&f)[FM]) __attribute__((always_inline)) {
                 if constexpr (dxi != 1) {
@@ -429,12 +436,24 @@ __global__ __launch_bounds__(64 * X3_WM * X3_WN, 1) void conv3x3_x3_kernel(const
     gemm_epilogue_f32io<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// fewest wide (192 x 256) tiles for which the wide form is dispatched: 4 rounds of the 256 CUs (below that the coarser tile count costs more
+// in its ragged last round than the wave tile gains; measured at 256 / 1024 / 2048, profiles/r6_conv_wide_tile.txt).
+// ADVGRPO_X3_WIDE_MIN (experiments build): another threshold; a huge one = never.
+int64_t x3_wide_min_tiles() {
+#ifdef ADVGRPO_EXPERIMENTS
+    static const int64_t v = getenv("ADVGRPO_X3_WIDE_MIN") ? atoll(getenv("ADVGRPO_X3_WIDE_MIN")) : 1024;
+    return v;
+#else
+    return 1024;
+#endif
+}
+
 }  // namespace
 
 // fp16 pair activations x one-piece fp16 weights: p as filled by advgrpo_conv3x3_nhwc_f16x2 (Cin = 3C, lda = 3C, ldw = 9C, f32_io)
 int conv3x3_f16x2_launch(const GemmParams& p, hipStream_t s, int form /* 0: f16x2, 1: bf16x2, 2: f16x1 */) {
     ADVGRPO_CHECK(p.conv && p.f32_io && p.Cin % 192 == 0 && p.zero_page && p.batch == 1 && p.splitk == 1, "conv3x3_f16x2: bad parameter block");
-    constexpr int WM = X3_GRID_M, WN = X3_GRID_N;
+    constexpr int WM = X3_GRID_M, WN = X3_GRID_N, WIDE = 2 * X3_BN;
     static bool attr_set = false;
     if (!attr_set) {
         ADVGRPO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<WM, WN, 0, 1>),
@@ -442,14 +461,33 @@ int conv3x3_f16x2_launch(const GemmParams& p, hipStream_t s, int form /* 0: f16x
                       hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<WM, WN, 0, 2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) == hipSuccess &&
                       hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<WM, WN, 0, 3>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) == hipSuccess &&
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<WM, WN, 0, 1, WIDE>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) == hipSuccess &&
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<WM, WN, 0, 2, WIDE>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) == hipSuccess &&
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<WM, WN, 0, 3, WIDE>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) == hipSuccess,
                       "conv3x3_f16x2: %d bytes of LDS refused", X3_LDS);
         attr_set = true;
     }
+    static_assert(X3_XSTAGE + 3 * WIDE * X3_BK * 2 <= X3_LDS, "three one-piece weight stages of the wide tile fit the same LDS");
+    // the wide tile where the launch stays several rounds deep (profiles/r6_conv_wide_tile.txt): Cout % 256 == 0 and >= x3_wide_min_tiles() wide tiles
+    const int64_t tiles_m = (p.M + X3_BM - 1) / X3_BM;
+    bool wide = p.N % WIDE == 0 && tiles_m * (p.N / WIDE) >= x3_wide_min_tiles();
+    const dim3 block(64 * WM * WN);
+    if (wide) {
+        const dim3 grid((unsigned)(tiles_m * (p.N / WIDE)));
+        if (form == 1) hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, 2, WIDE>), grid, block, X3_LDS, s, p);
+        else if (form == 2) hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, 3, WIDE>), grid, block, X3_LDS, s, p);
+        else hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, 1, WIDE>), grid, block, X3_LDS, s, p);
+        ADVGRPO_LAUNCH_CHECK();
+        return 0;
+    }
     const int tiles = ((p.M + X3_BM - 1) / X3_BM) * ((p.N + X3_BN - 1) / X3_BN);
-    if (form == 1) hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, 2>), dim3(tiles), dim3(64 * WM * WN), X3_LDS, s, p);
-    else if (form == 2) hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, 3>), dim3(tiles), dim3(64 * WM * WN), X3_LDS, s, p);
-    else hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, 1>), dim3(tiles), dim3(64 * WM * WN), X3_LDS, s, p);
+    if (form == 1) hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, 2>), dim3(tiles), block, X3_LDS, s, p);
+    else if (form == 2) hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, 3>), dim3(tiles), block, X3_LDS, s, p);
+    else hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, 0, 1>), dim3(tiles), block, X3_LDS, s, p);
     ADVGRPO_LAUNCH_CHECK();
     return 0;
 }

@@ -304,7 +304,9 @@ def test_vae_decode_is_bitwise_reproducible():
 
 
 @pytest.mark.parametrize("B,H,W,C,Co,up,gn", [(2, 16, 24, 128, 128, False, True), (1, 33, 20, 256, 128, False, True),
-                                              (2, 8, 12, 512, 512, True, False), (1, 16, 16, 64, 256, False, False)])
+                                              (2, 8, 12, 512, 512, True, False), (1, 16, 16, 64, 256, False, False),
+                                              # >= 1024 tiles of 192 x 256: the wide tile of round 6 (ragged last pixel tile; two column tiles + upsample)
+                                              (1, 448, 448, 128, 256, False, True), (1, 224, 224, 64, 512, True, False)])
 def test_conv3x3_f16x2_vs_fp64_conv(B, H, W, C, Co, up, gn):
     """The two-product convolution for fp16-exact weights (include/advgrpo.h "f16x2"): fp16-pair activations (from the
     GroupNorm + SiLU producer, or the plain split with the 2^-4 pre-scale of un-normalised inputs) x one-piece fp16 weights
@@ -445,7 +447,8 @@ def test_groupnorm_statistics_with_a_mean_far_from_zero(offset, tol):
         assert err < tol, (offset, ratio, err)
 
 
-@pytest.mark.parametrize("B,H,W,C,Co,up", [(3, 24, 24, 128, 256, False), (2, 16, 16, 512, 512, True), (5, 40, 24, 256, 128, False)])
+@pytest.mark.parametrize("B,H,W,C,Co,up", [(3, 24, 24, 128, 256, False), (2, 16, 16, 512, 512, True), (5, 40, 24, 256, 128, False),
+                                           (2, 320, 320, 128, 256, False)])       # (the last: the wide 192 x 256 tile's epilogue)
 def test_groupnorm_statistics_from_the_conv_epilogue(B, H, W, C, Co, up):
     """advgrpo_conv3x3_nhwc_f16x2's gn_partial: {sum, sum of squares} per block of 16 pixels x 4 output channels (HW is not a
     multiple of the kernel's 192-pixel tile in any of these cases) -- against the sums of the stored output, and the
